@@ -1,0 +1,657 @@
+"""CPU oracle for the ASVGP hot path  --  TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+A plain numpy/scipy fp64 restatement of the reference algorithm for the path named by
+BASELINE.json:north_star.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this module; the product package (asvgp_amd/) never does.
+
+Parity pinning: this oracle is checked (tests/test_oracle_golden.py) against fixtures
+produced by the reference's own basis.py / inducing_features.py / utils.py / kronecker.py
+(tests/golden/make_golden.py) and against the only numeric golden in the reference,
+the notebook printout ELBO = -60.8356263428725 (experiments/snelson/example.ipynb:78).
+The banded_matrices ops (C++/TF custom ops, wheel banded_matrices-0.0.6, branch
+awav/fix-banded-hashable-tensor; README.md:38,49) are NOT in /root/reference: their
+published semantics are restated here and anchored on the reference's call sites
+(gpr.py:56-75) - every op is uniquely defined linear algebra (Cholesky, inverse, product).
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+from fractions import Fraction
+from math import comb, factorial
+
+import numpy as np
+import scipy.sparse as sp
+
+# --------------------------------------------------------------------------------------
+# Cardinal B-spline pieces (basis.py:133-136,188-192,274-280,397-403,528-535,668-676)
+# --------------------------------------------------------------------------------------
+
+def piece_coeffs(order, deriv=0):
+    """Exact monomial coefficients (in t) of the `deriv`-th t-derivative of the order+1 pieces
+    of the cardinal B-spline N_k on knots 0..k+1:  piece i (i=0..k) is N_k(t+i), t in [0,1].
+    The reference's b1..b_{k+1} are these pieces written in (X, u, delta) with t=(X-u)/delta
+    (e.g. basis.py:276-279: b1 = t^3/6 ... b4 = (1-t)^3/6).  Returns list[k+1] of list[k+1] Fractions,
+    coefficient c[i][p] multiplying t^p."""
+    k = order
+    out = []
+    for i in range(k + 1):
+        c = [Fraction(0)] * (k + 1)
+        # N_k(s) = 1/k! sum_j (-1)^j C(k+1,j) (s-j)_+^k ; on piece i: s=t+i, j=0..i
+        for j in range(i + 1):
+            sgn = -1 if j % 2 else 1
+            for p in range(k + 1):  # (t + (i-j))^k binomial expansion
+                c[p] += Fraction(sgn * comb(k + 1, j) * comb(k, p) * (i - j) ** (k - p), factorial(k))
+        for _ in range(deriv):
+            c = [c[p] * p for p in range(1, len(c))] + [Fraction(0)]
+        out.append(c)
+    return out
+
+
+def piece_values(order, t, deriv=0):
+    """(order+1, n) array: N_k^(deriv)(t+i) by Horner in t (t-derivative; divide by delta^deriv for d/dx)."""
+    t = np.asarray(t, dtype=np.float64)
+    C = piece_coeffs(order, deriv)
+    out = np.empty((order + 1,) + t.shape)
+    for i, c in enumerate(C):
+        acc = np.zeros_like(t) + float(c[order])
+        for p in range(order - 1, -1, -1):
+            acc = acc * t + float(c[p])
+        out[i] = acc
+    return out
+
+
+def gram_constants(order, deriv):
+    """Per-interval rational constants int_0^1 N^(p)(t+i) N^(p)(t+i+d) dt  (the lists d0..dk of
+    basis.py:303-369 (B3), 429-503 (B4), ... without the delta^(1-2p) factor).
+    Returns list over d=0..k of list over i=0..k-d of Fractions."""
+    C = piece_coeffs(order, deriv)
+    k = order
+    lists = []
+    for d in range(k + 1):
+        lst = []
+        for i in range(k + 1 - d):
+            a, b = C[i], C[i + d]
+            tot = Fraction(0)
+            for p, ap in enumerate(a):
+                for q, bq in enumerate(b):
+                    if ap and bq:
+                        tot += ap * bq / (p + q + 1)
+            lst.append(tot)
+        lists.append(lst)
+    return lists
+
+# --------------------------------------------------------------------------------------
+# Mesh, index rule, design matrix  (basis.py:13-18, 51-80)
+# --------------------------------------------------------------------------------------
+
+def make_mesh(a, b, m, order):
+    """basis.py:17-18.  tf.linspace infers float32 from python-float endpoints and is only then cast
+    to f64; int / numpy-f64 endpoints give an exact fp64 linspace."""
+    n = m - (order - 1)
+    if type(a) is float or type(b) is float:
+        f = np.float32
+        s, e = f(a), f(b)
+        step = f((e - s) / f(n - 1))
+        mesh = (s + step * np.arange(n, dtype=f)).astype(f)
+        mesh[-1] = e
+        mesh = mesh.astype(np.float64)
+    else:
+        mesh = np.linspace(np.float64(a), np.float64(b), n)
+    return mesh, np.float64(mesh[1] - mesh[0])
+
+
+def neighbour_index(mesh, x):
+    """basis.py:58: relu(searchsorted_left(mesh, x) - 1)  -- a table search, not arithmetic."""
+    return np.maximum(np.searchsorted(mesh, x, side="left") - 1, 0).astype(np.int64)
+
+
+def evaluate_basis_coo(mesh, delta, order, m, x, deriv=0):
+    """basis.py:51-76.  Returns (rows, cols, data) in the reference's concat order:
+    piece i (i=0..order) block-concatenated, rows = idx+order-i, cols = point index."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    n = x.shape[0]
+    idx = neighbour_index(mesh, x)
+    u = mesh[idx]
+    t = (x - u) / delta
+    vals = piece_values(order, t, deriv) / (delta ** deriv)
+    rows = np.concatenate([idx + order - i for i in range(order + 1)])
+    cols = np.tile(np.arange(n, dtype=np.int64), order + 1)
+    return rows, cols, vals.reshape(-1)
+
+
+def evaluate_basis(mesh, delta, order, m, x, deriv=0, sparse=True):
+    """basis.py:51-80: CSR (m, n) design matrix Phi (sparse=True) or dense scatter (sparse=False)."""
+    rows, cols, data = evaluate_basis_coo(mesh, delta, order, m, x, deriv)
+    n = np.asarray(x).reshape(-1).shape[0]
+    if sparse:
+        return sp.csr_matrix((data, (rows, cols)), shape=(m, n))
+    out = np.zeros((m, n))
+    np.add.at(out, (rows, cols), data)
+    return out
+
+# --------------------------------------------------------------------------------------
+# Static Gram bands and boundary bands  (basis.py:31-45, 82-114)
+# --------------------------------------------------------------------------------------
+
+def make_banded_matrix(diags, m):
+    """basis.py:31-45 (pad='right'): row i = [cumsum(d_i), sum(d_i) x (m-2 len-i), reversed cumsum, i zeros]."""
+    bands = []
+    for i, diag in enumerate(diags):
+        diag = np.asarray(diag, dtype=np.float64)
+        lhs = np.cumsum(diag)
+        mid = np.repeat(np.sum(diag), m - 2 * diag.shape[0] - i)
+        bands.append(np.concatenate([lhs, mid, lhs[::-1], np.zeros(i)]))
+    return np.stack(bands, axis=0)
+
+
+def gram_band(order, deriv, delta, m):
+    """A (deriv=0), B (1), C (2), D (3): basis.py l2_*_inner_product -> _make_banded_matrix.
+    constant * delta^(1-2p), formed the way the reference forms it (c*delta, c/delta^(2p-1))."""
+    consts = gram_constants(order, deriv)
+    diags = []
+    for lst in consts:
+        if deriv == 0:
+            diags.append([float(c) * delta for c in lst])
+        else:
+            diags.append([float(c) / delta ** (2 * deriv - 1) for c in lst])
+    return make_banded_matrix(diags, m)
+
+
+def boundary_band(order, dx, delta, m):
+    """basis.py:82-114 (pad='right').  dx=0,1,2: outer product of phi^(dx)(a)[:order] with itself, placed
+    at the top-left and (the same diagonals) bottom-right corners, plus a zero last row.
+    dx=3,4 ('ggrad_none'/'none_ggrad'): rhs is evaluated at b whose first `order` rows are zero, so the
+    band is identically zero for m > 2*order+1."""
+    k = order
+    band = np.zeros((k + 1, m))
+    if dx in (3, 4):
+        return band
+    # phi^(dx)(a): idx=0, u=a, t=0; row r (r<order) holds piece i=order-r
+    v = piece_values(k, np.array([0.0]), dx)[:, 0] / (delta ** dx)
+    lhs = np.array([v[k - r] for r in range(k)])
+    mat = np.outer(lhs, lhs)
+    for i in range(k):
+        l = np.diagonal(mat, offset=i)
+        band[i, :l.shape[0]] = l
+        start = m - i - l.shape[0]
+        band[i, start:start + l.shape[0]] = l
+    return band
+
+
+STATIC_AVAILABLE = {  # basis.py:126-131,179-186,261-272,384-395,515-526,658-666
+    1: ("A", "B", "BC"),
+    2: ("A", "B", "C", "BC", "BC_grad"),
+    3: ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad"),
+    4: ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad"),
+    5: ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad"),
+    6: ("A", "B", "C", "D", "BC", "BC_grad"),
+}
+
+
+class Basis:
+    """B{order}Spline(a, b, m) (basis.py:117,170,252,372,506,649)."""
+
+    def __init__(self, order, a, b, m):
+        if order == 4 and m < 12:
+            raise NameError("Not enough basis functions m >= 12")  # basis.py:379-380
+        self.order, self.a, self.b, self.m = order, a, b, m
+        self.mesh, self.delta = make_mesh(a, b, m, order)
+        names = STATIC_AVAILABLE[order]
+        for nm, p in (("A", 0), ("B", 1), ("C", 2), ("D", 3)):
+            if nm in names:
+                setattr(self, nm, gram_band(order, p, self.delta, m))
+        for nm, dx in (("BC", 0), ("BC_grad", 1), ("BC_ggrad", 2), ("BC_ggrad_none", 3), ("BC_none_ggrad", 4)):
+            if nm in names:
+                setattr(self, nm, boundary_band(order, dx, self.delta, m))
+
+    def evaluate_basis(self, X, dx=0, sparse=True):
+        return evaluate_basis(self.mesh, self.delta, self.order, self.m, X, int(dx), sparse)
+
+# --------------------------------------------------------------------------------------
+# Kuu assembly  (inducing_features.py:12-44)
+# --------------------------------------------------------------------------------------
+
+MATERN12, MATERN32, MATERN52 = 0, 1, 2
+_S3, _S5 = np.sqrt(3.0), np.sqrt(5.0)
+
+
+def kuu_terms(kind, v, l):
+    """[(static band name, coefficient, d coefficient / d lengthscale)]  inducing_features.py:16-44."""
+    if kind == MATERN12:
+        return [("A", 1 / (2 * l * v), -1 / (2 * l * l * v)), ("B", l / (2 * v), 1 / (2 * v)),
+                ("BC", 1 / (2 * v), 0.0)]
+    if kind == MATERN32:
+        return [("A", _S3 / (4 * l * v), -_S3 / (4 * l * l * v)),
+                ("B", l / (2 * _S3 * v), 1 / (2 * _S3 * v)),
+                ("C", l ** 3 / (12 * _S3 * v), 3 * l * l / (12 * _S3 * v)),
+                ("BC", 1 / (2 * v), 0.0), ("BC_grad", l ** 2 / (2 * v), l / v)]
+    if kind == MATERN52:
+        return [("A", (3 * _S5) / (16 * l * v), -(3 * _S5) / (16 * l * l * v)),
+                ("B", (9 * l) / (16 * _S5 * v), 9 / (16 * _S5 * v)),
+                ("C", (9 * l ** 3) / (80 * _S5 * v), (27 * l * l) / (80 * _S5 * v)),
+                ("D", (3 * l ** 5) / (400 * _S5 * v), (15 * l ** 4) / (400 * _S5 * v)),
+                ("BC", 9 / (16 * v), 0.0), ("BC_grad", (3 * l ** 2) / (10 * v), (6 * l) / (10 * v)),
+                ("BC_ggrad", (9 * l ** 4) / (400 * v), (36 * l ** 3) / (400 * v)),
+                ("BC_ggrad_none", (3 * l ** 2) / (80 * v), (6 * l) / (80 * v)),
+                ("BC_none_ggrad", (3 * l ** 2) / (80 * v), (6 * l) / (80 * v))]
+    raise ValueError(kind)
+
+
+def make_Kuu(basis, kind, v, l, want_dl=False):
+    """inducing_features.py:12-44: lower band (k+1, m).  Optionally also dKuu/dl (same static bands)."""
+    K = np.zeros((basis.order + 1, basis.m))
+    dK = np.zeros_like(K)
+    for nm, c, dc in kuu_terms(kind, v, l):
+        S = getattr(basis, nm)  # AttributeError if the basis lacks the band - as in the reference
+        K = K + c * S
+        dK = dK + dc * S
+    return (K, dK) if want_dl else K
+
+# --------------------------------------------------------------------------------------
+# banded_matrices.banded op semantics (call sites gpr.py:56-75; utils.py:7-9,36-57)
+# band layout: (l+u+1, n), band[u+i-j, j] = M[i, j]
+# --------------------------------------------------------------------------------------
+
+def unpack_banded_matrix_to_dense(band, l, u):
+    band = np.asarray(band)
+    n = band.shape[1]
+    out = np.zeros((n, n), dtype=band.dtype)
+    for r in range(l + u + 1):
+        d = r - u  # i - j
+        for j in range(n):
+            i = j + d
+            if 0 <= i < n:
+                out[i, j] = band[r, j]
+    return out
+
+
+def pack_dense_matrix_to_banded(dense, l, u):
+    dense = np.asarray(dense)
+    n = dense.shape[0]
+    band = np.zeros((l + u + 1, n), dtype=dense.dtype)
+    for r in range(l + u + 1):
+        d = r - u
+        for j in range(n):
+            i = j + d
+            if 0 <= i < n:
+                band[r, j] = dense[i, j]
+    return band
+
+
+def transpose_band(band, l, u):
+    """(l,u) band of M -> (u,l) band of M^T (utils.py:8).  out[l + j - i, i] = M[i, j]."""
+    band = np.asarray(band)
+    n = band.shape[1]
+    out = np.zeros_like(band)
+    for r in range(l + u + 1):
+        d = r - u  # i-j of the source entry
+        # source entry M[i,j], i=j+d  ->  M^T[j,i]: row index in out = l + (j - i) = l - d, column i
+        j = np.arange(max(0, -d), min(n, n - d))
+        out[l - d, j + d] = band[r, j]
+    return out
+
+
+def symmetrise_band(lower, l):
+    """gpr.py:62 / utils.py:7-9: lower band (l+1, n) -> symmetric band (2l+1, n)."""
+    upper = transpose_band(lower, l, 0)
+    return np.concatenate([upper[:-1, :], lower], axis=0)
+
+
+def cholesky_band(K):
+    """gpr.py:56,73: lower-band Cholesky, column recurrence."""
+    K = np.asarray(K, dtype=np.float64)
+    k, M = K.shape[0] - 1, K.shape[1]
+    L = np.zeros_like(K)
+    for j in range(M):
+        for i in range(j, min(j + k, M - 1) + 1):
+            s = K[i - j, j]
+            for p in range(max(0, i - k), j):
+                s -= L[i - p, p] * L[j - p, p]
+            if i == j:
+                if not s > 0:
+                    raise np.linalg.LinAlgError("band not positive definite at column %d" % j)
+                L[0, j] = np.sqrt(s)
+            else:
+                L[i - j, j] = s / L[0, j]
+    return L
+
+
+def cholesky_band_jvp(K, dK):
+    """Forward-mode tangent of cholesky_band along dK (needed for d/dl tr(Kuu^-1 A))."""
+    k, M = K.shape[0] - 1, K.shape[1]
+    L = np.zeros_like(K)
+    dL = np.zeros_like(K)
+    for j in range(M):
+        for i in range(j, min(j + k, M - 1) + 1):
+            s, ds = K[i - j, j], dK[i - j, j]
+            for p in range(max(0, i - k), j):
+                s -= L[i - p, p] * L[j - p, p]
+                ds -= dL[i - p, p] * L[j - p, p] + L[i - p, p] * dL[j - p, p]
+            if i == j:
+                L[0, j] = np.sqrt(s)
+                dL[0, j] = ds / (2 * L[0, j])
+            else:
+                L[i - j, j] = s / L[0, j]
+                dL[i - j, j] = (ds - L[i - j, j] * dL[0, j]) / L[0, j]
+    return L, dL
+
+
+def inverse_from_cholesky_band(L, dL=None):
+    """gpr.py:59: lower band of (L L^T)^-1 restricted to the band (Takahashi / sparse inverse subset).
+    With dL also returns the tangent of that band."""
+    L = np.asarray(L, dtype=np.float64)
+    k, M = L.shape[0] - 1, L.shape[1]
+    S = np.zeros_like(L)
+    dS = np.zeros_like(L) if dL is not None else None
+
+    def sget(X, p, i):  # symmetric in-band read X[p,i]
+        return X[p - i, i] if p >= i else X[i - p, p]
+
+    for j in range(M - 1, -1, -1):
+        hi = min(j + k, M - 1)
+        ljj = L[0, j]
+        for i in range(hi, j - 1, -1):
+            acc = (1.0 / ljj) if i == j else 0.0
+            for p in range(j + 1, hi + 1):
+                acc -= L[p - j, j] * sget(S, p, i)
+            S[i - j, j] = acc / ljj
+            if dL is not None:
+                dacc = (-dL[0, j] / (ljj * ljj)) if i == j else 0.0
+                for p in range(j + 1, hi + 1):
+                    dacc -= dL[p - j, j] * sget(S, p, i) + L[p - j, j] * sget(dS, p, i)
+                dS[i - j, j] = (dacc - S[i - j, j] * dL[0, j]) / ljj
+    return S if dL is None else (S, dS)
+
+
+def solve_triang_mat(L, B, transpose_left=False):
+    """gpr.py:75: L^-1 B (or L^-T B) with L a lower band (k+1, M) and B dense (M, D)."""
+    L = np.asarray(L, dtype=np.float64)
+    k, M = L.shape[0] - 1, L.shape[1]
+    X = np.array(B, dtype=np.float64, copy=True)
+    if not transpose_left:
+        for i in range(M):
+            for p in range(max(0, i - k), i):
+                X[i] -= L[i - p, p] * X[p]
+            X[i] /= L[0, i]
+    else:
+        for i in range(M - 1, -1, -1):
+            for p in range(i + 1, min(i + k, M - 1) + 1):
+                X[i] -= L[p - i, i] * X[p]
+            X[i] /= L[0, i]
+    return X
+
+
+def product_band_band(left, right, left_lower_bandwidth, left_upper_bandwidth, right_lower_bandwidth,
+                      right_upper_bandwidth, result_lower_bandwidth, result_upper_bandwidth):
+    """gpr.py:60-69: banded x banded cropped to the result band (dense reference implementation)."""
+    Ld = unpack_banded_matrix_to_dense(left, left_lower_bandwidth, left_upper_bandwidth)
+    Rd = unpack_banded_matrix_to_dense(right, right_lower_bandwidth, right_upper_bandwidth)
+    return pack_dense_matrix_to_banded(Ld @ Rd, result_lower_bandwidth, result_upper_bandwidth)
+
+
+def band_sym_dot(S, A):
+    """<sym(S), sym(A)> for two lower bands = sum_j S0 A0 + 2 sum_{d>=1} S_d A_d  (= the trace gpr.py:60-70)."""
+    return float(np.sum(S[0] * A[0]) + 2.0 * np.sum(S[1:] * A[1:]))
+
+
+def band_sym_matvec(A, x):
+    """sym(A) @ x for a lower band A (k+1, M), x (M, D)."""
+    k, M = A.shape[0] - 1, A.shape[1]
+    out = A[0][:, None] * x
+    for d in range(1, k + 1):
+        out[d:] += A[d, :M - d][:, None] * x[:M - d]
+        out[:M - d] += A[d, :M - d][:, None] * x[d:]
+    return out
+
+# --------------------------------------------------------------------------------------
+# utils.py helpers
+# --------------------------------------------------------------------------------------
+
+def sparse_to_band(K_sparse, bandwidth):
+    """utils.py:24-30: main + `bandwidth` sub-diagonals, right-padded."""
+    M = K_sparse.shape[0]
+    rows = [np.asarray(K_sparse.diagonal()).reshape(-1)]
+    for i in range(1, bandwidth + 1):
+        rows.append(np.concatenate([np.asarray(K_sparse.diagonal(k=-i)).reshape(-1), np.zeros(i)]))
+    return np.stack(rows, axis=0).astype(np.float64)
+
+
+def band_to_sparse(K_lower):
+    """utils.py:32-33 (lower-triangular sparse from a lower band)."""
+    k1, M = K_lower.shape
+    return sp.spdiags(K_lower, np.arange(0, -k1, -1), M, M)
+
+# --------------------------------------------------------------------------------------
+# GPR_1d  (gpr.py:18-136)
+# --------------------------------------------------------------------------------------
+
+def sufficient_stats(basis, X, y):
+    """gpr.py:39-44, through the same steps the reference takes: CSR Phi, Phi@y, Phi@Phi.T, ->band, sum y^2."""
+    Kuf = basis.evaluate_basis(X, dx=0, sparse=True)
+    Kuf_y = np.asarray(Kuf @ y)
+    KK = Kuf @ Kuf.T
+    band = sparse_to_band(KK, basis.order)
+    return band, Kuf_y, float(np.sum(np.square(y)))
+
+
+def sufficient_stats_direct(basis, X, y):
+    """Same result by direct accumulation (no CSR) - the reduction order the GPU kernel mirrors."""
+    k, M = basis.order, basis.m
+    x = np.asarray(X, dtype=np.float64).reshape(-1)
+    y = np.asarray(y, dtype=np.float64).reshape(x.shape[0], -1)
+    idx = neighbour_index(basis.mesh, x)
+    t = (x - basis.mesh[idx]) / basis.delta
+    vals = piece_values(k, t)  # piece i -> row idx + k - i
+    band = np.zeros((k + 1, M))
+    rhs = np.zeros((M, y.shape[1]))
+    for i in range(k + 1):
+        np.add.at(rhs, idx + k - i, vals[i][:, None] * y)
+        for j in range(i, k + 1):  # row_i = idx+k-i >= row_j = idx+k-j ; d = j-i
+            np.add.at(band[j - i], idx + k - j, vals[i] * vals[j])
+    return band, rhs, float(np.sum(np.square(y)))
+
+
+def elbo_1d(Kuu, A, b, yy, N, v, s, D=1):
+    """gpr.py:49-89 from the sufficient statistics.  Returns (elbo, parts dict)."""
+    L_Kuu = cholesky_band(Kuu)
+    logdet_K = float(np.sum(np.log(np.square(L_Kuu[0]))))
+    Kinv = inverse_from_cholesky_band(L_Kuu)
+    trace_term = band_sym_dot(Kinv, A)
+    P = A / s + Kuu
+    L_P = cholesky_band(P)
+    logdet_P = float(np.sum(np.log(np.square(L_P[0]))))
+    c = solve_triang_mat(L_P, b) / s
+    ND = N * D
+    elbo = -0.5 * ND * np.log(2 * np.pi * s)
+    elbo -= 0.5 * D * logdet_P
+    elbo += 0.5 * D * logdet_K
+    elbo -= 0.5 * yy / s
+    elbo += 0.5 * float(np.sum(np.square(c)))
+    elbo -= 0.5 * N * v / s
+    elbo += 0.5 * trace_term / s
+    return float(elbo), dict(L_Kuu=L_Kuu, L_P=L_P, Kinv=Kinv, c=c, logdet_K=logdet_K, logdet_P=logdet_P,
+                             trace_term=trace_term)
+
+
+def elbo_grad_1d(basis, kind, A, b, yy, N, v, l, s):
+    """ELBO and its gradient w.r.t. (v, l, s) using only banded quantities.
+    The reference obtains the same numbers by TF reverse-mode through the banded_matrices op gradients."""
+    D = b.shape[1]
+    Kuu, dKl = make_Kuu(basis, kind, v, l, want_dl=True)
+    LK, dLK = cholesky_band_jvp(Kuu, dKl)
+    SK, dSK = inverse_from_cholesky_band(LK, dLK)
+    P = A / s + Kuu
+    LP = cholesky_band(P)
+    SP = inverse_from_cholesky_band(LP)
+    c = solve_triang_mat(LP, b) / s
+    alpha = solve_triang_mat(LP, c, transpose_left=True)  # P^-1 b / s
+    logdet_K = float(np.sum(np.log(np.square(LK[0]))))
+    logdet_P = float(np.sum(np.log(np.square(LP[0]))))
+    trKA = band_sym_dot(SK, A)
+    elbo = (-0.5 * N * D * np.log(2 * np.pi * s) - 0.5 * D * logdet_P + 0.5 * D * logdet_K - 0.5 * yy / s
+            + 0.5 * float(np.sum(c * c)) - 0.5 * N * v / s + 0.5 * trKA / s)
+
+    def G_dot(Kdot, dtrKA_along):
+        # <G, Kdot>, G = 1/2 (D Kuu^-1 - D P^-1 - alpha alpha^T - Kuu^-1 A Kuu^-1 / s);
+        # <Kuu^-1 A Kuu^-1, Kdot> = - d/dKdot tr(Kuu^-1 A)
+        aKa = float(np.sum(alpha * band_sym_matvec(Kdot, alpha)))
+        return 0.5 * (D * band_sym_dot(SK, Kdot) - D * band_sym_dot(SP, Kdot) - aKa + dtrKA_along / s)
+
+    d_l = G_dot(dKl, band_sym_dot(dSK, A))
+    # dKuu/dv = -Kuu/v  =>  d tr(Kuu^-1 A)/dv = + tr(Kuu^-1 A)/v
+    d_v = G_dot(-Kuu / v, trKA / v) - 0.5 * N / s
+    aAa = float(np.sum(alpha * band_sym_matvec(A, alpha)))
+    d_s = (-0.5 * N * D / s + 0.5 * D * band_sym_dot(SP, A) / s ** 2 + 0.5 * yy / s ** 2 + 0.5 * aAa / s ** 2
+           - float(np.sum(b * alpha)) / s ** 2 + 0.5 * N * v / s ** 2 - 0.5 * trKA / s ** 2)
+    return float(elbo), np.array([d_v, d_l, d_s]), dict(alpha=alpha, SK=SK, SP=SP, LK=LK, LP=LP, c=c)
+
+
+def predict_f_1d(basis, kind, A, b, v, l, s, Xnew):
+    """gpr.py:94-120 (full_cov=False): mean = Phi*^T P^-1 b / s ; var = v + |L_P^-1 Phi*|^2 - Phi*^T Kuu^-1 Phi*.
+    Dense textbook evaluation (the reference uses CHOLMOD with natural ordering == band Cholesky)."""
+    M, k = basis.m, basis.order
+    Kuu = make_Kuu(basis, kind, v, l)
+    Kd = unpack_banded_matrix_to_dense(symmetrise_band(Kuu, k), k, k)
+    Ad = unpack_banded_matrix_to_dense(symmetrise_band(A, k), k, k)
+    P = Ad / s + Kd
+    LP = np.linalg.cholesky(P)
+    c = np.linalg.solve(LP, b) / s
+    Kus = basis.evaluate_basis(Xnew, dx=0, sparse=False)
+    tmp = np.linalg.solve(LP, Kus)
+    mean = tmp.T @ c
+    KiKus = np.linalg.solve(Kd, Kus)
+    var = v + np.sum(tmp * tmp, axis=0) - np.sum(Kus * KiKus, axis=0)
+    return mean, var.reshape(-1, 1)
+
+
+def predict_f_1d_banded(basis, kind, A, b, v, l, s, Xnew):
+    """Same posterior through band quantities only: alpha = P^-1 b/s and the
+    (k+1)x(k+1) window of band(P^-1) - band(Kuu^-1) per test point."""
+    k = basis.order
+    Kuu = make_Kuu(basis, kind, v, l)
+    LK = cholesky_band(Kuu)
+    SK = inverse_from_cholesky_band(LK)
+    LP = cholesky_band(A / s + Kuu)
+    SP = inverse_from_cholesky_band(LP)
+    alpha = solve_triang_mat(LP, solve_triang_mat(LP, b) / s, transpose_left=True)
+    x = np.asarray(Xnew, dtype=np.float64).reshape(-1)
+    idx = neighbour_index(basis.mesh, x)
+    t = (x - basis.mesh[idx]) / basis.delta
+    vals = piece_values(k, t)  # piece i -> row idx+k-i
+    W = SP - SK
+    mean = np.zeros((x.shape[0], b.shape[1]))
+    var = np.full(x.shape[0], float(v))
+    for i in range(k + 1):
+        ri = idx + k - i
+        mean += vals[i][:, None] * alpha[ri]
+        for j in range(k + 1):
+            rj = idx + k - j
+            hi, lo = np.maximum(ri, rj), np.minimum(ri, rj)
+            var += vals[i] * vals[j] * W[hi - lo, lo]
+    return mean, var.reshape(-1, 1)
+
+# --------------------------------------------------------------------------------------
+# Kronecker (kronecker.py:7-33; gpr.py:239-359)
+# --------------------------------------------------------------------------------------
+
+def make_kvs_two_sparse(Pa, Pb):
+    """kronecker.py:27-30: column-wise Kronecker (Khatri-Rao) product, row = i_a * m_b + i_b."""
+    Pa, Pb = sp.csc_matrix(Pa), sp.csc_matrix(Pb)
+    n = Pa.shape[1]
+    ma, mb = Pa.shape[0], Pb.shape[0]
+    rows, cols, data = [], [], []
+    for c in range(n):
+        ra = Pa.indices[Pa.indptr[c]:Pa.indptr[c + 1]]
+        va = Pa.data[Pa.indptr[c]:Pa.indptr[c + 1]]
+        rb = Pb.indices[Pb.indptr[c]:Pb.indptr[c + 1]]
+        vb = Pb.data[Pb.indptr[c]:Pb.indptr[c + 1]]
+        rows.append((ra[:, None] * mb + rb[None, :]).reshape(-1))
+        data.append((va[:, None] * vb[None, :]).reshape(-1))
+        cols.append(np.full(ra.shape[0] * rb.shape[0], c))
+    return sp.csr_matrix((np.concatenate(data), (np.concatenate(rows), np.concatenate(cols))), shape=(ma * mb, n))
+
+
+def make_kvs_sparse(P_list):
+    """kronecker.py:32-33: left fold."""
+    out = P_list[0]
+    for P in P_list[1:]:
+        out = make_kvs_two_sparse(out, P)
+    return out
+
+
+def band_to_dense_sym(lower):
+    k = lower.shape[0] - 1
+    return unpack_banded_matrix_to_dense(symmetrise_band(lower, k), k, k)
+
+
+def elbo_kron(bases, kinds, thetas, s, X, y):
+    """gpr.py:260-308 (dense, as the reference does it): Kuu = kron(K_i), L = kron(L_i) (utils.py:45-51),
+    sum K_diag = N prod v_i (gpr.py:284).  thetas = [(v_i, l_i)]."""
+    N = X.shape[0]
+    Phis = [bs.evaluate_basis(X[:, i:i + 1]) for i, bs in enumerate(bases)]
+    Kuf = make_kvs_sparse(Phis)
+    A = (Kuf @ Kuf.T).toarray()
+    b = np.asarray(Kuf @ y)
+    Ks = [band_to_dense_sym(make_Kuu(bs, kd, v, l)) for bs, kd, (v, l) in zip(bases, kinds, thetas)]
+    Kuu = Ks[0]
+    for K in Ks[1:]:
+        Kuu = np.kron(Kuu, K)
+    LK = np.linalg.cholesky(Kuu)
+    P = A / s + Kuu
+    LP = np.linalg.cholesky(P)
+    c = np.linalg.solve(LP, b) / s
+    D = y.shape[1]
+    vprod = float(np.prod([v for v, _ in thetas]))
+    tr = np.trace(np.linalg.solve(Kuu, A))
+    elbo = (-0.5 * N * D * np.log(2 * np.pi * s) - 0.5 * D * 2 * np.sum(np.log(np.diag(LP)))
+            + 0.5 * D * 2 * np.sum(np.log(np.diag(LK))) - 0.5 * np.sum(y * y) / s + 0.5 * np.sum(c * c)
+            - 0.5 * N * vprod / s + 0.5 * tr / s)
+    return float(elbo), dict(A=A, b=b, Kuu=Kuu, P=P)
+
+
+def predict_f_kron(bases, kinds, thetas, s, X, y, Xnew):
+    """gpr.py:310-334: dense posterior (mean, var) of GPR_kron; var is tiled over D columns (gpr.py:331-332)."""
+    _, parts = elbo_kron(bases, kinds, thetas, s, X, y)
+    Kuu, P, b = parts["Kuu"], parts["P"], parts["b"]
+    Kus = make_kvs_sparse([bs.evaluate_basis(Xnew[:, i:i + 1]) for i, bs in enumerate(bases)]).toarray()
+    LP = np.linalg.cholesky(P)
+    tmp = np.linalg.solve(LP, Kus)
+    mean = tmp.T @ (np.linalg.solve(LP, b) / s)
+    vprod = float(np.prod([v for v, _ in thetas]))
+    var = vprod + np.sum(tmp * tmp, axis=0) - np.sum(Kus * np.linalg.solve(Kuu, Kus), axis=0)
+    return mean, np.tile(var.reshape(-1, 1), (1, y.shape[1]))
+
+# --------------------------------------------------------------------------------------
+# Parameter transforms + L-BFGS-B driver (example.py:28-33; GPflow Scipy optimiser / softplus / 1e-6 shift)
+# --------------------------------------------------------------------------------------
+
+def softplus(u):
+    return np.logaddexp(0.0, u)
+
+
+def softplus_inv(x):
+    return x + np.log(-np.expm1(-x))
+
+
+def sigmoid(u):
+    return 1.0 / (1.0 + np.exp(-u))
+
+
+LIK_SHIFT = 1e-6  # gpflow.likelihoods.Gaussian variance lower bound
+
+
+def fit_1d(basis, kind, X, y, v0=1.0, l0=1.0, s0=1.0, maxiter=15000):
+    """example.py:31-32: minimise -ELBO over unconstrained (v, l, s) with scipy L-BFGS-B (what
+    gpflow.optimizers.Scipy calls), from GPflow's defaults."""
+    from scipy.optimize import minimize
+    A, b, yy = sufficient_stats(basis, X, y)
+    N = X.shape[0]
+
+    def fun(u):
+        v, l, s = softplus(u[0]), softplus(u[1]), softplus(u[2]) + LIK_SHIFT
+        e, g, _ = elbo_grad_1d(basis, kind, A, b, yy, N, v, l, s)
+        return -e, -g * sigmoid(u)
+
+    u0 = np.array([softplus_inv(v0), softplus_inv(l0), softplus_inv(s0 - LIK_SHIFT)])
+    res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
+    theta = np.array([softplus(res.x[0]), softplus(res.x[1]), softplus(res.x[2]) + LIK_SHIFT])
+    return -res.fun, theta, res

@@ -1,0 +1,255 @@
+"""CPU: pin the oracle (oracle/asvgp_oracle.py) against fixtures made by the reference's own code
+(tests/golden/make_golden.py) and against the notebook golden (experiments/snelson/example.ipynb:78)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import asvgp_oracle as O
+
+KINDS = {"Matern12": 0, "Matern32": 1, "Matern52": 2}
+
+
+def _basis_from_spec(spec):
+    order, a, b, m, isf = spec
+    order, m = int(order), int(m)
+    a, b = (float(a), float(b)) if isf else (int(a), int(b))
+    return O.Basis(order, a, b, m)
+
+
+@pytest.fixture(scope="module")
+def F(golden_dir):
+    return np.load(os.path.join(golden_dir, "basis_fixtures.npz"))
+
+
+def test_mesh_index_and_design_matrix_bit_exact_structure(F):
+    for tag in F["tags"]:
+        bs = _basis_from_spec(F[tag + "/spec"])
+        assert np.array_equal(bs.mesh, F[tag + "/mesh"]), tag       # mesh incl. the fp32 quirk: bit exact
+        assert bs.delta == F[tag + "/delta"], tag
+        x = F[tag + "/x"]
+        assert np.array_equal(O.neighbour_index(bs.mesh, x), F[tag + "/idx"]), tag   # integer work: bit exact
+        Phi = bs.evaluate_basis(x.reshape(-1, 1))
+        Phi.sort_indices()
+        assert np.array_equal(Phi.indices, F[tag + "/csr_indices"]), tag
+        assert np.array_equal(Phi.indptr, F[tag + "/csr_indptr"]), tag
+        np.testing.assert_allclose(Phi.data, F[tag + "/csr_data"], rtol=0, atol=2e-14, err_msg=tag)
+
+
+def test_static_bands(F):
+    for tag in F["tags"]:
+        bs = _basis_from_spec(F[tag + "/spec"])
+        for nm in ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad"):
+            key = tag + "/" + nm
+            if key not in F:
+                continue
+            ref, mine = F[key], getattr(bs, nm)
+            assert ref.shape == mine.shape
+            scale = max(np.max(np.abs(ref)), 1e-300)
+            assert np.max(np.abs(ref - mine)) <= 4e-15 * scale, key
+            if nm in ("A", "B", "C", "D", "BC_ggrad_none", "BC_none_ggrad"):
+                assert np.array_equal(ref == 0, mine == 0), key     # structural zeros: exact positions
+            else:
+                k = bs.order  # boundary bands: non-zero only in the first/last k columns
+                assert not np.any(mine[:, k:bs.m - k]), key
+                assert not np.any(ref[:, k:bs.m - k]), key
+
+
+def test_partition_of_unity_and_cox_de_boor():
+    from scipy.interpolate import BSpline
+    t = np.linspace(0, 1, 33)
+    for k in range(1, 7):
+        vals = O.piece_values(k, t)
+        np.testing.assert_allclose(vals.sum(0), 1.0, atol=5e-15)
+        card = BSpline.basis_element(np.arange(k + 2), extrapolate=False)
+        for i in range(k + 1):
+            ref = np.nan_to_num(card(np.clip(t + i, 0, k + 1 - 1e-300)))
+            np.testing.assert_allclose(vals[i][:-1], ref[:-1], atol=5e-15)
+
+
+def test_kuu_bands(golden_dir):
+    K = np.load(os.path.join(golden_dir, "kuu_fixtures.npz"))
+    specs = {"B3_f": (3, -3.5, 10.5, 30), "B4_i": (4, 0, 1, 64), "B2_i": (2, 0, 1, 17), "B5_i": (5, -2, 3, 33),
+             "B1_i": (1, 0, 1, 16), "B6_i": (6, 0, 1, 40)}
+    n = 0
+    for key in K.files:
+        if key == "thetas":
+            continue
+        tag, kn, ti = key.split("/")
+        v, l = K["thetas"][int(ti)]
+        mine = O.make_Kuu(O.Basis(*specs[tag]), KINDS[kn], v, l)
+        assert np.max(np.abs(mine - K[key])) <= 4e-15 * np.max(np.abs(K[key])), key
+        n += 1
+    assert n >= 30
+
+
+def test_kuu_dl_matches_finite_difference():
+    bs = O.Basis(4, 0, 1, 40)
+    for kind in (0, 1, 2):
+        K, dK = O.make_Kuu(bs, kind, 0.9, 0.3, want_dl=True)
+        h = 1e-6
+        fd = (O.make_Kuu(bs, kind, 0.9, 0.3 + h) - O.make_Kuu(bs, kind, 0.9, 0.3 - h)) / (2 * h)
+        np.testing.assert_allclose(dK, fd, rtol=1e-6, atol=1e-6 * np.max(np.abs(dK)))
+
+
+def test_matern_order_availability():
+    with pytest.raises(AttributeError):
+        O.make_Kuu(O.Basis(1, 0, 1, 16), O.MATERN32, 1.0, 1.0)   # B1 has no C / BC_grad
+    with pytest.raises(AttributeError):
+        O.make_Kuu(O.Basis(6, 0, 1, 40), O.MATERN52, 1.0, 1.0)   # B6 has no BC_ggrad
+    with pytest.raises(NameError):
+        O.Basis(4, 0, 1, 11)                                     # basis.py:379-380
+
+
+def test_khatri_rao(golden_dir):
+    Kf = np.load(os.path.join(golden_dir, "kron_fixtures.npz"))
+    X = Kf["X"]
+    b1, b2 = O.Basis(3, 0, 1, 12), O.Basis(3, -1, 2, 14)
+    KR = O.make_kvs_sparse([b1.evaluate_basis(X[:, :1]), b2.evaluate_basis(X[:, 1:])])
+    dense = KR.toarray()
+    assert np.array_equal(dense != 0, Kf["dense"] != 0)            # row ids: bit exact
+    np.testing.assert_allclose(dense, Kf["dense"], atol=1e-15)
+    np.testing.assert_allclose((KR @ KR.T).toarray(), Kf["KKt"], atol=1e-14)
+    # einsum('in,jn->ijn') dim-0 major
+    e = np.einsum("in,jn->ijn", b1.evaluate_basis(X[:, :1]).toarray(), b2.evaluate_basis(X[:, 1:]).toarray())
+    np.testing.assert_allclose(dense, e.reshape(12 * 14, -1), atol=1e-15)
+
+
+@pytest.fixture(scope="module")
+def S(golden_dir):
+    return np.load(os.path.join(golden_dir, "snelson_fixtures.npz"))
+
+
+def test_snelson_sufficient_statistics(S):
+    X, Y = S["X"], S["Y"]
+    for tag, (o, m) in {"B3_30": (3, 30), "B3_100": (3, 100), "B4_30": (4, 30)}.items():
+        bs = O.Basis(o, -3.5, 10.5, m)
+        A, b, yy = O.sufficient_stats(bs, X, Y)
+        A2, b2, yy2 = O.sufficient_stats_direct(bs, X, Y)
+        np.testing.assert_allclose(A, S[tag + "/KufKfu"], atol=3e-14)
+        np.testing.assert_allclose(b, S[tag + "/Kuf_y"], atol=3e-14)
+        assert yy == S[tag + "/tr_yTy"]
+        np.testing.assert_allclose(A2, A, atol=3e-14)
+        np.testing.assert_allclose(b2, b, atol=5e-14)
+        assert np.array_equal(A == 0, S[tag + "/KufKfu"] == 0)
+
+
+def test_elbo_table_banded_vs_dense_reference_driven(S):
+    """ELBO through the banded op restatements == dense textbook bound evaluated on the reference's own Phi/Kuu."""
+    X, Y = S["X"], S["Y"]
+    for o, m, kd, v, l, s, e in S["elbo_table"]:
+        bs = O.Basis(int(o), -3.5, 10.5, int(m))
+        A, b, yy = O.sufficient_stats(bs, X, Y)
+        el, _ = O.elbo_1d(O.make_Kuu(bs, int(kd), v, l), A, b, yy, X.shape[0], v, s)
+        assert abs(el - e) <= 1e-9 * abs(e)
+        eg, g, _ = O.elbo_grad_1d(bs, int(kd), A, b, yy, X.shape[0], v, l, s)
+        assert abs(eg - e) <= 1e-9 * abs(e)
+
+
+def test_survey_appendix_c_known_answers(S):
+    X, Y = S["X"], S["Y"]
+    rows = [  # kernel, order, m, theta, elbo, grad
+        (0, 3, 30, (1, 1, 1), -219.723146974397, (-11.477170634776, 10.333618112628, -76.565425742224)),
+        (1, 3, 30, (0.8, 1.03, 0.08), -67.612856813100, (-9.180425410307, 18.255068566583, 116.459732434501)),
+        (2, 4, 30, (1, 1, 1), -209.617790548486, (0.402429876954, -4.206361763195, -86.362184373251)),
+        (1, 3, 100, (1, 1, 1), -209.779460221240, (-0.897434583696, 0.337205874007, -86.30506007662)),
+    ]
+    for kd, o, m, (v, l, s), e, g in rows:
+        bs = O.Basis(o, -3.5, 10.5, m)
+        A, b, yy = O.sufficient_stats(bs, X, Y)
+        el, gr, _ = O.elbo_grad_1d(bs, kd, A, b, yy, 200, float(v), float(l), float(s))
+        assert abs(el - e) < 1e-9 * abs(e)
+        np.testing.assert_allclose(gr, g, rtol=2e-6)
+    # fp64-mesh discriminator for quirk B-1
+    bs = O.Basis(3, np.float64(-3.5), np.float64(10.5), 100)
+    A, b, yy = O.sufficient_stats(bs, X, Y)
+    el, _ = O.elbo_1d(O.make_Kuu(bs, 1, 1.0, 1.0), A, b, yy, 200, 1.0, 1.0)
+    assert abs(el - (-209.779459803854)) < 1e-8
+
+
+def test_gradient_vs_finite_differences(S):
+    X, Y = S["X"], S["Y"]
+    bs = O.Basis(4, -3.5, 10.5, 30)
+    A, b, yy = O.sufficient_stats(bs, X, Y)
+    for kd in (0, 1, 2):
+        v, l, s = 0.8, 1.03, 0.08
+        _, g, _ = O.elbo_grad_1d(bs, kd, A, b, yy, 200, v, l, s)
+        f = lambda v, l, s: O.elbo_1d(O.make_Kuu(bs, kd, v, l), A, b, yy, 200, v, s)[0]
+        h = 1e-6
+        fd = np.array([(f(v + h, l, s) - f(v - h, l, s)), (f(v, l + h, s) - f(v, l - h, s)),
+                       (f(v, l, s + h) - f(v, l, s - h))]) / (2 * h)
+        np.testing.assert_allclose(g, fd, rtol=2e-6)
+
+
+def test_notebook_golden_after_lbfgs(S):
+    """example.ipynb:78: ASVGP ELBO = -60.8356263428725 (B3Spline(-3.5, 10.5, 100), Matern32, GPflow defaults)."""
+    bs = O.Basis(3, -3.5, 10.5, 100)
+    e, theta, res = O.fit_1d(bs, O.MATERN32, S["X"], S["Y"])
+    assert abs(e - float(S["golden_elbo_asvgp"])) < 1e-8
+    assert e < float(S["golden_elbo_gp"])          # exact-GP marginal likelihood is an upper bound
+    np.testing.assert_allclose(theta, [0.798145059, 1.026880136, 0.080066643], rtol=2e-5)
+
+
+def test_predict_dense_vs_banded_and_survey_values(S, golden_dir):
+    Xs = np.loadtxt(os.path.join(golden_dir, "snelson", "test_inputs")).reshape(-1, 1)
+    bs = O.Basis(3, -3.5, 10.5, 100)
+    A, b, yy = O.sufficient_stats(bs, S["X"], S["Y"])
+    v, l, s = 0.798145059, 1.026880136, 0.080066643
+    m1, v1 = O.predict_f_1d(bs, 1, A, b, v, l, s, Xs)
+    m2, v2 = O.predict_f_1d_banded(bs, 1, A, b, v, l, s, Xs)
+    np.testing.assert_allclose(m1, m2, atol=1e-10)
+    np.testing.assert_allclose(v1, v2, atol=1e-10)
+    np.testing.assert_allclose(m1[[0, 150, 300], 0], [0.01123846, -0.20213625, -0.00027056], atol=2e-7)
+    np.testing.assert_allclose(v1[[0, 150, 300], 0], [0.79721169, 0.00731127, 0.79809196], atol=2e-7)
+
+
+def test_band_ops_against_dense():
+    rng = np.random.default_rng(0)
+    for k, M in [(1, 9), (3, 17), (4, 40), (6, 25)]:
+        Bm = rng.normal(size=(M, M))
+        dense = Bm @ Bm.T + M * np.eye(M)
+        dense = np.triu(np.tril(dense, k), -k)
+        dense += np.eye(M) * (np.abs(dense).sum(1).max())
+        lower = O.pack_dense_matrix_to_banded(dense, k, 0)
+        L = O.cholesky_band(lower)
+        Ld = np.linalg.cholesky(dense)
+        np.testing.assert_allclose(O.unpack_banded_matrix_to_dense(L, k, 0), Ld, atol=1e-12)
+        S_ = O.inverse_from_cholesky_band(L)
+        inv = np.linalg.inv(dense)
+        np.testing.assert_allclose(S_, O.pack_dense_matrix_to_banded(inv, k, 0), atol=1e-13)
+        rhs = rng.normal(size=(M, 2))
+        np.testing.assert_allclose(O.solve_triang_mat(L, rhs), np.linalg.solve(Ld, rhs), atol=1e-12)
+        np.testing.assert_allclose(O.solve_triang_mat(L, rhs, True), np.linalg.solve(Ld.T, rhs), atol=1e-12)
+        sym = O.symmetrise_band(lower, k)
+        np.testing.assert_array_equal(O.unpack_banded_matrix_to_dense(sym, k, k), dense)
+        g = rng.normal(size=(M, M))
+        g = np.triu(np.tril(g, 2), -1)
+        gb = O.pack_dense_matrix_to_banded(g, 1, 2)      # lower bw 1, upper bw 2
+        np.testing.assert_array_equal(O.unpack_banded_matrix_to_dense(O.transpose_band(gb, 1, 2), 2, 1), g.T)
+        prod = O.product_band_band(sym, sym, k, k, k, k, 0, 0)
+        np.testing.assert_allclose(prod[0], np.diag(dense @ dense), rtol=1e-13)
+        np.testing.assert_allclose(O.band_sym_dot(S_, lower), np.trace(inv @ dense), rtol=1e-10)
+        np.testing.assert_allclose(O.band_sym_matvec(lower, rhs), dense @ rhs, rtol=1e-12)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.cholesky_band(np.array([[1.0, -1.0, 1.0], [2.0, 0.5, 0.0]]))
+
+
+def test_kron_elbo_matches_direct_dense():
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0.01, 0.99, size=(300, 2))
+    y = (np.sin(12 * X[:, :1]) * np.cos(9 * X[:, 1:]) + 0.1 * rng.normal(size=(300, 1)))
+    bases = [O.Basis(3, 0, 1, 8), O.Basis(3, 0, 1, 9)]
+    e, parts = O.elbo_kron(bases, [1, 1], [(1.0, 0.3), (0.7, 0.4)], 0.05, X, y)
+    # direct: Phi via einsum, Kuu via np.kron
+    P1, P2 = bases[0].evaluate_basis(X[:, :1]).toarray(), bases[1].evaluate_basis(X[:, 1:]).toarray()
+    Phi = np.einsum("in,jn->ijn", P1, P2).reshape(72, -1)
+    np.testing.assert_allclose(parts["A"], Phi @ Phi.T, atol=1e-12)
+    Kuu = np.kron(O.band_to_dense_sym(O.make_Kuu(bases[0], 1, 1.0, 0.3)), O.band_to_dense_sym(O.make_Kuu(bases[1], 1, 0.7, 0.4)))
+    np.testing.assert_allclose(parts["Kuu"], Kuu)
+    # SGPR collapsed bound == log N(y | 0, Qff + s I) - 1/(2s) tr(Kff - Qff) with Kff diag = v1 v2
+    s = 0.05
+    Qff = Phi.T @ np.linalg.solve(Kuu, Phi)
+    C = Qff + s * np.eye(300)
+    sign, ld = np.linalg.slogdet(C)
+    direct = -0.5 * (300 * np.log(2 * np.pi) + ld + float(y.T @ np.linalg.solve(C, y))) - 0.5 / s * (300 * 0.7 - np.trace(Qff))
+    assert abs(e - direct) < 1e-8 * abs(direct)
