@@ -1,0 +1,98 @@
+"""ctypes loader for the C-ABI in include/asvgp_hip.h.  No CPU fallback: a missing library is a loud error."""
+import ctypes
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libasvgp_hip.so")
+
+_c = ctypes
+_P, _I, _L, _D, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double, _c.c_size_t
+
+# name -> (restype, argtypes): exactly the prototypes of include/asvgp_hip.h
+SIGNATURES = {
+    "asvgp_version": (_I, []),
+    "asvgp_last_error_string": (_c.c_char_p, []),
+    "asvgp_status_name": (_c.c_char_p, [_I]),
+    "asvgp_phi_workspace_bytes": (_Z, [_L, _I, _L]),
+    "asvgp_phi_accumulate_1d": (_I, [_P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
+    "asvgp_phi_index_1d": (_I, [_P, _L, _P, _L, _D, _P, _P]),
+    "asvgp_phi_evaluate_1d": (_I, [_P, _L, _P, _L, _D, _I, _I, _P, _P, _P]),
+    "asvgp_matern_coeffs": (_I, [_I, _D, _D, _c.POINTER(_D), _c.POINTER(_D), _c.POINTER(_I)]),
+    "asvgp_kuu_assemble": (_I, [_P, _I, _c.POINTER(_D), _c.POINTER(_D), _L, _I, _P, _P, _P]),
+    "asvgp_cholesky_band": (_I, [_P, _P, _L, _I, _P, _P]),
+    "asvgp_inverse_from_cholesky_band": (_I, [_P, _P, _L, _I, _P]),
+    "asvgp_solve_triang_mat": (_I, [_P, _P, _P, _L, _I, _L, _I, _P]),
+    "asvgp_product_band_band": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "asvgp_transpose_band": (_I, [_P, _P, _L, _I, _I, _P]),
+    "asvgp_symmetrise_band": (_I, [_P, _P, _L, _I, _P]),
+    "asvgp_unpack_banded_matrix_to_dense": (_I, [_P, _P, _L, _I, _I, _P]),
+    "asvgp_pack_dense_matrix_to_banded": (_I, [_P, _P, _L, _I, _I, _P]),
+    "asvgp_band_trace_sym": (_I, [_P, _P, _L, _I, _P, _P]),
+    "asvgp_elbo_workspace_bytes": (_Z, [_L, _I, _L]),
+    "asvgp_elbo_grad_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_posterior_prepare_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),
+    "asvgp_predict_1d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),
+    "asvgp_profile_enable": (_I, [_I]),
+    "asvgp_profile_read": (_I, [_c.POINTER(_D), _c.POINTER(_L)]),
+    "asvgp_kron_workspace_bytes": (_Z, [_L, _L, _I, _I]),
+    "asvgp_phi_accumulate_kron2d": (_I, [_P, _P, _L, _P, _L, _D, _I, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
+    "asvgp_blockband_cholesky": (_I, [_P, _L, _L, _P, _P]),
+    "asvgp_blockband_solve": (_I, [_P, _L, _L, _P, _L, _I, _P]),
+    "asvgp_kron_expand_band": (_I, [_P, _P, _L, _L, _I, _I, _D, _P, _P]),
+    "asvgp_predict_kron2d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _L, _D, _I, _L, _P, _P, _P]),
+}
+
+
+class AsvgpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def get_lib():
+    """Load libasvgp_hip.so (built in-tree by asvgp_amd.build).  Raises if it is missing - there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsvgpError("HIP extension %s is missing: run `python -m asvgp_amd.build` (hipcc, gfx950). "
+                         "asvgp_amd has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if name.startswith(("asvgp_kron", "asvgp_phi_accumulate_kron", "asvgp_blockband", "asvgp_predict_kron")):
+                continue
+            raise AsvgpError("libasvgp_hip.so does not export %s" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        lib = get_lib()
+        raise AsvgpError("%s failed: %s (%s)" % (what or "asvgp call", lib.asvgp_status_name(status).decode(),
+                                                  lib.asvgp_last_error_string().decode()))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise AsvgpError("asvgp_amd operates on ROCm device tensors only (got a %s tensor); there is no CPU path"
+                             % t.device)
+
+
+def f64c(t):
+    """contiguous fp64 view/copy"""
+    if t.dtype != torch.float64:
+        t = t.to(torch.float64)
+    return t.contiguous()

@@ -1,0 +1,134 @@
+// Shared device/host helpers for the gfx950 ASVGP kernels (wave64, fp64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/asvgp_hip.h"
+
+namespace asvgp {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+static inline hipStream_t as_stream(asvgp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ------------------------------------------------------------------------------------------------
+// Cardinal B-spline pieces N_k(t+i), t in [0,1], i = 0..k, as monomial coefficients (exact integer
+// numerators / k!).  Same mathematical objects as b1..b_{k+1} of basis.py:133-136 ... 668-676.
+// ------------------------------------------------------------------------------------------------
+constexpr long long ipow(long long b, int e) { long long r = 1; for (int i = 0; i < e; ++i) r *= b; return r; }
+constexpr long long binom(int n, int r) {
+  if (r < 0 || r > n) return 0;
+  long long v = 1;
+  for (int i = 1; i <= r; ++i) v = v * (n - r + i) / i;
+  return v;
+}
+constexpr long long fact(int n) { long long v = 1; for (int i = 2; i <= n; ++i) v *= i; return v; }
+
+// coefficient of t^p in the DERIV-th t-derivative of piece i of the order-K cardinal B-spline
+template <int K, int DERIV>
+constexpr double piece_coef(int i, int p) {
+  // base polynomial coefficient of t^(p+DERIV), times falling factorial
+  int q = p + DERIV;
+  if (q > K) return 0.0;
+  long long num = 0;
+  for (int j = 0; j <= i; ++j) {
+    long long term = binom(K + 1, j) * binom(K, q) * ipow(i - j, K - q);
+    num += (j & 1) ? -term : term;
+  }
+  long long ff = 1;
+  for (int d = 0; d < DERIV; ++d) ff *= (q - d);
+  return (double)(num * ff) / (double)fact(K);
+}
+
+// vals[i] = N_K^(DERIV)(t + i), Horner in t (t-derivative: caller scales by delta^-DERIV)
+template <int K, int DERIV = 0>
+__device__ __forceinline__ void bspline_pieces(double t, double (&vals)[K + 1]) {
+#pragma unroll
+  for (int i = 0; i <= K; ++i) {
+    double acc = piece_coef<K, DERIV>(i, K - DERIV);
+#pragma unroll
+    for (int p = K - DERIV - 1; p >= 0; --p) acc = fma(acc, t, piece_coef<K, DERIV>(i, p));
+    vals[i] = acc;
+  }
+}
+
+// basis.py:58-59: idx = max(#{mesh < x} - 1, 0), a table search (floor guess + fix-up against the table).
+// Clamped to n_mesh-2 so rows idx..idx+k stay inside [0, M) for x beyond b (the reference asserts a < x < b).
+__device__ __forceinline__ int neighbour_index(double x, const double* mesh, int n_mesh, double m0, double inv_delta) {
+  double g = floor((x - m0) * inv_delta);
+  int i = (g < 0.0) ? 0 : ((g > (double)(n_mesh - 2)) ? (n_mesh - 2) : (int)g);  // NaN -> 0
+  while (i > 0 && !(mesh[i] < x)) --i;                 // x on knot j>0 belongs to interval j-1
+  while (i < n_mesh - 2 && mesh[i + 1] < x) ++i;
+  return i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 lane helpers for fp64 values (two 32-bit halves)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: wave-uniform
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// block-wide sum of one double per thread; result valid in thread 0.  scratch: >= blockDim/64 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (w == 0) {
+    r = (lane < nw) ? scratch[lane] : 0.0;
+    r = wave_sum(r);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward-mode dual number (value, tangent) - one direction (d/d lengthscale), SURVEY App. A-6
+// ------------------------------------------------------------------------------------------------
+struct Dual {
+  double v, d;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, fma(a.v, b.d, a.d * b.v)}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+
+template <typename T> struct Num;
+template <> struct Num<double> {
+  static __device__ __forceinline__ double zero() { return 0.0; }
+  static __device__ __forceinline__ double make(double v, double) { return v; }
+  static __device__ __forceinline__ double val(double a) { return a; }
+  static __device__ __forceinline__ double tan(double) { return 0.0; }
+  static __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
+  static __device__ __forceinline__ double inv(double a) { return 1.0 / a; }
+  static __device__ __forceinline__ double rl(double a, int lane) { return readlane_f64(a, lane); }
+  static __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
+  // a - b*c
+  static __device__ __forceinline__ double nfma(double b, double c, double a) { return fma(-b, c, a); }
+};
+template <> struct Num<Dual> {
+  static __device__ __forceinline__ Dual zero() { return {0.0, 0.0}; }
+  static __device__ __forceinline__ Dual make(double v, double d) { return {v, d}; }
+  static __device__ __forceinline__ double val(Dual a) { return a.v; }
+  static __device__ __forceinline__ double tan(Dual a) { return a.d; }
+  static __device__ __forceinline__ Dual sqrt_(Dual a) { double s = sqrt(a.v); return {s, a.d / (2.0 * s)}; }
+  static __device__ __forceinline__ Dual inv(Dual a) { double r = 1.0 / a.v; return {r, -a.d * r * r}; }
+  static __device__ __forceinline__ Dual rl(Dual a, int lane) { return {readlane_f64(a.v, lane), readlane_f64(a.d, lane)}; }
+  static __device__ __forceinline__ Dual sel(bool c, Dual a, Dual b) { return {c ? a.v : b.v, c ? a.d : b.d}; }
+  static __device__ __forceinline__ Dual nfma(Dual b, Dual c, Dual a) {
+    return {fma(-b.v, c.v, a.v), fma(-b.v, c.d, fma(-b.d, c.v, a.d))};
+  }
+};
+
+}  // namespace asvgp

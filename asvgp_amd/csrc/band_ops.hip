@@ -1,0 +1,311 @@
+// banded_matrices.banded operator replacements + Kuu assembly (C-ABI entry points).
+// Reference call sites: gpr.py:56-75, utils.py:7-9,24-57, inducing_features.py:12-44.
+#include <math.h>
+#include <stdarg.h>
+
+#include "band_sweeps.hpp"
+
+namespace asvgp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return ASVGP_ERR_HIP;
+  }
+  return ASVGP_OK;
+}
+
+// ---------------------------------------------------------------- kernels
+template <int K>
+__global__ __launch_bounds__(64) void cholesky_band_kernel(const double* A, double* L, int M, int* info) {
+  cholesky_sweep<double, K, false>(BandPtr<double>{A, nullptr}, BandOut<double>{L, nullptr}, M, nullptr, nullptr, info);
+}
+template <int K>
+__global__ __launch_bounds__(64) void takahashi_kernel(const double* L, double* S, int M) {
+  takahashi_sweep<double, K, false>(BandPtr<double>{L, nullptr}, BandOut<double>{S, nullptr}, M, nullptr, nullptr);
+}
+template <int K>
+__global__ __launch_bounds__(64) void trsv_kernel(const double* L, int M, const double* B, double* X, long D, int trans) {
+  const long d = blockIdx.x;  // one wave per right-hand-side column
+  if (trans) trsv_sweep<K, true>(L, M, B + d, X + d, D);
+  else trsv_sweep<K, false>(L, M, B + d, X + d, D);
+}
+
+struct KuuCoefs { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]; int n; };
+
+// inducing_features.py:16-44: Kuu = sum_t c_t * S_t, accumulated left to right like the reference (no FMA
+// contraction, so the band is bit-identical to the numpy/TF evaluation order).
+__global__ void kuu_assemble_kernel(const double* __restrict__ S, KuuCoefs cf, long E, double* __restrict__ Kuu,
+                                    double* __restrict__ dK) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double acc = __dmul_rn(cf.c[0], S[e]);
+  double dacc = __dmul_rn(cf.dc[0], S[e]);
+  for (int t = 1; t < cf.n; ++t) {
+    double s = S[(long)t * E + e];
+    acc = __dadd_rn(acc, __dmul_rn(cf.c[t], s));
+    dacc = __dadd_rn(dacc, __dmul_rn(cf.dc[t], s));
+  }
+  Kuu[e] = acc;
+  if (dK) dK[e] = dacc;
+}
+
+// out (u,l) band of A^T from the (l,u) band of A: out[(l + j - i), i] = A[i][j]
+__global__ void transpose_band_kernel(const double* __restrict__ in, double* __restrict__ out, long M, int l, int u) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)(l + u + 1) * M) return;
+  int r = (int)(t / M);      // output row
+  long i = t - (long)r * M;  // output column = source row index
+  long j = i + r - l;        // r = l + j - i
+  double v = 0.0;
+  if (j >= 0 && j < M) v = in[(long)(u + i - j) * M + j];
+  out[t] = v;
+}
+
+__global__ void symmetrise_band_kernel(const double* __restrict__ in, double* __restrict__ out, long M, int l) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)(2 * l + 1) * M) return;
+  int r = (int)(t / M);
+  long j = t - (long)r * M;
+  double v;
+  if (r >= l) v = in[(long)(r - l) * M + j];                     // lower part: row offset d = r-l, A[j+d][j]
+  else { int d = l - r; long c = j - d; v = (c >= 0) ? in[(long)d * M + c] : 0.0; }  // A[j-d][j] = A[j][j-d]
+  out[t] = v;
+}
+
+__global__ void unpack_band_kernel(const double* __restrict__ band, double* __restrict__ dense, long M, int l, int u) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * M) return;
+  long i = t / M, j = t - i * M;
+  long d = i - j;
+  dense[t] = (d <= l && -d <= u) ? band[(long)(u + d) * M + j] : 0.0;
+}
+
+__global__ void pack_band_kernel(const double* __restrict__ dense, double* __restrict__ band, long M, int l, int u) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)(l + u + 1) * M) return;
+  int r = (int)(t / M);
+  long j = t - (long)r * M;
+  long i = j + r - u;
+  band[t] = (i >= 0 && i < M) ? dense[i * M + j] : 0.0;
+}
+
+__global__ void product_band_band_kernel(const double* __restrict__ L, const double* __restrict__ R,
+                                         double* __restrict__ out, long M, int ll, int lu, int rl, int ru, int ol,
+                                         int ou) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)(ol + ou + 1) * M) return;
+  int r = (int)(t / M);
+  long j = t - (long)r * M;
+  long i = j + r - ou;
+  double acc = 0.0;
+  if (i >= 0 && i < M) {
+    long p0 = i - ll; if (j - ru > p0) p0 = j - ru; if (p0 < 0) p0 = 0;
+    long p1 = i + lu; if (j + rl < p1) p1 = j + rl; if (p1 > M - 1) p1 = M - 1;
+    for (long p = p0; p <= p1; ++p)
+      acc = fma(L[(long)(lu + i - p) * M + p], R[(long)(ru + p - j) * M + j], acc);
+  }
+  out[t] = acc;
+}
+
+__global__ __launch_bounds__(1024) void band_trace_sym_kernel(const double* __restrict__ S, const double* __restrict__ A,
+                                                              long M, int k, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (long j = threadIdx.x; j < M; j += blockDim.x) {
+    double a = S[j] * A[j];
+    for (int d = 1; d <= k; ++d) a = fma(2.0 * S[(long)d * M + j], A[(long)d * M + j], a);
+    acc += a;
+  }
+  double tot = block_sum(acc, scratch);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
+template <template <int> class Launcher, typename... Args>
+static int dispatch_k(int k, Args... args) {
+  switch (k) {
+    case 1: return Launcher<1>::run(args...);
+    case 2: return Launcher<2>::run(args...);
+    case 3: return Launcher<3>::run(args...);
+    case 4: return Launcher<4>::run(args...);
+    case 5: return Launcher<5>::run(args...);
+    case 6: return Launcher<6>::run(args...);
+    case 7: return Launcher<7>::run(args...);
+    case 8: return Launcher<8>::run(args...);
+    default: set_error("bandwidth %d outside 1..%d", k, (int)ASVGP_MAX_BANDWIDTH); return ASVGP_ERR_UNSUPPORTED;
+  }
+}
+template <int K> struct CholLauncher {
+  static int run(const double* A, double* L, int M, int* info, hipStream_t st) {
+    hipLaunchKernelGGL(cholesky_band_kernel<K>, dim3(1), dim3(64), 0, st, A, L, M, info);
+    return check_launch("cholesky_band");
+  }
+};
+template <int K> struct TakaLauncher {
+  static int run(const double* L, double* S, int M, hipStream_t st) {
+    hipLaunchKernelGGL(takahashi_kernel<K>, dim3(1), dim3(64), 0, st, L, S, M);
+    return check_launch("inverse_from_cholesky_band");
+  }
+};
+template <int K> struct TrsvLauncher {
+  static int run(const double* L, int M, const double* B, double* X, long D, int trans, hipStream_t st) {
+    hipLaunchKernelGGL(trsv_kernel<K>, dim3((unsigned)D), dim3(64), 0, st, L, M, B, X, D, trans);
+    return check_launch("solve_triang_mat");
+  }
+};
+
+}  // namespace asvgp
+
+using namespace asvgp;
+
+extern "C" int asvgp_version(void) { return 100; }
+extern "C" const char* asvgp_last_error_string(void) { return g_err; }
+extern "C" const char* asvgp_status_name(int s) {
+  switch (s) {
+    case ASVGP_OK: return "ASVGP_OK";
+    case ASVGP_ERR_BAD_ARG: return "ASVGP_ERR_BAD_ARG";
+    case ASVGP_ERR_UNSUPPORTED: return "ASVGP_ERR_UNSUPPORTED";
+    case ASVGP_ERR_LDS_CAPACITY: return "ASVGP_ERR_LDS_CAPACITY";
+    case ASVGP_ERR_WORKSPACE: return "ASVGP_ERR_WORKSPACE";
+    case ASVGP_ERR_HIP: return "ASVGP_ERR_HIP";
+    default: return "ASVGP_ERR_UNKNOWN";
+  }
+}
+
+extern "C" int asvgp_matern_coeffs(int kind, double v, double l, double* c, double* dc, int* n_terms) {
+  if (!c || !dc || !n_terms || !(v > 0.0) || !(l > 0.0)) { set_error("matern_coeffs: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  const double s3 = sqrt(3.0), s5 = sqrt(5.0);
+  // term order: A, B, C, D, BC, BC_grad, BC_ggrad, BC_ggrad_none, BC_none_ggrad (those the kernel uses)
+  // expressions written exactly as inducing_features.py:17-42 writes them (same rounding sequence)
+  switch (kind) {
+    case ASVGP_MATERN12:
+      c[0] = 1 / (2 * l * v);      dc[0] = -1 / (2 * l * l * v);
+      c[1] = l / (2 * v);          dc[1] = 1 / (2 * v);
+      c[2] = 1 / (2 * v);          dc[2] = 0.0;
+      *n_terms = 3;
+      return ASVGP_OK;
+    case ASVGP_MATERN32:
+      c[0] = s3 / (4 * l * v);             dc[0] = -s3 / (4 * l * l * v);
+      c[1] = l / (2 * s3 * v);             dc[1] = 1 / (2 * s3 * v);
+      c[2] = pow(l, 3) / (12 * s3 * v);     dc[2] = 3 * l * l / (12 * s3 * v);
+      c[3] = 1 / (2 * v);                  dc[3] = 0.0;
+      c[4] = pow(l, 2) / (2 * v);          dc[4] = l / v;
+      *n_terms = 5;
+      return ASVGP_OK;
+    case ASVGP_MATERN52:
+      c[0] = (3 * s5) / (16 * l * v);                  dc[0] = -(3 * s5) / (16 * l * l * v);
+      c[1] = (9 * l) / (16 * s5 * v);                  dc[1] = 9 / (16 * s5 * v);
+      c[2] = (9 * pow(l, 3)) / (80 * s5 * v);          dc[2] = (27 * l * l) / (80 * s5 * v);
+      c[3] = (3 * pow(l, 5)) / (400 * s5 * v); dc[3] = (15 * l * l * l * l) / (400 * s5 * v);
+      c[4] = 9 / (16 * v);                             dc[4] = 0.0;
+      c[5] = (3 * pow(l, 2)) / (10 * v);                 dc[5] = (6 * l) / (10 * v);
+      c[6] = (9 * pow(l, 4)) / (400 * v);         dc[6] = (36 * l * l * l) / (400 * v);
+      c[7] = (3 * pow(l, 2)) / (80 * v);                 dc[7] = (6 * l) / (80 * v);
+      c[8] = (3 * pow(l, 2)) / (80 * v);                 dc[8] = (6 * l) / (80 * v);
+      *n_terms = 9;
+      return ASVGP_OK;
+    default:
+      set_error("matern_coeffs: unknown kernel kind %d", kind);
+      return ASVGP_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int asvgp_kuu_assemble(const double* static_bands, int n_terms, const double* coef, const double* dcoef,
+                                  int64_t M, int k, double* Kuu, double* dKuu_dl, asvgp_stream_t stream) {
+  if (!static_bands || !coef || !Kuu || n_terms < 1 || n_terms > ASVGP_MAX_KUU_TERMS || M < 1 || k < 0) {
+    set_error("kuu_assemble: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  KuuCoefs cf;
+  cf.n = n_terms;
+  for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) {
+    cf.c[t] = t < n_terms ? coef[t] : 0.0;
+    cf.dc[t] = (t < n_terms && dcoef) ? dcoef[t] : 0.0;
+  }
+  long E = (long)(k + 1) * M;
+  hipLaunchKernelGGL(kuu_assemble_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     static_bands, cf, E, Kuu, dKuu_dl);
+  return check_launch("kuu_assemble");
+}
+
+static int band_args_ok(const void* a, const void* b, int64_t M, int k, const char* who) {
+  if (!a || !b || M < 1) { set_error("%s: bad argument", who); return ASVGP_ERR_BAD_ARG; }
+  if (M > 0x3fffffff) { set_error("%s: M too large", who); return ASVGP_ERR_UNSUPPORTED; }
+  if (k < 1 || k > ASVGP_MAX_BANDWIDTH) { set_error("%s: bandwidth %d outside 1..%d", who, k, (int)ASVGP_MAX_BANDWIDTH); return ASVGP_ERR_UNSUPPORTED; }
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_cholesky_band(const double* K, double* L, int64_t M, int k, int* info, asvgp_stream_t stream) {
+  int rc = band_args_ok(K, L, M, k, "cholesky_band");
+  if (rc) return rc;
+  return dispatch_k<CholLauncher>(k, K, L, (int)M, info, as_stream(stream));
+}
+
+extern "C" int asvgp_inverse_from_cholesky_band(const double* L, double* S, int64_t M, int k, asvgp_stream_t stream) {
+  int rc = band_args_ok(L, S, M, k, "inverse_from_cholesky_band");
+  if (rc) return rc;
+  return dispatch_k<TakaLauncher>(k, L, S, (int)M, as_stream(stream));
+}
+
+extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* X, int64_t M, int k, int64_t D,
+                                      int transpose_left, asvgp_stream_t stream) {
+  int rc = band_args_ok(L, B, M, k, "solve_triang_mat");
+  if (rc) return rc;
+  if (!X || D < 1 || D > 65535) { set_error("solve_triang_mat: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  return dispatch_k<TrsvLauncher>(k, L, (int)M, B, X, (long)D, transpose_left, as_stream(stream));
+}
+
+#define EW_LAUNCH(kern, total, ...)                                                                        \
+  hipLaunchKernelGGL(kern, dim3((unsigned)(((total) + 255) / 256)), dim3(256), 0, as_stream(stream), __VA_ARGS__)
+
+extern "C" int asvgp_product_band_band(const double* left, const double* right, double* out, int64_t M, int ll,
+                                       int lu, int rl, int ru, int ol, int ou, asvgp_stream_t stream) {
+  if (!left || !right || !out || M < 1 || ll < 0 || lu < 0 || rl < 0 || ru < 0 || ol < 0 || ou < 0) {
+    set_error("product_band_band: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  EW_LAUNCH(product_band_band_kernel, (long)(ol + ou + 1) * M, left, right, out, (long)M, ll, lu, rl, ru, ol, ou);
+  return check_launch("product_band_band");
+}
+
+extern "C" int asvgp_transpose_band(const double* in, double* out, int64_t M, int lower, int upper,
+                                    asvgp_stream_t stream) {
+  if (!in || !out || in == out || M < 1 || lower < 0 || upper < 0) { set_error("transpose_band: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  EW_LAUNCH(transpose_band_kernel, (long)(lower + upper + 1) * M, in, out, (long)M, lower, upper);
+  return check_launch("transpose_band");
+}
+
+extern "C" int asvgp_symmetrise_band(const double* in, double* out, int64_t M, int lower, asvgp_stream_t stream) {
+  if (!in || !out || in == out || M < 1 || lower < 0) { set_error("symmetrise_band: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  EW_LAUNCH(symmetrise_band_kernel, (long)(2 * lower + 1) * M, in, out, (long)M, lower);
+  return check_launch("symmetrise_band");
+}
+
+extern "C" int asvgp_unpack_banded_matrix_to_dense(const double* band, double* dense, int64_t M, int lower, int upper,
+                                                   asvgp_stream_t stream) {
+  if (!band || !dense || M < 1 || lower < 0 || upper < 0) { set_error("unpack_banded_matrix_to_dense: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  EW_LAUNCH(unpack_band_kernel, (long)M * M, band, dense, (long)M, lower, upper);
+  return check_launch("unpack_banded_matrix_to_dense");
+}
+
+extern "C" int asvgp_pack_dense_matrix_to_banded(const double* dense, double* band, int64_t M, int lower, int upper,
+                                                 asvgp_stream_t stream) {
+  if (!band || !dense || M < 1 || lower < 0 || upper < 0) { set_error("pack_dense_matrix_to_banded: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  EW_LAUNCH(pack_band_kernel, (long)(lower + upper + 1) * M, dense, band, (long)M, lower, upper);
+  return check_launch("pack_dense_matrix_to_banded");
+}
+
+extern "C" int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, double* out,
+                                    asvgp_stream_t stream) {
+  if (!S || !A || !out || M < 1 || k < 0) { set_error("band_trace_sym: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(band_trace_sym_kernel, dim3(1), dim3(1024), 0, as_stream(stream), S, A, (long)M, k, out);
+  return check_launch("band_trace_sym");
+}

@@ -1,0 +1,271 @@
+// Fused ELBO + gradient and posterior-preparation drivers (stream-ordered, no host sync).
+//
+// Replaces GPR_1d.elbo (gpr.py:49-89) + the TF reverse-mode pass through banded_matrices' op gradients, and
+// the CHOLMOD factor/solve part of GPR_1d.predict_f (gpr.py:96-108).  Everything is O(M k^2) on (k+1) x M bands;
+// the two independent chains (Kuu with its d/d-lengthscale tangent, and P = Kuu + A/s with the rhs riding along)
+// run concurrently as two single-wave workgroups per phase.
+//
+//   phase 0  prepare  : Kuu, dKuu/dl (inducing_features.py:16-44), P = A/s + Kuu (gpr.py:72)          [elementwise]
+//   phase 1  factor   : block0 dual Cholesky(Kuu) (gpr.py:56) | block1 Cholesky(P) + c = L_P^-1 b (gpr.py:73-75)
+//   phase 2  inverse  : block0 dual Takahashi(Kuu) (gpr.py:59) | block1 Takahashi(P) + alpha = L_P^-T c
+//   phase 3  finalize : log-dets (gpr.py:57,74), band traces (gpr.py:60-70), 7-term bound (gpr.py:78-87), gradient
+#include "band_sweeps.hpp"
+
+namespace asvgp {
+
+struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]; int n; };
+
+__global__ void elbo_prepare_kernel(const double* __restrict__ S, KuuCoefs2 cf, long E, const double* __restrict__ A,
+                                    double s, double* __restrict__ Kuu, double* __restrict__ dK,
+                                    double* __restrict__ P) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double acc = __dmul_rn(cf.c[0], S[e]);
+  double dacc = __dmul_rn(cf.dc[0], S[e]);
+  for (int t = 1; t < cf.n; ++t) {
+    double sv = S[(long)t * E + e];
+    acc = __dadd_rn(acc, __dmul_rn(cf.c[t], sv));
+    dacc = __dadd_rn(dacc, __dmul_rn(cf.dc[t], sv));
+  }
+  Kuu[e] = acc;
+  if (dK) dK[e] = dacc;
+  P[e] = __dadd_rn(__ddiv_rn(A[e], s), acc);  // gpr.py:72  KufKfu / sigma2 + Kuu
+}
+
+template <int K, bool TANGENT, bool RHS>
+__global__ __launch_bounds__(64) void elbo_factor_kernel(const double* Kuu, const double* dK, const double* P,
+                                                         double* LK, double* dLK, double* LP, const double* b,
+                                                         double* c, int M, int* info) {
+  if (blockIdx.x == 0) {
+    if (TANGENT) cholesky_sweep<Dual, K, false>(BandPtr<Dual>{Kuu, dK}, BandOut<Dual>{LK, dLK}, M, nullptr, nullptr, info);
+    else cholesky_sweep<double, K, false>(BandPtr<double>{Kuu, nullptr}, BandOut<double>{LK, nullptr}, M, nullptr, nullptr, info);
+  } else {
+    cholesky_sweep<double, K, RHS>(BandPtr<double>{P, nullptr}, BandOut<double>{LP, nullptr}, M, b, c, info + 1);
+  }
+}
+
+template <int K, bool TANGENT, bool RHS>
+__global__ __launch_bounds__(64) void elbo_inverse_kernel(const double* LK, const double* dLK, const double* LP,
+                                                          double* SK, double* dSK, double* SP, const double* c,
+                                                          double* alpha, int M) {
+  if (blockIdx.x == 0) {
+    if (TANGENT) takahashi_sweep<Dual, K, false>(BandPtr<Dual>{LK, dLK}, BandOut<Dual>{SK, dSK}, M, nullptr, nullptr);
+    else takahashi_sweep<double, K, false>(BandPtr<double>{LK, nullptr}, BandOut<double>{SK, nullptr}, M, nullptr, nullptr);
+  } else {
+    takahashi_sweep<double, K, RHS>(BandPtr<double>{LP, nullptr}, BandOut<double>{SP, nullptr}, M, c, alpha);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void elbo_trsv_kernel(const double* L, int M, const double* B, double* X, long D,
+                                                       int trans, double scale) {
+  const long d = blockIdx.x;
+  if (trans) trsv_sweep<K, true>(L, M, B + d, X + d, D);
+  else trsv_sweep<K, false>(L, M, B + d, X + d, D);
+  (void)scale;
+}
+
+// sym-band quadratic form helper: x^T sym(S) x over columns handled by this thread
+__device__ __forceinline__ double quad_col(const double* S, long M, int k, long j, const double* x, long D, long d) {
+  double xj = x[j * D + d];
+  double a = S[j] * xj * xj;
+  for (int r = 1; r <= k; ++r)
+    if (j + r < M) a = fma(2.0 * S[(long)r * M + j] * xj, x[(j + r) * D + d], a);
+  return a;
+}
+
+struct ElboScalars { double v, l, s, N; };
+
+__global__ __launch_bounds__(1024) void elbo_finalize_kernel(
+    const double* __restrict__ stats, const double* __restrict__ Kuu, const double* __restrict__ dK,
+    const double* __restrict__ LK, const double* __restrict__ LP, const double* __restrict__ SK,
+    const double* __restrict__ dSK, const double* __restrict__ SP, const double* __restrict__ c,
+    const double* __restrict__ alpha, long M, int k, long D, ElboScalars th, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  const double* A = stats;
+  const double* b = stats + (long)(k + 1) * M;
+  const double yy = stats[(long)(k + 1) * M + M * D];
+  enum { LOGK, LOGP, TRKA, DTRKA, SKDK, SPDK, SKK, SPK, SPA, CC, AKA, ADKA, AAA, BA, NACC };
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  for (long j = threadIdx.x; j < M; j += blockDim.x) {
+    double lk = LK[j], lp = LP[j];
+    acc[LOGK] += log(lk * lk);  // gpr.py:57  log(square(L[0,:]))
+    acc[LOGP] += log(lp * lp);  // gpr.py:74
+    for (int r = 0; r <= k; ++r) {
+      long o = (long)r * M + j;
+      double w = (r == 0) ? 1.0 : 2.0;
+      double sk = SK[o], sp = SP[o], a = A[o], kk = Kuu[o], dk = dK[o];
+      acc[TRKA] = fma(w * sk, a, acc[TRKA]);
+      acc[DTRKA] = fma(w * dSK[o], a, acc[DTRKA]);
+      acc[SKDK] = fma(w * sk, dk, acc[SKDK]);
+      acc[SPDK] = fma(w * sp, dk, acc[SPDK]);
+      acc[SKK] = fma(w * sk, kk, acc[SKK]);
+      acc[SPK] = fma(w * sp, kk, acc[SPK]);
+      acc[SPA] = fma(w * sp, a, acc[SPA]);
+    }
+    for (long d = 0; d < D; ++d) {
+      double cv = c[j * D + d];
+      acc[CC] = fma(cv, cv, acc[CC]);
+      acc[AKA] += quad_col(Kuu, M, k, j, alpha, D, d);
+      acc[ADKA] += quad_col(dK, M, k, j, alpha, D, d);
+      acc[AAA] += quad_col(A, M, k, j, alpha, D, d);
+      acc[BA] = fma(b[j * D + d], alpha[j * D + d], acc[BA]);
+    }
+  }
+  double tot[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) tot[i] = block_sum(acc[i], scratch);
+  if (threadIdx.x == 0) {
+    const double v = th.v, s = th.s, N = th.N, Dd = (double)D;
+    const double two_pi = 6.283185307179586476925286766559;
+    double elbo = -0.5 * N * Dd * log(two_pi * s);
+    elbo -= 0.5 * Dd * tot[LOGP];
+    elbo += 0.5 * Dd * tot[LOGK];
+    elbo -= 0.5 * yy / s;
+    elbo += 0.5 * tot[CC];
+    elbo -= 0.5 * N * v / s;
+    elbo += 0.5 * tot[TRKA] / s;
+    // G = 1/2 (D Kuu^-1 - D P^-1 - alpha alpha^T - Kuu^-1 A Kuu^-1 / s)   
+    double d_l = 0.5 * (Dd * tot[SKDK] - Dd * tot[SPDK] - tot[ADKA] + tot[DTRKA] / s);
+    double d_v = 0.5 * (-Dd * tot[SKK] / v + Dd * tot[SPK] / v + tot[AKA] / v + tot[TRKA] / (v * s)) - 0.5 * N / s;
+    double s2 = s * s;
+    double d_s = -0.5 * N * Dd / s + 0.5 * Dd * tot[SPA] / s2 + 0.5 * yy / s2 + 0.5 * tot[AAA] / s2 - tot[BA] / s2 +
+                 0.5 * N * v / s2 - 0.5 * tot[TRKA] / s2;
+    out[0] = elbo; out[1] = d_v; out[2] = d_l; out[3] = d_s;
+    out[4] = tot[LOGK]; out[5] = tot[LOGP]; out[6] = tot[TRKA]; out[7] = tot[CC];
+  }
+}
+
+__global__ void scale_sub_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
+                                 long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] - b[i];
+}
+__global__ void scale_kernel(double* __restrict__ x, double f, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = x[i] * f;
+}
+
+struct Ws {
+  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha;
+};
+static size_t ws_doubles(long M, int k, long D) { return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64; }
+static Ws carve(void* ws, long M, int k, long D) {
+  double* p = static_cast<double*>(ws);
+  size_t E = (size_t)(k + 1) * M;
+  Ws w;
+  w.Kuu = p; p += E; w.dK = p; p += E; w.P = p; p += E; w.LK = p; p += E; w.dLK = p; p += E;
+  w.LP = p; p += E; w.SK = p; p += E; w.dSK = p; p += E; w.SP = p; p += E;
+  w.c = p; p += (size_t)M * D; w.alpha = p;
+  return w;
+}
+
+template <int K, bool TANGENT>
+static int run_chains(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+                      Ws w, int* info, hipStream_t st) {
+  KuuCoefs2 cf;
+  for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
+  int rc = asvgp_matern_coeffs(kind, v, l, cf.c, cf.dc, &cf.n);
+  if (rc) return rc;
+  const long E = (long)(K + 1) * M;
+  const double* A = stats;
+  const double* b = stats + E;
+  hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s, w.Kuu,
+                     w.dK, w.P);
+  if (D == 1) {
+    hipLaunchKernelGGL((elbo_factor_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.Kuu, w.dK, w.P, w.LK, w.dLK,
+                       w.LP, b, w.c, (int)M, info);
+    hipLaunchKernelGGL((elbo_inverse_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.LK, w.dLK, w.LP, w.SK,
+                       w.dSK, w.SP, w.c, w.alpha, (int)M);
+  } else {
+    hipLaunchKernelGGL((elbo_factor_kernel<K, TANGENT, false>), dim3(2), dim3(64), 0, st, w.Kuu, w.dK, w.P, w.LK,
+                       w.dLK, w.LP, b, w.c, (int)M, info);
+    hipLaunchKernelGGL(elbo_trsv_kernel<K>, dim3((unsigned)D), dim3(64), 0, st, w.LP, (int)M, b, w.c, D, 0, 1.0);
+    hipLaunchKernelGGL((elbo_inverse_kernel<K, TANGENT, false>), dim3(2), dim3(64), 0, st, w.LK, w.dLK, w.LP, w.SK,
+                       w.dSK, w.SP, w.c, w.alpha, (int)M);
+    hipLaunchKernelGGL(elbo_trsv_kernel<K>, dim3((unsigned)D), dim3(64), 0, st, w.LP, (int)M, w.c, w.alpha, D, 1, 1.0);
+  }
+  // c = L_P^-1 b / s (gpr.py:75), alpha = P^-1 b / s
+  long n = M * D;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.c, 1.0 / s, n);
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
+  return check_launch("elbo chains");
+}
+
+template <int K> struct ElboLauncher {
+  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
+                 double* out, int* info, void* ws, hipStream_t st) {
+    Ws w = carve(ws, M, K, D);
+    int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st);
+    if (rc) return rc;
+    ElboScalars th{v, l, s, (double)N};
+    hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(1024), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK, w.dSK,
+                       w.SP, w.c, w.alpha, M, K, D, th, out);
+    return check_launch("elbo_grad_1d");
+  }
+};
+template <int K> struct PostLauncher {
+  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+                 double* alpha, double* W, int* info, void* ws, hipStream_t st) {
+    Ws w = carve(ws, M, K, D);
+    int rc = run_chains<K, false>(stats, S, kind, v, l, s, M, D, w, info, st);
+    if (rc) return rc;
+    long E = (long)(K + 1) * M;
+    hipLaunchKernelGGL(scale_sub_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, w.SP, w.SK, W, E);
+    hipError_t e = hipMemcpyAsync(alpha, w.alpha, sizeof(double) * M * D, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+    return check_launch("posterior_prepare_1d");
+  }
+};
+
+}  // namespace asvgp
+
+using namespace asvgp;
+
+extern "C" size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D) {
+  if (M < 1 || k < 1 || D < 1) return 0;
+  return sizeof(double) * ws_doubles(M, k, D);
+}
+
+static int elbo_args_ok(const void* stats, const void* S, const void* out, int64_t M, int k, int64_t D, double v,
+                        double l, double s, void* ws, size_t wsb, int* info, const char* who) {
+  if (!stats || !S || !out || !info || M < 1 || D < 1 || D > 65535 || !(v > 0.0) || !(l > 0.0) || !(s > 0.0)) {
+    set_error("%s: bad argument", who);
+    return ASVGP_ERR_BAD_ARG;
+  }
+  if (k < 1 || k > ASVGP_MAX_ORDER) { set_error("%s: bandwidth %d outside 1..%d", who, k, (int)ASVGP_MAX_ORDER); return ASVGP_ERR_UNSUPPORTED; }
+  if (M > 0x3fffffff) { set_error("%s: M too large", who); return ASVGP_ERR_UNSUPPORTED; }
+  if (!ws || wsb < asvgp_elbo_workspace_bytes(M, k, D)) { set_error("%s: workspace too small", who); return ASVGP_ERR_WORKSPACE; }
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind, double variance,
+                                  double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                                  double* out, int* info, void* workspace, size_t workspace_bytes,
+                                  asvgp_stream_t stream) {
+  int rc = elbo_args_ok(stats, static_bands, out, M, k, D, variance, lengthscale, noise_variance, workspace,
+                        workspace_bytes, info, "elbo_grad_1d");
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st);
+  switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
+#undef ELBO_CASE
+  return ASVGP_ERR_UNSUPPORTED;
+}
+
+extern "C" int asvgp_posterior_prepare_1d(const double* stats, const double* static_bands, int kind, double variance,
+                                          double lengthscale, double noise_variance, int64_t M, int k, int64_t D,
+                                          double* alpha, double* W, int* info, void* workspace, size_t workspace_bytes,
+                                          asvgp_stream_t stream) {
+  int rc = elbo_args_ok(stats, static_bands, alpha, M, k, D, variance, lengthscale, noise_variance, workspace,
+                        workspace_bytes, info, "posterior_prepare_1d");
+  if (rc) return rc;
+  if (!W) { set_error("posterior_prepare_1d: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+#define POST_CASE(KK) case KK: return PostLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)M, (long)D, alpha, W, info, workspace, st);
+  switch (k) { POST_CASE(1) POST_CASE(2) POST_CASE(3) POST_CASE(4) POST_CASE(5) POST_CASE(6) }
+#undef POST_CASE
+  return ASVGP_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,147 @@
+/* asvgp_hip.h  --  C-ABI of the MI355X-native ASVGP hot path (libasvgp_hip.so, gfx950).
+ *
+ * Drop-in boundary: these entry points replace, for the asvgp.gpr ELBO/posterior
+ * path only, (i) the scipy/TF work of asvgp/basis.py + gpr.py:39-44 (the N-dependent Phi pass) and
+ * (ii) the `banded_matrices.banded` TensorFlow custom ops called at gpr.py:56-75 / utils.py:7-9.
+ * Paths below are relative to the reference checkout (HJakeCunningham/ASVGP).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`; the caller owns every buffer
+ *     (e.g. torch tensors' data_ptr()); the library allocates nothing.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and is
+ *     asynchronous; no entry point synchronises the device.
+ *   - return value: ASVGP_OK or a negative asvgp_status; asvgp_last_error_string() describes the last failure
+ *     on the calling thread.  Numerical failure (band not positive definite) is reported asynchronously
+ *     in the device slot `info`: 0 = ok, j+1 = first failing column j.
+ *   - band layout = banded_matrices layout: an n x n matrix with lower bandwidth l and upper bandwidth u is a
+ *     dense row-major (l+u+1) x n array with band[(u + i - j) * n + j] = A[i][j] (row u = main diagonal,
+ *     sub-diagonal d right-padded with d zeros).  A "lower band" has u = 0 and k = l rows below the diagonal.
+ *   - fp64 throughout ("f64" is the arithmetic type of the reference path).
+ */
+#ifndef ASVGP_HIP_H
+#define ASVGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* asvgp_stream_t; /* hipStream_t */
+
+typedef enum {
+  ASVGP_OK = 0,
+  ASVGP_ERR_BAD_ARG = -1,      /* null pointer, negative size, inconsistent shapes */
+  ASVGP_ERR_UNSUPPORTED = -2,  /* spline order / bandwidth / kernel kind outside the built range */
+  ASVGP_ERR_LDS_CAPACITY = -3, /* problem does not fit the 160 KiB LDS even after column chunking */
+  ASVGP_ERR_WORKSPACE = -4,    /* workspace pointer null or too small */
+  ASVGP_ERR_HIP = -5           /* a HIP runtime call failed (launch error) */
+} asvgp_status;
+
+enum { ASVGP_MATERN12 = 0, ASVGP_MATERN32 = 1, ASVGP_MATERN52 = 2 };
+enum { ASVGP_MAX_ORDER = 6, ASVGP_MAX_BANDWIDTH = 8, ASVGP_MAX_KUU_TERMS = 9 };
+
+int asvgp_version(void);
+const char* asvgp_last_error_string(void);
+const char* asvgp_status_name(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Phi pass: B-spline design matrix + sufficient statistics, fused
+ * replaces  basis.py:51-76 (SplineBasis.evaluate_basis -> CSR Phi), inducing_features.py:47-48 (make_Kuf),
+ *           gpr.py:41-44 (Kuf@y, Kuf@Kuf.T, utils.sparse_to_band utils.py:24-30, sum y^2)
+ * x: (N) inputs, y: (N, D) row-major targets, mesh: (n_mesh = M - order + 1) knots exactly as
+ * basis.py:17 makes them (including its float32 rounding), delta = mesh[1]-mesh[0] (basis.py:18).
+ * stats (output, overwritten): packed [ (order+1)*M lower band of Phi Phi^T | M*D  Phi y | 1  sum y^2 ].
+ * This packed buffer is what one RCCL all-reduce(sum) combines across N-shards.
+ * ---------------------------------------------------------------------------------------------- */
+size_t asvgp_phi_workspace_bytes(int64_t M, int order, int64_t D);
+int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t D,
+                            const double* mesh, int64_t n_mesh, double delta, int order, int64_t M,
+                            double* stats, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+
+/* basis.py:58-59  neighbour_index = relu(searchsorted_left(mesh, x) - 1)  (integer work, bit-exact) */
+int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,
+                       int64_t* idx, asvgp_stream_t stream);
+
+/* basis.py:62,72-73  the COO triplets of Phi in the reference's concat order:
+ * rows[i*N + n] = idx[n] + order - i, data[i*N + n] = piece i of point n (deriv-th x-derivative, 0..3). */
+int asvgp_phi_evaluate_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,
+                          int order, int deriv, int64_t* rows, double* data, asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kuu assembly   replaces inducing_features.py:12-44 (SplineFeatures1D.make_Kuu)
+ * asvgp_matern_coeffs fills (host) the coefficient of each static band and its d/d lengthscale in the
+ * fixed term order  A, B, C, D, BC, BC_grad, BC_ggrad, BC_ggrad_none, BC_none_ggrad  restricted to the
+ * terms the kernel uses (Matern12: A,B,BC; Matern32: A,B,C,BC,BC_grad; Matern52: all nine).
+ * static_bands: (n_terms, k+1, M) device array in that order.  dKuu_dl may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int asvgp_matern_coeffs(int kind, double variance, double lengthscale, double* coef_host, double* dcoef_dl_host,
+                        int* n_terms_host);
+int asvgp_kuu_assemble(const double* static_bands, int n_terms, const double* coef_host,
+                       const double* dcoef_dl_host, int64_t M, int k, double* Kuu, double* dKuu_dl,
+                       asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * banded_matrices.banded operator replacements (reference call sites in brackets)
+ * ---------------------------------------------------------------------------------------------- */
+/* cholesky_band(K) [gpr.py:56,73]: lower band (k+1, M) -> lower band of L. */
+int asvgp_cholesky_band(const double* K, double* L, int64_t M, int k, int* info, asvgp_stream_t stream);
+/* inverse_from_cholesky_band(L) [gpr.py:59]: lower band of (L L^T)^-1 restricted to the band. */
+int asvgp_inverse_from_cholesky_band(const double* L, double* S, int64_t M, int k, asvgp_stream_t stream);
+/* solve_triang_mat(L, B) [gpr.py:75]: X = L^-1 B (transpose_left=0) or L^-T B (1); B, X: (M, D) row-major. */
+int asvgp_solve_triang_mat(const double* L, const double* B, double* X, int64_t M, int k, int64_t D,
+                           int transpose_left, asvgp_stream_t stream);
+/* product_band_band(left, right, ...) [gpr.py:60-69]: banded x banded cropped to the result band. */
+int asvgp_product_band_band(const double* left, const double* right, double* out, int64_t M,
+                            int left_lower, int left_upper, int right_lower, int right_upper,
+                            int result_lower, int result_upper, asvgp_stream_t stream);
+/* transpose_band(B, l, u) [utils.py:8]: (l,u) band of A -> (u,l) band of A^T. */
+int asvgp_transpose_band(const double* in, double* out, int64_t M, int lower, int upper, asvgp_stream_t stream);
+/* symmetrise_band(B, l) [gpr.py:62; utils.py:7-9]: lower band (l+1, M) -> symmetric band (2l+1, M). */
+int asvgp_symmetrise_band(const double* in, double* out, int64_t M, int lower, asvgp_stream_t stream);
+/* unpack_banded_matrix_to_dense / pack_dense_matrix_to_banded [utils.py:40-55] (test helpers; the hot path never densifies). */
+int asvgp_unpack_banded_matrix_to_dense(const double* band, double* dense, int64_t M, int lower, int upper,
+                                        asvgp_stream_t stream);
+int asvgp_pack_dense_matrix_to_banded(const double* dense, double* band, int64_t M, int lower, int upper,
+                                      asvgp_stream_t stream);
+/* fused gpr.py:59-70: out[0] = trace(sym(S) sym(A)) for two lower bands (the only use of product_band_band on the path). */
+int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, double* out, asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused ELBO + gradient   replaces GPR_1d.elbo gpr.py:49-89 and the TF reverse-mode pass through the
+ * banded_matrices op gradients that opt.minimize(training_loss) triggers (example.py:31-32).
+ * stats: packed buffer of asvgp_phi_accumulate_1d (after the cross-rank sum); N = GLOBAL number of rows.
+ * out (device, 8 doubles): [elbo, d/d variance, d/d lengthscale, d/d noise variance, log|Kuu|, log|P|,
+ *                           trace(Kuu^-1 PhiPhi^T), |c|^2].
+ * ---------------------------------------------------------------------------------------------- */
+size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D);
+int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind, double variance,
+                       double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                       double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Posterior   replaces GPR_1d.predict_f gpr.py:91-120 (CHOLMOD natural-ordering solves)
+ * prepare: alpha = P^-1 Phi y / s  (M, D)  and  W = band(P^-1) - band(Kuu^-1)  (k+1, M), once per theta.
+ * predict: per test point mean = phi*^T alpha, var = variance + phi*^T W phi*  (full_cov=False only).
+ * ---------------------------------------------------------------------------------------------- */
+int asvgp_posterior_prepare_1d(const double* stats, const double* static_bands, int kind, double variance,
+                               double lengthscale, double noise_variance, int64_t M, int k, int64_t D,
+                               double* alpha, double* W, int* info, void* workspace, size_t workspace_bytes,
+                               asvgp_stream_t stream);
+int asvgp_predict_1d(const double* xnew, int64_t n, const double* mesh, int64_t n_mesh, double delta, int order,
+                     int64_t M, const double* alpha, const double* W, double variance, int64_t D, double* mean,
+                     double* var, asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): when enabled, HIP events are recorded on the launch stream immediately around
+ * every Phi-pass kernel launch (up to 1024 launches); asvgp_profile_read synchronises on them and returns the
+ * summed kernel time in milliseconds and the number of launches, then resets the ring.  Host-side, not stream-ordered.
+ * ---------------------------------------------------------------------------------------------- */
+int asvgp_profile_enable(int on);
+int asvgp_profile_read(double* phi_kernel_ms_sum_host, int64_t* launches_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASVGP_HIP_H */

@@ -1,0 +1,393 @@
+"""GPU parity: the HIP path (through the C-ABI, via asvgp_amd) against the CPU oracle and the golden fixtures.
+Tolerances: indices/structure bit-exact; band/rhs/yy rel 1e-12; ELBO rel 1e-9; gradient rel 1e-6;
+posterior abs 1e-8."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import asvgp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {0: "Matern12", 1: "Matern32", 2: "Matern52"}
+
+
+@pytest.fixture(scope="module")
+def A():
+    import asvgp_amd
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from asvgp_amd import _lib
+    _lib.get_lib()  # must load: no fallback
+    return asvgp_amd
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _spec(F, tag):
+    order, a, b, m, isf = F[tag + "/spec"]
+    order, m = int(order), int(m)
+    a, b = (float(a), float(b)) if isf else (int(a), int(b))
+    return order, a, b, m
+
+
+def _mk_basis(A, order, a, b, m):
+    return getattr(A, "B%dSpline" % order)(a, b, m)
+
+
+def _kernel(A, kind, v, l):
+    return getattr(A, KINDS[kind])(variance=v, lengthscales=l)
+
+
+# ------------------------------------------------------------------------------------------------ basis / Phi
+def test_index_and_design_matrix_vs_reference_fixtures(A, golden_dir):
+    F = np.load(os.path.join(golden_dir, "basis_fixtures.npz"))
+    for tag in F["tags"]:
+        order, a, b, m = _spec(F, tag)
+        bs = _mk_basis(A, order, a, b, m)
+        assert np.array_equal(bs.mesh.cpu().numpy(), F[tag + "/mesh"]), tag
+        x = F[tag + "/x"]
+        idx = bs.neighbour_index(dev(x)).cpu().numpy()
+        assert np.array_equal(idx, F[tag + "/idx"]), tag                      # integer work: bit exact
+        rows, cols, data = bs.evaluate_basis_coo(dev(x))
+        orow, ocol, odata = O.evaluate_basis_coo(F[tag + "/mesh"], float(F[tag + "/delta"]), order, m, x)
+        assert np.array_equal(rows.cpu().numpy(), orow), tag
+        assert np.array_equal(cols.cpu().numpy(), ocol), tag
+        np.testing.assert_allclose(data.cpu().numpy(), odata, rtol=0, atol=2e-14, err_msg=tag)
+        csr = bs.evaluate_basis(dev(x).reshape(-1, 1))
+        dense = csr.to_dense().cpu().numpy()
+        import scipy.sparse as sp
+        ref = sp.csr_matrix((F[tag + "/csr_data"], F[tag + "/csr_indices"], F[tag + "/csr_indptr"]), shape=(m, x.shape[0]))
+        np.testing.assert_allclose(dense, ref.toarray(), rtol=0, atol=2e-14, err_msg=tag)
+
+
+def test_basis_derivatives_vs_oracle(A):
+    rng = np.random.default_rng(5)
+    for order in range(1, 7):
+        bs = _mk_basis(A, order, 0, 2, 30)
+        ob = O.Basis(order, 0, 2, 30)
+        x = rng.uniform(0, 2, 257)
+        for dx in range(0, min(order, 3) + 1):
+            rows, cols, data = bs.evaluate_basis_coo(dev(x), dx=dx)
+            orow, ocol, odata = O.evaluate_basis_coo(ob.mesh, ob.delta, order, 30, x, dx)
+            assert np.array_equal(rows.cpu().numpy(), orow)
+            np.testing.assert_allclose(data.cpu().numpy(), odata, rtol=1e-12, atol=1e-12 * np.max(np.abs(odata)))
+
+
+def test_static_bands_and_kuu_bit_level(A, golden_dir):
+    F = np.load(os.path.join(golden_dir, "basis_fixtures.npz"))
+    for tag in F["tags"]:
+        order, a, b, m = _spec(F, tag)
+        bs = _mk_basis(A, order, a, b, m)
+        for nm in ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad"):
+            if tag + "/" + nm in F:
+                ref = F[tag + "/" + nm]
+                mine = getattr(bs, nm).cpu().numpy()
+                assert np.max(np.abs(ref - mine)) <= 4e-15 * max(np.max(np.abs(ref)), 1e-300), (tag, nm)
+    K = np.load(os.path.join(golden_dir, "kuu_fixtures.npz"))
+    specs = {"B3_f": (3, -3.5, 10.5, 30), "B4_i": (4, 0, 1, 64), "B2_i": (2, 0, 1, 17), "B5_i": (5, -2, 3, 33),
+             "B1_i": (1, 0, 1, 16), "B6_i": (6, 0, 1, 40)}
+    kid = {"Matern12": 0, "Matern32": 1, "Matern52": 2}
+    for key in K.files:
+        if key == "thetas":
+            continue
+        tag, kn, ti = key.split("/")
+        v, l = K["thetas"][int(ti)]
+        bs = _mk_basis(A, *specs[tag])
+        kern = _kernel(A, kid[kn], v, l)
+        feat = A.SplineFeatures1D(kern, bs)
+        Kuu, dK = feat.make_Kuu(kern, with_dl=True)
+        ref = K[key]
+        assert np.max(np.abs(Kuu.cpu().numpy() - ref)) <= 4e-15 * np.max(np.abs(ref)), key
+        _, odK = O.make_Kuu(O.Basis(*specs[tag]), kid[kn], v, l, want_dl=True)
+        np.testing.assert_allclose(dK.cpu().numpy(), odK, rtol=1e-13, atol=1e-13 * np.max(np.abs(odK)))
+    with pytest.raises(AttributeError):
+        b1 = _mk_basis(A, 1, 0, 1, 16)
+        A.SplineFeatures1D(A.Matern32(), b1).make_Kuu(A.Matern32())
+
+
+@pytest.mark.parametrize("order,M,N", [(1, 16, 1000), (2, 17, 999), (3, 30, 4097), (4, 64, 20000), (5, 33, 3001),
+                                        (6, 40, 2048), (4, 1024, 50001)])
+def test_phi_accumulate_vs_oracle(A, order, M, N):
+    rng = np.random.default_rng(order * 1000 + M)
+    a, b = (0, 1) if order != 5 else (-2, 3)
+    bs = _mk_basis(A, order, a, b, M)
+    ob = O.Basis(order, a, b, M)
+    x = rng.uniform(a + 1e-9, b - 1e-9, N)
+    x[:8] = ob.mesh[1:9]                      # points exactly on knots
+    y = np.sin(20 * x) + 0.1 * rng.normal(size=N)
+    model = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern12(), bs)
+    band, rhs, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+    got = model.KufKfu.cpu().numpy()
+    sc = np.max(np.abs(band))
+    assert np.max(np.abs(got - band)) <= 1e-12 * sc
+    assert np.array_equal(got == 0, band == 0)            # structural zeros of the right-padded band
+    np.testing.assert_allclose(model.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)))
+    assert abs(model.tr_yTy.item() - yy) <= 1e-12 * yy
+    if N <= 5000:  # the CSR/SpGEMM route the reference takes gives the same numbers
+        band2, rhs2, _ = O.sufficient_stats(ob, x.reshape(-1, 1), y.reshape(-1, 1))
+        assert np.max(np.abs(got - band2)) <= 1e-12 * sc
+
+
+def test_phi_edge_cases(A):
+    bs = _mk_basis(A, 3, 0, 1, 24)
+    ob = O.Basis(3, 0, 1, 24)
+    # empty input
+    m0 = A.GPR_1d((np.zeros((0, 1)), np.zeros((0, 1))), A.Matern12(), bs)
+    assert float(m0._stats.abs().sum()) == 0.0
+    # single point, odd counts, unaligned (sliced) inputs, two output columns
+    rng = np.random.default_rng(1)
+    for N in (1, 2, 3, 2047, 2049):
+        x = rng.uniform(0.001, 0.999, N + 1)
+        y = rng.normal(size=(N + 1, 2))
+        xs = dev(x)[1:].reshape(-1, 1)            # 8-byte-aligned only -> scalar load path
+        m = A.GPR_1d((xs, dev(y)[1:]), A.Matern12(), bs)
+        band, rhs, yy = O.sufficient_stats_direct(ob, x[1:], y[1:])
+        assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= 1e-12 * np.max(np.abs(band))
+        np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * max(np.max(np.abs(rhs)), 1e-300))
+        assert abs(m.tr_yTy.item() - yy) <= 1e-12 * yy
+    with pytest.raises(AssertionError):
+        A.GPR_1d((np.array([[0.0], [0.5]]), np.zeros((2, 1))), A.Matern12(), bs)   # gpr.py:25: X > a strictly
+    with pytest.raises(AssertionError):
+        A.GPR_1d((np.array([[0.5, 0.5]]), np.zeros((1, 1))), A.Matern12(), bs)     # gpr.py:23
+
+
+def test_phi_full_size_properties(A):
+    """BASELINE config 2 size (N=1M, M=1024, k=4): size-independent properties instead of an O(N) oracle run."""
+    N, M = 1_000_000, 1024
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * (1 - 2e-9) + 1e-9
+    y = torch.sin(20 * x) + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+    bs = A.B4Spline(0, 1, M)
+    m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern32(), bs)
+    band = m.KufKfu
+    # partition of unity: 1^T Phi Phi^T 1 = N and 1^T Phi y = sum y
+    tot = band[0].sum() + 2 * band[1:].sum()
+    assert abs(tot.item() - N) <= 1e-9 * N
+    assert abs(m.Kuf_y.sum().item() - y.sum().item()) <= 1e-9 * y.abs().sum().item()
+    assert abs(m.tr_yTy.item() - (y * y).sum().item()) <= 1e-12 * (y * y).sum().item()
+    # diagonal dominance of Phi Phi^T entries: band[0] >= 0, |band[d,j]| <= sqrt(band[0,j] band[0,j+d])
+    assert (band[0] >= 0).all()
+    for d in range(1, 5):
+        assert (band[d, :M - d].abs() <= torch.sqrt(band[0, :M - d] * band[0, d:]) * (1 + 1e-12)).all()
+        assert (band[d, M - d:] == 0).all()
+    # linearity over shards: stats(all) = stats(first half) + stats(second half)
+    h = N // 2
+    m1 = A.GPR_1d((x[:h].reshape(-1, 1), y[:h].reshape(-1, 1)), A.Matern32(), bs)
+    m2 = A.GPR_1d((x[h:].reshape(-1, 1), y[h:].reshape(-1, 1)), A.Matern32(), bs)
+    s12 = m1._stats + m2._stats
+    assert (s12 - m._stats).abs().max().item() <= 1e-11 * m._stats.abs().max().item()
+    # sorted input (time-series order) gives the same statistics
+    xs, order = torch.sort(x)
+    m3 = A.GPR_1d((xs.reshape(-1, 1), y[order].reshape(-1, 1)), A.Matern32(), bs)
+    assert (m3._stats - m._stats).abs().max().item() <= 1e-11 * m._stats.abs().max().item()
+    # and on a 20k subsample the oracle agrees
+    ob = O.Basis(4, 0, 1, M)
+    sub = slice(0, 20000)
+    ms = A.GPR_1d((x[sub].reshape(-1, 1), y[sub].reshape(-1, 1)), A.Matern32(), bs)
+    ob_band, ob_rhs, _ = O.sufficient_stats_direct(ob, x[sub].cpu().numpy(), y[sub].cpu().numpy().reshape(-1, 1))
+    assert np.max(np.abs(ms.KufKfu.cpu().numpy() - ob_band)) <= 1e-12 * np.max(np.abs(ob_band))
+
+
+def test_phi_large_M_column_chunks(A):
+    """M = 4096, k = 4 (BASELINE config 3 shape) exceeds one LDS image: column-chunked passes must agree."""
+    rng = np.random.default_rng(11)
+    N, M = 30000, 4096
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = rng.normal(size=(N, 1))
+    bs = A.B4Spline(0, 1, M)
+    m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern52(), bs)
+    band, rhs, yy = O.sufficient_stats_direct(O.Basis(4, 0, 1, M), x, y)
+    assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= 1e-12 * np.max(np.abs(band))
+    np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)))
+    assert abs(m.tr_yTy.item() - yy) <= 1e-12 * yy
+
+
+# ------------------------------------------------------------------------------------------------ banded ops
+def _spd_band(rng, k, M):
+    Bm = rng.normal(size=(M, M))
+    dense = Bm @ Bm.T
+    dense = np.triu(np.tril(dense, k), -k)
+    dense += np.eye(M) * (np.abs(dense).sum(1).max() + 1.0)
+    return dense, O.pack_dense_matrix_to_banded(dense, k, 0)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_banded_operator_api_vs_oracle(A, k):
+    from asvgp_amd import banded
+    rng = np.random.default_rng(k)
+    for M in (k + 1, 9, 63, 64, 65, 130, 257, 1000):
+        if M <= k:
+            continue
+        dense, lower = _spd_band(rng, k, M)
+        L = banded.cholesky_band(dev(lower))
+        oL = O.cholesky_band(lower)
+        np.testing.assert_allclose(L.cpu().numpy(), oL, rtol=0, atol=1e-12 * np.max(np.abs(oL)), err_msg="M=%d" % M)
+        assert np.array_equal(L.cpu().numpy() == 0, oL == 0)
+        S = banded.inverse_from_cholesky_band(L)
+        oS = O.inverse_from_cholesky_band(oL)
+        np.testing.assert_allclose(S.cpu().numpy(), oS, rtol=0, atol=1e-12 * np.max(np.abs(oS)), err_msg="M=%d" % M)
+        for D in (1, 3):
+            rhs = rng.normal(size=(M, D))
+            np.testing.assert_allclose(banded.solve_triang_mat(L, dev(rhs)).cpu().numpy(), O.solve_triang_mat(oL, rhs),
+                                       rtol=0, atol=1e-11)
+            np.testing.assert_allclose(banded.solve_triang_mat(L, dev(rhs), transpose_left=True).cpu().numpy(),
+                                       O.solve_triang_mat(oL, rhs, True), rtol=0, atol=1e-11)
+        sym = banded.symmetrise_band(dev(lower), k)
+        assert np.array_equal(sym.cpu().numpy(), O.symmetrise_band(lower, k))            # index shuffles: bit exact
+        assert np.array_equal(A.utils.symmetrise_banded(dev(lower)).cpu().numpy(), O.symmetrise_band(lower, k))
+        assert np.array_equal(banded.unpack_banded_matrix_to_dense(sym, k, k).cpu().numpy(), dense)
+        assert np.array_equal(banded.pack_dense_matrix_to_banded(dev(dense), k, 0).cpu().numpy(), lower)
+        assert np.array_equal(banded.transpose_band(dev(lower), k, 0).cpu().numpy(), O.transpose_band(lower, k, 0))
+        if M <= 130:
+            prod = banded.product_band_band(sym, sym, left_lower_bandwidth=k, left_upper_bandwidth=k,
+                                            right_lower_bandwidth=k, right_upper_bandwidth=k,
+                                            result_lower_bandwidth=0, result_upper_bandwidth=0)
+            np.testing.assert_allclose(prod.cpu().numpy(), O.product_band_band(O.symmetrise_band(lower, k),
+                                       O.symmetrise_band(lower, k), k, k, k, k, 0, 0), rtol=1e-13)
+            g = np.triu(np.tril(rng.normal(size=(M, M)), 2), -1)   # lower bw 1, upper bw 2
+            gb = O.pack_dense_matrix_to_banded(g, 1, 2)
+            assert np.array_equal(banded.transpose_band(dev(gb), 1, 2).cpu().numpy(), O.transpose_band(gb, 1, 2))
+            pr = banded.product_band_band(dev(gb), sym, 1, 2, k, k, 2, 1)
+            np.testing.assert_allclose(pr.cpu().numpy(), O.product_band_band(gb, O.symmetrise_band(lower, k), 1, 2, k, k, 2, 1),
+                                       rtol=1e-12, atol=1e-12)
+        tr = banded.band_trace_sym(S, dev(lower)).item()
+        assert abs(tr - O.band_sym_dot(oS, lower)) <= 1e-10 * abs(tr)
+
+
+def test_cholesky_not_positive_definite_reports_column(A):
+    from asvgp_amd import banded
+    bad = np.array([[4.0, 1.0, -3.0, 2.0], [1.0, 0.5, 0.2, 0.0]])
+    with pytest.raises(banded.NotPositiveDefiniteError) as ei:
+        banded.cholesky_band(dev(bad))
+    assert "column 2" in str(ei.value)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.cholesky_band(bad)
+
+
+# ------------------------------------------------------------------------------------------------ ELBO / gradient
+@pytest.fixture(scope="module")
+def S(golden_dir):
+    return np.load(os.path.join(golden_dir, "snelson_fixtures.npz"))
+
+
+def test_snelson_statistics_vs_reference_fixture(A, S):
+    for tag, (o, m) in {"B3_30": (3, 30), "B3_100": (3, 100), "B4_30": (4, 30)}.items():
+        bs = _mk_basis(A, o, -3.5, 10.5, m)
+        model = A.GPR_1d((S["X"], S["Y"]), A.Matern32(), bs)
+        np.testing.assert_allclose(model.KufKfu.cpu().numpy(), S[tag + "/KufKfu"], rtol=0, atol=1e-12 * np.max(S[tag + "/KufKfu"]))
+        np.testing.assert_allclose(model.Kuf_y.cpu().numpy(), S[tag + "/Kuf_y"], rtol=0, atol=1e-12 * np.max(np.abs(S[tag + "/Kuf_y"])))
+        assert abs(model.tr_yTy.item() - S[tag + "/tr_yTy"]) < 1e-12 * S[tag + "/tr_yTy"]
+        assert model.bandwidth == o
+        dense = model.KufKfu_sparse.to_dense().cpu().numpy()
+        np.testing.assert_allclose(dense, O.band_to_dense_sym(S[tag + "/KufKfu"]), atol=1e-12)
+
+
+def test_elbo_table_and_gradient(A, S):
+    X, Y = S["X"], S["Y"]
+    for o, m, kd, v, l, s, e in S["elbo_table"]:
+        o, m, kd = int(o), int(m), int(kd)
+        bs = _mk_basis(A, o, -3.5, 10.5, m)
+        kern = _kernel(A, kd, v, l)
+        model = A.GPR_1d((X, Y), kern, bs)
+        model.likelihood.variance.assign(s)
+        got = model.elbo().item()
+        assert abs(got - e) <= 1e-9 * abs(e), (o, m, kd, v, l, s)
+        assert abs(model.maximum_log_likelihood_objective().item() - e) <= 1e-9 * abs(e)
+        assert abs(model.training_loss().item() + e) <= 1e-9 * abs(e)
+        ob = O.Basis(o, -3.5, 10.5, m)
+        Ab, b, yy = O.sufficient_stats(ob, X, Y)
+        oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, 200, v, l, s)
+        r = model.elbo_and_grad().cpu().numpy()
+        assert abs(r[0] - oe) <= 1e-9 * abs(oe)
+        np.testing.assert_allclose(r[1:4], og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
+
+
+def test_elbo_synthetic_medium_vs_oracle(A):
+    rng = np.random.default_rng(3)
+    N, M = 20000, 256
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    for kd, order in ((1, 4), (2, 4), (0, 2), (2, 5), (1, 6)):
+        bs = _mk_basis(A, order, 0, 1, M)
+        model = A.GPR_1d((x.reshape(-1, 1), y), _kernel(A, kd, 1.0, 0.05), bs)
+        model.likelihood.variance.assign(0.01)
+        ob = O.Basis(order, 0, 1, M)
+        Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
+        oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, N, 1.0, 0.05, 0.01)
+        r = model.elbo_and_grad().cpu().numpy()
+        assert abs(r[0] - oe) <= 1e-9 * abs(oe), (kd, order)
+        np.testing.assert_allclose(r[1:4], og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)), err_msg=str((kd, order)))
+
+
+def test_two_output_columns(A):
+    rng = np.random.default_rng(4)
+    N, M = 3000, 40
+    x = rng.uniform(0.01, 0.99, N)
+    y = np.stack([np.sin(9 * x), np.cos(5 * x)], 1) + 0.1 * rng.normal(size=(N, 2))
+    bs = A.B3Spline(0, 1, M)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=0.9, lengthscales=0.2), bs)
+    model.likelihood.variance.assign(0.05)
+    ob = O.Basis(3, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
+    oe, og, _ = O.elbo_grad_1d(ob, 1, Ab, b, yy, N, 0.9, 0.2, 0.05)
+    r = model.elbo_and_grad().cpu().numpy()
+    assert abs(r[0] - oe) <= 1e-9 * abs(oe)
+    np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
+    xs = rng.uniform(0.01, 0.99, 100)
+    om, ov = O.predict_f_1d(ob, 1, Ab, b, 0.9, 0.2, 0.05, xs)
+    mean, var = model.predict_f(xs.reshape(-1, 1))
+    np.testing.assert_allclose(mean, om, atol=1e-8)
+    np.testing.assert_allclose(var, ov, atol=1e-8)
+
+
+def test_notebook_golden_end_to_end(A, S):
+    """experiments/snelson/example.py:25-33 on the HIP path -> example.ipynb:78  ASVGP: ELBO = -60.8356263428725"""
+    bs = A.B3Spline(-3.5, 10.5, 100)
+    model = A.GPR_1d((S["X"], S["Y"]), A.Matern32(), bs)
+    res = model.fit()
+    e = model.elbo().item()
+    assert abs(e - float(S["golden_elbo_asvgp"])) < 1e-7
+    assert e < float(S["golden_elbo_gp"])
+    np.testing.assert_allclose(model.theta(), [0.798145059, 1.026880136, 0.080066643], rtol=5e-5)
+
+
+def test_predict_vs_oracle_and_survey_values(A, S, golden_dir):
+    Xs = np.loadtxt(os.path.join(golden_dir, "snelson", "test_inputs")).reshape(-1, 1)
+    bs = A.B3Spline(-3.5, 10.5, 100)
+    v, l, s = 0.798145059, 1.026880136, 0.080066643
+    model = A.GPR_1d((S["X"], S["Y"]), A.Matern32(variance=v, lengthscales=l), bs)
+    model.likelihood.variance.assign(s)
+    mean, var = model.predict_f(Xs)
+    assert isinstance(mean, np.ndarray) and mean.shape == (301, 1) and var.shape == (301, 1)
+    ob = O.Basis(3, -3.5, 10.5, 100)
+    Ab, b, yy = O.sufficient_stats(ob, S["X"], S["Y"])
+    om, ov = O.predict_f_1d(ob, 1, Ab, b, v, l, s, Xs)
+    np.testing.assert_allclose(mean, om, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(var, ov, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(mean[[0, 150, 300], 0], [0.01123846, -0.20213625, -0.00027056], atol=2e-7)
+    np.testing.assert_allclose(var[[0, 150, 300], 0], [0.79721169, 0.00731127, 0.79809196], atol=2e-7)
+    with pytest.raises(NotImplementedError):
+        model.predict_f(Xs, full_cov=True)
+    # batch=True reproduces the reference's dropped remainder (gpr.py:125-136)
+    big = np.linspace(-3, 10, 25_000).reshape(-1, 1)
+    mb, vb = model.predict_f(big, batch=True)
+    m1, v1 = model.predict_f(big)
+    np.testing.assert_allclose(mb[:20_000], m1[:20_000], atol=1e-12)
+    assert not mb[20_000:].any() and not vb[20_000:].any()
+    # large streaming predict (LDS-staged path) equals the small path
+    big2 = np.linspace(-3.4, 10.4, 200_000).reshape(-1, 1)
+    m2, v2 = model.predict_f(big2)
+    sel = np.arange(0, 200_000, 997)
+    m3, v3 = model.predict_f(big2[sel])
+    np.testing.assert_allclose(m2[sel], m3, atol=1e-13)
+    np.testing.assert_allclose(v2[sel], v3, atol=1e-13)
+
+
+def test_cpu_tensors_are_refused(A):
+    from asvgp_amd import banded, _lib
+    with pytest.raises(_lib.AsvgpError):
+        banded.cholesky_band(torch.ones(2, 4, dtype=torch.float64))
