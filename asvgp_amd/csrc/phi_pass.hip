@@ -306,7 +306,7 @@ extern "C" size_t asvgp_phi_workspace_bytes(int64_t M, int order, int64_t D) {
 extern "C" int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t D, const double* mesh,
                                        int64_t n_mesh, double delta, int order, int64_t M, double* stats,
                                        void* workspace, size_t workspace_bytes, asvgp_stream_t stream) {
-  if (!x || !y || !mesh || !stats || N < 0 || D < 1 || M < 1 || !(delta > 0.0)) {
+  if (((!x || !y) && N > 0) || !mesh || !stats || N < 0 || D < 1 || M < 1 || !(delta > 0.0)) {
     set_error("phi_accumulate_1d: bad argument");
     return ASVGP_ERR_BAD_ARG;
   }

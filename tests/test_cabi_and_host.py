@@ -1,0 +1,172 @@
+"""CPU (-m "not gpu"): the C-ABI library builds, loads and exports every symbol include/asvgp_hip.h declares
+(no compute calls), host-side argument checking, host logic of the package (mesh, static bands, parameter
+transforms), and the N>1 sharding + collective path on gloo with world_size 2."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import asvgp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from asvgp_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.get_lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "asvgp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(asvgp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 24
+    from asvgp_amd import _lib
+    for n in names:
+        assert hasattr(lib, n), "libasvgp_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "no ctypes prototype for %s" % n
+    assert lib.asvgp_version() >= 100
+    assert lib.asvgp_status_name(0) == b"ASVGP_OK"
+    assert lib.asvgp_status_name(-3) == b"ASVGP_ERR_LDS_CAPACITY"
+
+
+def test_host_side_argument_checks_fail_loudly(lib):
+    from asvgp_amd import _lib
+    assert lib.asvgp_cholesky_band(None, None, 10, 4, None, None) == -1
+    assert b"cholesky_band" in lib.asvgp_last_error_string()
+    assert lib.asvgp_cholesky_band(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 9, None, None) == -2   # bandwidth > 8
+    assert lib.asvgp_phi_accumulate_1d(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 7, 0.1, 4, 10,
+                                       ctypes.c_void_p(8), None, 0, None) == -4                         # no workspace
+    assert lib.asvgp_phi_accumulate_1d(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 5, 0.1, 4, 10,
+                                       ctypes.c_void_p(8), ctypes.c_void_p(8), 1 << 30, None) == -1     # n_mesh != M-k+1
+    assert lib.asvgp_phi_accumulate_1d(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 7, 0.1, 7, 13,
+                                       ctypes.c_void_p(8), ctypes.c_void_p(8), 1 << 30, None) == -2     # order 7
+    assert lib.asvgp_phi_workspace_bytes(2048, 4, 1) == 8 * 256 * (6 * 2048 + 1)
+    assert lib.asvgp_elbo_workspace_bytes(2048, 4, 1) >= 8 * (9 * 5 * 2048 + 2 * 2048)
+    with pytest.raises(_lib.AsvgpError):
+        _lib.check(-2, "x")
+    with pytest.raises(_lib.AsvgpError):
+        _lib.require_cuda(torch.zeros(3))
+
+
+def test_matern_coefficient_table(lib):
+    for kind in (0, 1, 2):
+        for v, l in ((1.0, 1.0), (0.8, 1.03), (2.5, 0.05)):
+            c = (ctypes.c_double * 9)()
+            dc = (ctypes.c_double * 9)()
+            n = ctypes.c_int(0)
+            assert lib.asvgp_matern_coeffs(kind, v, l, c, dc, ctypes.byref(n)) == 0
+            terms = O.kuu_terms(kind, v, l)
+            assert n.value == len(terms)
+            for t, (nm, cc, dcc) in enumerate(terms):
+                assert c[t] == cc, (kind, nm)                      # same rounding sequence as inducing_features.py
+                assert abs(dc[t] - dcc) <= 1e-15 * abs(dcc) if dcc else dc[t] == 0
+    n = ctypes.c_int(0)
+    c = (ctypes.c_double * 9)()
+    assert lib.asvgp_matern_coeffs(7, 1.0, 1.0, c, c, ctypes.byref(n)) == -2
+    assert lib.asvgp_matern_coeffs(1, -1.0, 1.0, c, c, ctypes.byref(n)) == -1
+
+
+def test_package_host_logic_mesh_and_static_bands(golden_dir):
+    import asvgp_amd as A
+    F = np.load(os.path.join(golden_dir, "basis_fixtures.npz"))
+    cpu = torch.device("cpu")
+    for tag in F["tags"]:
+        order, a, b, m, isf = F[tag + "/spec"]
+        order, m = int(order), int(m)
+        a, b = (float(a), float(b)) if isf else (int(a), int(b))
+        bs = getattr(A, "B%dSpline" % order)(a, b, m, device=cpu)
+        assert bs.order == order and bs.m == m
+        assert np.array_equal(bs.mesh_np, F[tag + "/mesh"]) and bs.delta_np == float(F[tag + "/delta"])
+        for nm in ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad"):
+            if tag + "/" + nm in F:
+                ref = F[tag + "/" + nm]
+                assert np.max(np.abs(ref - bs.static_np[nm])) <= 4e-15 * max(np.max(np.abs(ref)), 1e-300), (tag, nm)
+            else:
+                assert not hasattr(bs, nm) or m > 100
+    with pytest.raises(NameError):
+        A.B4Spline(0, 1, 11, device=cpu)
+    # compute entry points refuse to run without the GPU
+    from asvgp_amd import _lib
+    bs = A.B3Spline(0, 1, 20, device=cpu)
+    with pytest.raises(_lib.AsvgpError):
+        bs.neighbour_index(np.array([0.5]))
+
+
+def test_parameter_transforms():
+    from asvgp_amd import kernels as K
+    p = K.Parameter(1.0)
+    assert abs(float(p) - 1.0) < 1e-15 and abs(p.unconstrained - O.softplus_inv(1.0)) < 1e-15
+    g = K.Gaussian()
+    assert abs(float(g.variance) - 1.0) < 1e-15 and abs(g.variance.unconstrained - O.softplus_inv(1.0 - 1e-6)) < 1e-15
+    for u in (-30.0, -1.0, 0.0, 2.0, 40.0):
+        p.unconstrained = u
+        assert abs(float(p) - O.softplus(u)) <= 1e-15 * max(1.0, abs(u))
+        assert abs(p.dtheta_du() - O.sigmoid(u)) < 1e-15
+    k = K.Matern52(variance=2.0, lengthscales=0.3)
+    assert k.kind == 2 and abs(2 * k.variance - 4.0) < 1e-14 and abs(k.lengthscales ** 2 - 0.09) < 1e-15
+
+
+def test_shard_bounds_cover_and_align():
+    from asvgp_amd.dist import shard_bounds
+    for N in (0, 1, 7, 1000, 10_000_000, 10_000_001):
+        for W in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(N, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == N
+            for (l0, h0), (l1, h1) in zip(spans, spans[1:]):
+                assert h0 == l1 and l0 <= h0
+            assert all(lo % 2 == 0 for lo, hi in spans if hi > lo)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asvgp_amd.dist import allreduce_stats, shard_bounds
+    rng = np.random.default_rng(99)
+    N, M = 5001, 40
+    x = rng.uniform(0.001, 0.999, N)
+    y = rng.normal(size=(N, 1))
+    bs = O.Basis(4, 0, 1, M)
+    lo, hi = shard_bounds(N, world, rank)
+    band, rhs, yy = O.sufficient_stats_direct(bs, x[lo:hi], y[lo:hi])     # the oracle stands in for the HIP Phi pass
+    packed = torch.from_numpy(np.concatenate([band.reshape(-1), rhs.reshape(-1), [yy]]))
+    n_glob = allreduce_stats(packed, hi - lo, None)
+    q.put((rank, n_glob, packed.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_band_allreduce_matches_single_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(99)
+    N, M = 5001, 40
+    x = rng.uniform(0.001, 0.999, N)
+    y = rng.normal(size=(N, 1))
+    band, rhs, yy = O.sufficient_stats_direct(O.Basis(4, 0, 1, M), x, y)
+    full = np.concatenate([band.reshape(-1), rhs.reshape(-1), [yy]])
+    for rank, n_glob, packed in res:
+        assert n_glob == N
+        np.testing.assert_allclose(packed, full, rtol=0, atol=1e-12 * np.max(np.abs(full)))   # sum order differs: tolerance
+    # the ELBO from the all-reduced statistics equals the single-rank one
+    e1, _ = O.elbo_1d(O.make_Kuu(O.Basis(4, 0, 1, M), 1, 1.0, 0.1), band, rhs, yy, N, 1.0, 0.05)
+    p = res[0][2]
+    e2, _ = O.elbo_1d(O.make_Kuu(O.Basis(4, 0, 1, M), 1, 1.0, 0.1), p[:5 * M].reshape(5, M), p[5 * M:6 * M].reshape(M, 1),
+                      p[-1], N, 1.0, 0.05)
+    assert abs(e1 - e2) <= 1e-10 * abs(e1)

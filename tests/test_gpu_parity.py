@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 KINDS = {0: "Matern12", 1: "Matern32", 2: "Matern52"}
 
 
+def elbo_tol(e, N, v, s, yy):
+    """fp64 tolerance for the bound: rel 1e-9 of the value plus 2e-11 of the two large cancelling
+    terms N v/(2s), y^T y/(2s) the bound is a difference of (gpr.py:81-87).  Two fp64 evaluation orders of the
+    *oracle itself* (banded vs dense) differ by 9e-10 rel on the Matern-5/2 case below, cond(Kuu) = 7e5."""
+    return 1e-9 * abs(e) + 2e-11 * (0.5 * N * v / s + 0.5 * yy / s)
+
+
 @pytest.fixture(scope="module")
 def A():
     import asvgp_amd
@@ -319,7 +326,7 @@ def test_elbo_synthetic_medium_vs_oracle(A):
         Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
         oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, N, 1.0, 0.05, 0.01)
         r = model.elbo_and_grad().cpu().numpy()
-        assert abs(r[0] - oe) <= 1e-9 * abs(oe), (kd, order)
+        assert abs(r[0] - oe) <= elbo_tol(oe, N, 1.0, 0.01, yy), (kd, order)
         np.testing.assert_allclose(r[1:4], og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)), err_msg=str((kd, order)))
 
 
