@@ -6,3 +6,9 @@ from .basis import B1Spline, B2Spline, B3Spline, B4Spline, B5Spline, B6Spline  #
 from .gpr import GPR_1d  # noqa: F401
 from .inducing_features import SplineFeatures1D  # noqa: F401
 from .kernels import Gaussian, Matern12, Matern32, Matern52  # noqa: F401
+
+
+def set_band_algorithm(algo):
+    """0 = auto, 1 = sequential single-wave sweeps, 2 = block cyclic reduction (asvgp_set_band_algorithm)."""
+    from ._lib import check, get_lib
+    check(get_lib().asvgp_set_band_algorithm(int(algo)), "set_band_algorithm")

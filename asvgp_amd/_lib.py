@@ -31,6 +31,7 @@ SIGNATURES = {
     "asvgp_pack_dense_matrix_to_banded": (_I, [_P, _P, _L, _I, _I, _P]),
     "asvgp_band_trace_sym": (_I, [_P, _P, _L, _I, _P, _P]),
     "asvgp_elbo_workspace_bytes": (_Z, [_L, _I, _L]),
+    "asvgp_set_band_algorithm": (_I, [_I]),
     "asvgp_elbo_grad_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "asvgp_posterior_prepare_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "asvgp_predict_1d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),

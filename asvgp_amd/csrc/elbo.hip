@@ -9,9 +9,11 @@
 //   phase 1  factor   : block0 dual Cholesky(Kuu) (gpr.py:56) | block1 Cholesky(P) + c = L_P^-1 b (gpr.py:73-75)
 //   phase 2  inverse  : block0 dual Takahashi(Kuu) (gpr.py:59) | block1 Takahashi(P) + alpha = L_P^-T c
 //   phase 3  finalize : log-dets (gpr.py:57,74), band traces (gpr.py:60-70), 7-term bound (gpr.py:78-87), gradient
-#include "band_sweeps.hpp"
+#include "bcr.hpp"
 
 namespace asvgp {
+
+static int g_band_algo = 0;  // 0 auto (BCR when it fits the LDS), 1 sequential sweeps, 2 force BCR
 
 struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]; int n; };
 
@@ -65,6 +67,21 @@ __global__ __launch_bounds__(64) void elbo_trsv_kernel(const double* L, int M, c
   (void)scale;
 }
 
+// Both chains by block cyclic reduction, one 256-thread workgroup each (bcr.hpp).
+template <int K, bool TANGENT>
+__global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu, const double* dK, const double* P,
+                                                               const double* b, int M, double* wsK, double* wsP,
+                                                               double* SK, double* dSK, double* SP, double* x,
+                                                               double* logdets, int* info) {
+  extern __shared__ double lds[];
+  if (blockIdx.x == 0) {
+    if (TANGENT) bcr_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info);
+    else bcr_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info);
+  } else {
+    bcr_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1);
+  }
+}
+
 // sym-band quadratic form helper: x^T sym(S) x over columns handled by this thread
 __device__ __forceinline__ double quad_col(const double* S, long M, int k, long j, const double* x, long D, long d) {
   double xj = x[j * D + d];
@@ -80,7 +97,8 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
     const double* __restrict__ stats, const double* __restrict__ Kuu, const double* __restrict__ dK,
     const double* __restrict__ LK, const double* __restrict__ LP, const double* __restrict__ SK,
     const double* __restrict__ dSK, const double* __restrict__ SP, const double* __restrict__ c,
-    const double* __restrict__ alpha, long M, int k, long D, ElboScalars th, double* __restrict__ out) {
+    const double* __restrict__ alpha, const double* __restrict__ logdets, long M, int k, long D, ElboScalars th,
+    double* __restrict__ out) {
   __shared__ double scratch[16];
   const double* A = stats;
   const double* b = stats + (long)(k + 1) * M;
@@ -90,9 +108,11 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   for (long j = threadIdx.x; j < M; j += blockDim.x) {
-    double lk = LK[j], lp = LP[j];
-    acc[LOGK] += log(lk * lk);  // gpr.py:57  log(square(L[0,:]))
-    acc[LOGP] += log(lp * lp);  // gpr.py:74
+    if (!logdets) {
+      double lk = LK[j], lp = LP[j];
+      acc[LOGK] += log(lk * lk);  // gpr.py:57  log(square(L[0,:]))
+      acc[LOGP] += log(lp * lp);  // gpr.py:74
+    }
     for (int r = 0; r <= k; ++r) {
       long o = (long)r * M + j;
       double w = (r == 0) ? 1.0 : 2.0;
@@ -106,8 +126,10 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
       acc[SPA] = fma(w * sp, a, acc[SPA]);
     }
     for (long d = 0; d < D; ++d) {
-      double cv = c[j * D + d];
-      acc[CC] = fma(cv, cv, acc[CC]);
+      if (!logdets) {
+        double cv = c[j * D + d];
+        acc[CC] = fma(cv, cv, acc[CC]);
+      }
       acc[AKA] += quad_col(Kuu, M, k, j, alpha, D, d);
       acc[ADKA] += quad_col(dK, M, k, j, alpha, D, d);
       acc[AAA] += quad_col(A, M, k, j, alpha, D, d);
@@ -119,6 +141,11 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
   for (int i = 0; i < NACC; ++i) tot[i] = block_sum(acc[i], scratch);
   if (threadIdx.x == 0) {
     const double v = th.v, s = th.s, N = th.N, Dd = (double)D;
+    if (logdets) {  // BCR path: log-dets come from the elimination, |c|^2 = b^T P^-1 b / s^2 = (b . alpha) / s
+      tot[LOGK] = logdets[0];
+      tot[LOGP] = logdets[2];
+      tot[CC] = tot[BA] / s;
+    }
     const double two_pi = 6.283185307179586476925286766559;
     double elbo = -0.5 * N * Dd * log(two_pi * s);
     elbo -= 0.5 * Dd * tot[LOGP];
@@ -149,22 +176,32 @@ __global__ void scale_kernel(double* __restrict__ x, double f, long n) {
 }
 
 struct Ws {
-  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha;
+  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha, *logdets, *bcrK, *bcrP;
 };
-static size_t ws_doubles(long M, int k, long D) { return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64; }
+static size_t bcr_ws_total(long M, int k) {  // factor workspaces of both chains (Dual + double)
+  long nb = (M + k - 1) / k;
+  return (size_t)3 * (7 * k * k + k) * nb + 64;
+}
+static size_t ws_doubles(long M, int k, long D) {
+  return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64 + bcr_ws_total(M, k);
+}
 static Ws carve(void* ws, long M, int k, long D) {
   double* p = static_cast<double*>(ws);
   size_t E = (size_t)(k + 1) * M;
   Ws w;
   w.Kuu = p; p += E; w.dK = p; p += E; w.P = p; p += E; w.LK = p; p += E; w.dLK = p; p += E;
   w.LP = p; p += E; w.SK = p; p += E; w.dSK = p; p += E; w.SP = p; p += E;
-  w.c = p; p += (size_t)M * D; w.alpha = p;
+  w.c = p; p += (size_t)M * D; w.alpha = p; p += (size_t)M * D;
+  w.logdets = p; p += 64;
+  long nb = (M + k - 1) / k;
+  w.bcrK = p; p += (size_t)2 * (7 * k * k + k) * nb;
+  w.bcrP = p;
   return w;
 }
 
 template <int K, bool TANGENT>
 static int run_chains(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
-                      Ws w, int* info, hipStream_t st) {
+                      Ws w, int* info, hipStream_t st, bool& use_bcr) {
   KuuCoefs2 cf;
   for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
   int rc = asvgp_matern_coeffs(kind, v, l, cf.c, cf.dc, &cf.n);
@@ -174,7 +211,20 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   const double* b = stats + E;
   hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s, w.Kuu,
                      w.dK, w.P);
-  if (D == 1) {
+  const long nb = (M + K - 1) / K;
+  size_t ldsK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0>(nb) : bcr_lds_doubles<double, K, 0>(nb));
+  size_t ldsP = sizeof(double) * bcr_lds_doubles<double, K, 1>(nb);
+  size_t lds_bytes = ldsK > ldsP ? ldsK : ldsP;
+  const bool fits = lds_bytes <= 160 * 1024 - 256;
+  use_bcr = (D == 1) && (g_band_algo == 2 || (g_band_algo == 0 && fits));
+  if (use_bcr) {
+    if (!fits) { set_error("BCR forced but needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
+    auto kern = elbo_bcr_kernel<K, TANGENT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+    hipLaunchKernelGGL(kern, dim3(2), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK, w.P, b, (int)M, w.bcrK, w.bcrP, w.SK,
+                       w.dSK, w.SP, w.alpha, w.logdets, info);
+  } else if (D == 1) {
     hipLaunchKernelGGL((elbo_factor_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.Kuu, w.dK, w.P, w.LK, w.dLK,
                        w.LP, b, w.c, (int)M, info);
     hipLaunchKernelGGL((elbo_inverse_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.LK, w.dLK, w.LP, w.SK,
@@ -189,7 +239,7 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   }
   // c = L_P^-1 b / s (gpr.py:75), alpha = P^-1 b / s
   long n = M * D;
-  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.c, 1.0 / s, n);
+  if (!use_bcr) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.c, 1.0 / s, n);
   hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
   return check_launch("elbo chains");
 }
@@ -198,11 +248,12 @@ template <int K> struct ElboLauncher {
   static int run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
                  double* out, int* info, void* ws, hipStream_t st) {
     Ws w = carve(ws, M, K, D);
-    int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st);
+    bool bcr = false;
+    int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st, bcr);
     if (rc) return rc;
     ElboScalars th{v, l, s, (double)N};
     hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(1024), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK, w.dSK,
-                       w.SP, w.c, w.alpha, M, K, D, th, out);
+                       w.SP, w.c, w.alpha, bcr ? w.logdets : (const double*)nullptr, M, K, D, th, out);
     return check_launch("elbo_grad_1d");
   }
 };
@@ -210,7 +261,8 @@ template <int K> struct PostLauncher {
   static int run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
                  double* alpha, double* W, int* info, void* ws, hipStream_t st) {
     Ws w = carve(ws, M, K, D);
-    int rc = run_chains<K, false>(stats, S, kind, v, l, s, M, D, w, info, st);
+    bool bcr = false;
+    int rc = run_chains<K, false>(stats, S, kind, v, l, s, M, D, w, info, st, bcr);
     if (rc) return rc;
     long E = (long)(K + 1) * M;
     hipLaunchKernelGGL(scale_sub_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, w.SP, w.SK, W, E);
@@ -223,6 +275,12 @@ template <int K> struct PostLauncher {
 }  // namespace asvgp
 
 using namespace asvgp;
+
+extern "C" int asvgp_set_band_algorithm(int algo) {
+  if (algo < 0 || algo > 2) { set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 block cyclic reduction"); return ASVGP_ERR_BAD_ARG; }
+  g_band_algo = algo;
+  return ASVGP_OK;
+}
 
 extern "C" size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D) {
   if (M < 1 || k < 1 || D < 1) return 0;

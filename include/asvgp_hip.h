@@ -116,6 +116,10 @@ int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, dou
  *                           trace(Kuu^-1 PhiPhi^T), |c|^2].
  * ---------------------------------------------------------------------------------------------- */
 size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D);
+/* band algorithm of the two fused drivers below: 0 = auto (block cyclic reduction, O(log M) dependent levels, when both
+ * chains fit the 160 KiB LDS and D == 1; otherwise the sequential single-wave sweeps), 1 = sequential sweeps,
+ * 2 = block cyclic reduction or ASVGP_ERR_LDS_CAPACITY.  Process-wide, host-side. */
+int asvgp_set_band_algorithm(int algo);
 int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind, double variance,
                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                        double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
