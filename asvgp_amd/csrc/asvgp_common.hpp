@@ -104,6 +104,15 @@ __device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a
 __device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, fma(a.v, b.d, a.d * b.v)}; }
 __device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
 
+// 1/sqrt(x) to ~1 ulp from v_rsq_f64 + two Newton steps (no IEEE sqrt/div sequences on the dependent chain)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
 template <typename T> struct Num;
 template <> struct Num<double> {
   static __device__ __forceinline__ double zero() { return 0.0; }
@@ -112,6 +121,13 @@ template <> struct Num<double> {
   static __device__ __forceinline__ double tan(double) { return 0.0; }
   static __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
   static __device__ __forceinline__ double inv(double a) { return 1.0 / a; }
+  // (sqrt(a), 1/sqrt(a)) with one rsqrt: s = a*y corrected by one Newton step on s
+  static __device__ __forceinline__ void sqrt_inv(double a, double& s, double& inv) {
+    double y = fast_rsqrt(a);
+    double t = a * y;
+    s = fma(0.5 * y, fma(-t, t, a), t);
+    inv = y;
+  }
   static __device__ __forceinline__ double rl(double a, int lane) { return readlane_f64(a, lane); }
   static __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
   // a - b*c
@@ -124,6 +140,13 @@ template <> struct Num<Dual> {
   static __device__ __forceinline__ double tan(Dual a) { return a.d; }
   static __device__ __forceinline__ Dual sqrt_(Dual a) { double s = sqrt(a.v); return {s, a.d / (2.0 * s)}; }
   static __device__ __forceinline__ Dual inv(Dual a) { double r = 1.0 / a.v; return {r, -a.d * r * r}; }
+  static __device__ __forceinline__ void sqrt_inv(Dual a, Dual& s, Dual& inv) {
+    double sv, y;
+    Num<double>::sqrt_inv(a.v, sv, y);
+    double ds = 0.5 * a.d * y;          // d sqrt(a) = a' / (2 sqrt(a))
+    s = {sv, ds};
+    inv = {y, -ds * y * y};             // d (1/s) = -s' / s^2
+  }
   static __device__ __forceinline__ Dual rl(Dual a, int lane) { return {readlane_f64(a.v, lane), readlane_f64(a.d, lane)}; }
   static __device__ __forceinline__ Dual sel(bool c, Dual a, Dual b) { return {c ? a.v : b.v, c ? a.d : b.d}; }
   static __device__ __forceinline__ Dual nfma(Dual b, Dual c, Dual a) {

@@ -31,8 +31,8 @@ __device__ __forceinline__ void blk_chol(T (&D)[B][B], T (&invd)[B], int& bad, i
 #pragma unroll
     for (int p = 0; p < j; ++p) s = N::nfma(D[j][p], D[j][p], s);
     if (!(N::val(s) > 0.0) && !bad) bad = col0 + j + 1;
-    T ljj = N::sqrt_(s);
-    T inv = N::inv(ljj);
+    T ljj, inv;
+    N::sqrt_inv(s, ljj, inv);
     D[j][j] = ljj;
     invd[j] = inv;
 #pragma unroll
@@ -205,12 +205,7 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
             z[r] = t * N::val(invd[r]);
           }
         }
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-          ld_acc += 2.0 * log(N::val(D[r][r]));
-          dld_acc += 2.0 * N::tan(D[r][r]) / N::val(D[r][r]);
-        }
-        // factors -> workspace
+        // factors -> workspace (log-determinant terms are summed from the stored diagonals after the solve)
 #pragma unroll
         for (int r = 0; r < B; ++r) {
           W.set(Lay::W_I + r, i, invd[r]);
@@ -292,10 +287,7 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
       for (int c = 0; c < B; ++c) D[r][c] = (c <= r) ? F.get(Lay::F_D + r * B + c, 0) : N::zero();
     blk_chol<T, B>(D, invd, bad, 0);
 #pragma unroll
-    for (int r = 0; r < B; ++r) {
-      ld_acc += 2.0 * log(N::val(D[r][r]));
-      dld_acc += 2.0 * N::tan(D[r][r]) / N::val(D[r][r]);
-    }
+    for (int r = 0; r < B; ++r) W.set(Lay::W_L + r * B + r, 0, D[r][r]);
     // Sigma_00 = L^-T L^-1
 #pragma unroll
     for (int r = 0; r < B; ++r)
@@ -462,6 +454,12 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
   }
   if (NRHS)
     for (int r = tid; r < M; r += BCR_THREADS) x[r] = xs[r];
+  // log|A| = 2 sum log diag(L_i) over all nodes, off the dependent chain (padding rows have L = 1)
+  for (int e = tid; e < nb * B; e += BCR_THREADS) {
+    T d = W.get(Lay::W_L + (e % B) * B + (e % B), e / B);
+    ld_acc += 2.0 * log(N::val(d));
+    dld_acc += 2.0 * N::tan(d) / N::val(d);
+  }
   // reductions
   double tot = block_sum(ld_acc, red);
   double dtot = block_sum(dld_acc, red);

@@ -136,9 +136,21 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
       acc[BA] = fma(b[j * D + d], alpha[j * D + d], acc[BA]);
     }
   }
-  double tot[NACC];
+  // one shuffle tree per accumulator, ONE barrier pair for all of them
+  __shared__ double part[16][NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) tot[i] = block_sum(acc[i], scratch);
+  for (int i = 0; i < NACC; ++i) {
+    double v = wave_sum(acc[i]);
+    if (lane == 0) part[wv][i] = v;
+  }
+  __syncthreads();
+  double tot[NACC];
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) tot[i] = wave_sum(lane < nw ? part[lane][i] : 0.0);
+  }
+  (void)scratch;
   if (threadIdx.x == 0) {
     const double v = th.v, s = th.s, N = th.N, Dd = (double)D;
     if (logdets) {  // BCR path: log-dets come from the elimination, |c|^2 = b^T P^-1 b / s^2 = (b . alpha) / s
