@@ -17,6 +17,7 @@ SIGNATURES = {
     "asvgp_status_name": (_c.c_char_p, [_I]),
     "asvgp_phi_workspace_bytes": (_Z, [_L, _I, _L]),
     "asvgp_phi_accumulate_1d": (_I, [_P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
+    "asvgp_set_phi_algorithm": (_I, [_I]),
     "asvgp_phi_index_1d": (_I, [_P, _L, _P, _L, _D, _P, _P]),
     "asvgp_phi_evaluate_1d": (_I, [_P, _L, _P, _L, _D, _I, _I, _P, _P, _P]),
     "asvgp_matern_coeffs": (_I, [_I, _D, _D, _c.POINTER(_D), _c.POINTER(_D), _c.POINTER(_I)]),
@@ -37,12 +38,13 @@ SIGNATURES = {
     "asvgp_predict_1d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),
     "asvgp_profile_enable": (_I, [_I]),
     "asvgp_profile_read": (_I, [_c.POINTER(_D), _c.POINTER(_L)]),
-    "asvgp_kron_workspace_bytes": (_Z, [_L, _L, _I, _I]),
-    "asvgp_phi_accumulate_kron2d": (_I, [_P, _P, _L, _P, _L, _D, _I, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
-    "asvgp_blockband_cholesky": (_I, [_P, _L, _L, _P, _P]),
-    "asvgp_blockband_solve": (_I, [_P, _L, _L, _P, _L, _I, _P]),
-    "asvgp_kron_expand_band": (_I, [_P, _P, _L, _L, _I, _I, _D, _P, _P]),
-    "asvgp_predict_kron2d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _L, _D, _I, _L, _P, _P, _P]),
+    "asvgp_kron_stats_doubles": (_Z, [_L, _L, _I]),
+    "asvgp_phi_accumulate_kron2d": (_I, [_P, _P, _L, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P]),
+    "asvgp_kron_evaluate_2d": (_I, [_P, _L, _P, _L, _D, _P, _L, _D, _L, _I, _P, _P, _P]),
+    "asvgp_kron_assemble": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _D, _P, _P, _P]),
+    "asvgp_blockband_cholesky": (_I, [_P, _L, _L, _P, _P, _P, _P]),
+    "asvgp_blockband_backsolve": (_I, [_P, _L, _L, _P, _P]),
+    "asvgp_predict_kron2d": (_I, [_P, _L, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P, _P, _P, _P, _P]),
 }
 
 
@@ -65,8 +67,6 @@ def get_lib():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:
-            if name.startswith(("asvgp_kron", "asvgp_phi_accumulate_kron", "asvgp_blockband", "asvgp_predict_kron")):
-                continue
             raise AsvgpError("libasvgp_hip.so does not export %s" % name)
         fn.restype = res
         fn.argtypes = args

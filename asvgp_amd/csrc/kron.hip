@@ -1,0 +1,438 @@
+// 2-D Kronecker (tensor-product) path: GPR_kron of gpr.py:239-359 without ever densifying.
+//
+// Replaces (reference): kronecker.make_kvs_sparse kronecker.py:7-33 + Kuf@y, Kuf@Kuf.T, todense gpr.py:266-272,
+// the dense tf.linalg.cholesky / triangular_solve / cholesky_solve of gpr.py:293-307 and 319-326.
+// Row index of basis pair (i1, i2) is i1*m2 + i2 (dim-0 major, = make_kvs_two_sparse).  A = Phi Phi^T is a
+// "band of bands": A[(i1+d1)*m2 + i2+d2, i1*m2 + i2] != 0 only for |d1| <= k, |d2| <= k.  Only the lower triangle is
+// kept: offsets (d1 = 0, d2 = 0..k) and (d1 = 1..k, d2 = -k..k), n_off = k(2k+1) + k + 1, stored as
+// Ablk[off][col] (n_off x M_tot).  P = Kuu + A/s is then a plain band matrix of bandwidth bw = k*m2 + k which is
+// factorised by a blocked right-looking band Cholesky on column-major band storage Pb[col*LD + (row-col)], LD = bw+1.
+#include "asvgp_common.hpp"
+
+namespace asvgp {
+
+__host__ __device__ inline int kron_noff(int k) { return k * (2 * k + 1) + k + 1; }
+__host__ __device__ inline int kron_off(int k, int d1, int d2) {
+  return d1 == 0 ? d2 : (k + 1) + (d1 - 1) * (2 * k + 1) + (d2 + k);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused Khatri-Rao Phi pass: one thread per point, (k+1)^2 products in registers, fp64 global atomics into the
+// L2-resident block band (3-8 MB) - first correct version; see DESIGN.md for the sorted/per-cell plan.
+// ---------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void phi_kron2d_kernel(const double* __restrict__ X, const double* __restrict__ y,
+                                                         long N, const double* __restrict__ mesh1, int n1, double id1,
+                                                         int m1, const double* __restrict__ mesh2, int n2, double id2,
+                                                         int m2, double* __restrict__ Ablk, double* __restrict__ rhs,
+                                                         double* __restrict__ yy_out) {
+  __shared__ double scratch[16];
+  const long Mtot = (long)m1 * m2;
+  double yy = 0.0;
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    const double2 xv = *reinterpret_cast<const double2*>(X + 2 * n);
+    const double yv = y[n];
+    const int i1 = neighbour_index(xv.x, mesh1, n1, mesh1[0], id1);
+    const int i2 = neighbour_index(xv.y, mesh2, n2, mesh2[0], id2);
+    double v1[K + 1], v2[K + 1];
+    bspline_pieces<K>((xv.x - mesh1[i1]) * id1, v1);
+    bspline_pieces<K>((xv.y - mesh2[i2]) * id2, v2);
+    yy = fma(yv, yv, yy);
+#pragma unroll
+    for (int a = 0; a <= K; ++a)
+#pragma unroll
+      for (int b = 0; b <= K; ++b) {
+        const double w = v1[a] * v2[b];
+        const long row = (long)(i1 + K - a) * m2 + (i2 + K - b);
+        __hip_atomic_fetch_add(rhs + row, w * yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int a2 = a; a2 <= K; ++a2)  // d1 = a2 - a >= 0  (row block >= col block)
+#pragma unroll
+          for (int b2 = 0; b2 <= K; ++b2) {
+            const int d1 = a2 - a, d2 = b2 - b;
+            if (d1 == 0 && d2 < 0) continue;
+            const long col = (long)(i1 + K - a2) * m2 + (i2 + K - b2);
+            __hip_atomic_fetch_add(Ablk + (long)kron_off(K, d1, d2) * Mtot + col, w * v1[a2] * v2[b2], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+          }
+      }
+  }
+  double tot = block_sum(yy, scratch);
+  if (threadIdx.x == 0 && tot != 0.0) __hip_atomic_fetch_add(yy_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Khatri-Rao COO triplets (kronecker.make_kvs_sparse): for point n, entry e = a*(K+1)+b: row, value
+template <int K>
+__global__ void kron_evaluate_kernel(const double* __restrict__ X, long N, const double* __restrict__ mesh1, int n1,
+                                     double id1, const double* __restrict__ mesh2, int n2, double id2, int m2,
+                                     long long* __restrict__ rows, double* __restrict__ data) {
+  long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double2 xv = *reinterpret_cast<const double2*>(X + 2 * n);
+  const int i1 = neighbour_index(xv.x, mesh1, n1, mesh1[0], id1);
+  const int i2 = neighbour_index(xv.y, mesh2, n2, mesh2[0], id2);
+  double v1[K + 1], v2[K + 1];
+  bspline_pieces<K>((xv.x - mesh1[i1]) * id1, v1);
+  bspline_pieces<K>((xv.y - mesh2[i2]) * id2, v2);
+#pragma unroll
+  for (int a = 0; a <= K; ++a)
+#pragma unroll
+    for (int b = 0; b <= K; ++b) {
+      const long e = (long)(a * (K + 1) + b) * N + n;
+      rows[e] = (long long)(i1 + K - a) * m2 + (i2 + K - b);
+      data[e] = v1[a] * v2[b];
+    }
+}
+
+// symmetric read of a 1-D lower band S (k+1, m): Sigma[i + d, i], d may be negative
+__device__ __forceinline__ double band_sym(const double* S, int m, int i, int d) {
+  return d >= 0 ? S[(long)d * m + i] : S[(long)(-d) * m + i + d];
+}
+
+// P (column-major band, LD = bw+1, zero-filled beforehand) = K1 (x) K2 + A / s ;  also tr( (S1 (x) S2) A )
+__global__ void kron_assemble_kernel(const double* __restrict__ K1, const double* __restrict__ K2,
+                                     const double* __restrict__ S1, const double* __restrict__ S2,
+                                     const double* __restrict__ Ablk, int k, int m1, int m2, double s, long LD,
+                                     double* __restrict__ Pb, double* __restrict__ trace_out) {
+  __shared__ double scratch[16];
+  const long Mtot = (long)m1 * m2;
+  const int noff = kron_noff(k);
+  double tr = 0.0;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < Mtot * noff; t += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(t / Mtot);
+    const long c = t - (long)o * Mtot;
+    int d1, d2;
+    if (o <= k) { d1 = 0; d2 = o; } else { int q = o - (k + 1); d1 = 1 + q / (2 * k + 1); d2 = q % (2 * k + 1) - k; }
+    const int i1 = (int)(c / m2), i2 = (int)(c - (long)i1 * m2);
+    if (i1 + d1 >= m1 || i2 + d2 < 0 || i2 + d2 >= m2) continue;
+    const double a = Ablk[t];
+    const double kv = K1[(long)d1 * m1 + i1] * band_sym(K2, m2, i2, d2);
+    if (Pb) Pb[c * LD + (long)d1 * m2 + d2] = kv + a / s;
+    if (S1) {
+      const double sv = S1[(long)d1 * m1 + i1] * band_sym(S2, m2, i2, d2);
+      tr = fma((o == 0) ? 1.0 : 2.0, sv * a, tr);
+    }
+  }
+  if (trace_out) {
+    double tot = block_sum(tr, scratch);
+    if (threadIdx.x == 0 && tot != 0.0) __hip_atomic_fetch_add(trace_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Blocked band Cholesky, column-major lower band Pb[c*LD + (r-c)], bandwidth bw, block NB.
+// panel kernel (one workgroup): factor the NB x NB diagonal block in LDS, solve the rows below (one thread per row),
+// carry one right-hand side along (forward substitution fused, like the 1-D sweep).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BB_NB = 32;
+
+__global__ __launch_bounds__(1024) void bb_panel_kernel(double* __restrict__ Pb, long M, int bw, long LD, long j0,
+                                                        double* __restrict__ rhs, int* __restrict__ info) {
+  __shared__ double Ls[BB_NB][BB_NB + 1];
+  __shared__ double cs[BB_NB];
+  const int tid = threadIdx.x;
+  const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
+  for (int idx = tid; idx < BB_NB * BB_NB; idx += blockDim.x) {
+    int r = idx / BB_NB, c = idx % BB_NB;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r >= c && r < nbk && c < nbk) v = (r - c <= bw) ? Pb[(j0 + c) * LD + (r - c)] : 0.0;
+    Ls[r][c] = v;
+  }
+  __syncthreads();
+  for (int j = 0; j < nbk; ++j) {
+    if (tid == 0) {
+      double piv = Ls[j][j];
+      if (!(piv > 0.0)) atomicCAS(info, 0, (int)(j0 + j + 1));
+      Ls[j][j] = sqrt(piv);
+    }
+    __syncthreads();
+    if (tid > j && tid < BB_NB) Ls[tid][j] = Ls[tid][j] / Ls[j][j];
+    __syncthreads();
+    {
+      int r = tid / BB_NB, c = tid % BB_NB;  // 1024 threads = 32 x 32 entries
+      if (c > j && r >= c) Ls[r][c] = fma(-Ls[r][j], Ls[c][j], Ls[r][c]);
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < BB_NB * BB_NB; idx += blockDim.x) {
+    int r = idx / BB_NB, c = idx % BB_NB;
+    if (r >= c && r < nbk && c < nbk && r - c <= bw) Pb[(j0 + c) * LD + (r - c)] = Ls[r][c];
+  }
+  if (rhs && tid == 0) {
+    for (int r = 0; r < nbk; ++r) {
+      double t = rhs[j0 + r];
+      for (int p = 0; p < r; ++p) t = fma(-Ls[r][p], cs[p], t);
+      cs[r] = t / Ls[r][r];
+      rhs[j0 + r] = cs[r];
+    }
+    for (int r = nbk; r < BB_NB; ++r) cs[r] = 0.0;
+  }
+  __syncthreads();
+  const long r_lo = j0 + nbk;
+  long r_hi = j0 + nbk - 1 + bw;  // last row touching this block column
+  if (r_hi > M - 1) r_hi = M - 1;
+  for (long r = r_lo + tid; r <= r_hi; r += blockDim.x) {
+    double xr[BB_NB];
+    double t = rhs ? rhs[r] : 0.0;
+#pragma unroll
+    for (int c = 0; c < BB_NB; ++c) {
+      const long d = r - (j0 + c);
+      double v = (c < nbk && d <= bw) ? Pb[(j0 + c) * LD + d] : 0.0;
+#pragma unroll
+      for (int p = 0; p < c; ++p) v = fma(-xr[p], Ls[c][p], v);
+      xr[c] = v / Ls[c][c];
+      if (c < nbk && d <= bw) Pb[(j0 + c) * LD + d] = xr[c];
+      t = fma(-xr[c], cs[c], t);
+    }
+    if (rhs) rhs[r] = t;
+  }
+}
+
+// trailing update: P[r][r'] -= sum_c L[r][j0+c] L[r'][j0+c] for r >= r' in the rows below the panel, inside the band.
+__global__ __launch_bounds__(256) void bb_update_kernel(double* __restrict__ Pb, long M, int bw, long LD, long j0) {
+  __shared__ double Lr[32][BB_NB + 1], Lc[32][BB_NB + 1];
+  const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
+  const long r_lo = j0 + nbk;
+  // tile pair from the linear block index: ti >= tj
+  int ti = 0, rem = blockIdx.x;
+  while (rem > ti) { rem -= ti + 1; ++ti; }
+  const int tj = rem;
+  const long rbase = r_lo + (long)ti * 32, cbase = r_lo + (long)tj * 32;
+  for (int idx = threadIdx.x; idx < 32 * BB_NB; idx += blockDim.x) {
+    int rr = idx % 32, c = idx / 32;
+    long r = rbase + rr, r2 = cbase + rr;
+    long d = r - (j0 + c), d2 = r2 - (j0 + c);
+    Lr[rr][c] = (c < nbk && r < M && d <= bw) ? Pb[(j0 + c) * LD + d] : 0.0;
+    Lc[rr][c] = (c < nbk && r2 < M && d2 <= bw) ? Pb[(j0 + c) * LD + d2] : 0.0;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int rr = tx + 16 * u, cc = ty + 16 * w;  // rr: row in tile ti (contiguous in memory), cc: row in tile tj
+      const long r = rbase + rr, c = cbase + cc;
+      if (r < M && c < M && r >= c && r - c <= bw) {
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < BB_NB; ++p) acc = fma(Lr[rr][p], Lc[cc][p], acc);
+        Pb[c * LD + (r - c)] -= acc;
+      }
+    }
+}
+
+// backward substitution x = L^-T c for one block column (called for j0 descending): one workgroup.
+__global__ __launch_bounds__(1024) void bb_backsolve_kernel(const double* __restrict__ Pb, long M, int bw, long LD, long j0,
+                                                            double* __restrict__ x) {
+  __shared__ double Ls[BB_NB][BB_NB + 1];
+  __shared__ double ts[BB_NB];
+  const int tid = threadIdx.x;
+  const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
+  for (int idx = tid; idx < BB_NB * BB_NB; idx += blockDim.x) {
+    int r = idx / BB_NB, c = idx % BB_NB;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r >= c && r < nbk && c < nbk) v = (r - c <= bw) ? Pb[(j0 + c) * LD + (r - c)] : 0.0;
+    Ls[r][c] = v;
+  }
+  const long r_lo = j0 + nbk;
+  long r_hi = j0 + nbk - 1 + bw;
+  if (r_hi > M - 1) r_hi = M - 1;
+  const int c = tid / 32, part = tid % 32;  // 32 columns x 32 row-lanes (a half wave per column)
+  double acc = 0.0;
+  if (c < nbk)
+    for (long r = r_lo + part; r <= r_hi; r += 32) {
+      long d = r - (j0 + c);
+      if (d <= bw) acc = fma(Pb[(j0 + c) * LD + d], x[r], acc);
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (part == 0) ts[c] = (c < nbk) ? x[j0 + c] - acc : 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    for (int cc = nbk - 1; cc >= 0; --cc) {
+      double t = ts[cc];
+      for (int p = cc + 1; p < nbk; ++p) t = fma(-Ls[p][cc], ts[p], t);
+      ts[cc] = t / Ls[cc][cc];
+      x[j0 + cc] = ts[cc];
+    }
+  }
+}
+
+// sum of 2 log diag over the band factor
+__global__ __launch_bounds__(1024) void bb_logdet_kernel(const double* __restrict__ Pb, long M, long LD, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (long)gridDim.x * blockDim.x) acc += 2.0 * log(Pb[j * LD]);
+  double tot = block_sum(acc, scratch);
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// posterior mean / "Kuu part" of the variance per test point:  mean = phi*^T alpha,
+// q = (phi1^T S1 phi1)(phi2^T S2 phi2) = phi*^T Kuu^-1 phi*   (Kuu^-1 = K1^-1 (x) K2^-1, only band entries needed)
+template <int K>
+__global__ void predict_kron2d_kernel(const double* __restrict__ X, long n, const double* __restrict__ mesh1, int n1,
+                                      double id1, int m1, const double* __restrict__ mesh2, int n2, double id2, int m2,
+                                      const double* __restrict__ alpha, const double* __restrict__ S1,
+                                      const double* __restrict__ S2, double* __restrict__ mean, double* __restrict__ qk) {
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double2 xv = *reinterpret_cast<const double2*>(X + 2 * p);
+  const int i1 = neighbour_index(xv.x, mesh1, n1, mesh1[0], id1);
+  const int i2 = neighbour_index(xv.y, mesh2, n2, mesh2[0], id2);
+  double v1[K + 1], v2[K + 1];
+  bspline_pieces<K>((xv.x - mesh1[i1]) * id1, v1);
+  bspline_pieces<K>((xv.y - mesh2[i2]) * id2, v2);
+  double mu = 0.0;
+#pragma unroll
+  for (int a = 0; a <= K; ++a)
+#pragma unroll
+    for (int b = 0; b <= K; ++b) mu = fma(v1[a] * v2[b], alpha[(long)(i1 + K - a) * m2 + (i2 + K - b)], mu);
+  mean[p] = mu;
+  if (qk) {
+    double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int a = 0; a <= K; ++a)
+#pragma unroll
+      for (int a2 = 0; a2 <= K; ++a2) {  // rows i+K-a, i+K-a2
+        int lo1 = i1 + K - (a > a2 ? a : a2), d = a > a2 ? a - a2 : a2 - a;
+        q1 = fma(v1[a] * v1[a2], S1[(long)d * m1 + lo1], q1);
+        int lo2 = i2 + K - (a > a2 ? a : a2);
+        q2 = fma(v2[a] * v2[a2], S2[(long)d * m2 + lo2], q2);
+      }
+    qk[p] = q1 * q2;
+  }
+}
+
+}  // namespace asvgp
+
+using namespace asvgp;
+
+extern "C" size_t asvgp_kron_stats_doubles(int64_t m1, int64_t m2, int k) {
+  if (m1 < 1 || m2 < 1 || k < 1 || k > ASVGP_MAX_ORDER) return 0;
+  return (size_t)kron_noff(k) * m1 * m2 + (size_t)m1 * m2 + 1;
+}
+
+#define KRON_DISPATCH(KK, CALL)                                  \
+  switch (KK) {                                                  \
+    case 1: { constexpr int K = 1; CALL; } break;                \
+    case 2: { constexpr int K = 2; CALL; } break;                \
+    case 3: { constexpr int K = 3; CALL; } break;                \
+    case 4: { constexpr int K = 4; CALL; } break;                \
+    case 5: { constexpr int K = 5; CALL; } break;                \
+    default: { constexpr int K = 6; CALL; } break;               \
+  }
+
+extern "C" int asvgp_phi_accumulate_kron2d(const double* X, const double* y, int64_t N, const double* mesh1,
+                                           int64_t n_mesh1, double delta1, int64_t m1, const double* mesh2,
+                                           int64_t n_mesh2, double delta2, int64_t m2, int order, double* stats,
+                                           asvgp_stream_t stream) {
+  if ((N > 0 && (!X || !y)) || !mesh1 || !mesh2 || !stats || N < 0 || !(delta1 > 0) || !(delta2 > 0) ||
+      n_mesh1 != m1 - order + 1 || n_mesh2 != m2 - order + 1) {
+    set_error("phi_accumulate_kron2d: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  if (order < 1 || order > ASVGP_MAX_ORDER) { set_error("phi_accumulate_kron2d: order %d unsupported", order); return ASVGP_ERR_UNSUPPORTED; }
+  if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) { set_error("phi_accumulate_kron2d: X must be 16-byte aligned (N,2) row-major"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  const size_t nd = asvgp_kron_stats_doubles(m1, m2, order);
+  hipError_t e = hipMemsetAsync(stats, 0, nd * sizeof(double), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  if (N == 0) return ASVGP_OK;
+  const long Mtot = (long)m1 * m2;
+  double* Ablk = stats;
+  double* rhs = stats + (size_t)kron_noff(order) * Mtot;
+  double* yy = rhs + Mtot;
+  long blocks = (N + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  KRON_DISPATCH(order, hipLaunchKernelGGL(phi_kron2d_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, st, X, y, (long)N, mesh1,
+                                          (int)n_mesh1, 1.0 / delta1, (int)m1, mesh2, (int)n_mesh2, 1.0 / delta2, (int)m2,
+                                          Ablk, rhs, yy));
+  return check_launch("phi_accumulate_kron2d");
+}
+
+extern "C" int asvgp_kron_evaluate_2d(const double* X, int64_t N, const double* mesh1, int64_t n_mesh1, double delta1,
+                                      const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                      int64_t* rows, double* data, asvgp_stream_t stream) {
+  if (!X || !mesh1 || !mesh2 || !rows || !data || N < 0 || order < 1 || order > ASVGP_MAX_ORDER) {
+    set_error("kron_evaluate_2d: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  if (N == 0) return ASVGP_OK;
+  KRON_DISPATCH(order, hipLaunchKernelGGL(kron_evaluate_kernel<K>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                                          as_stream(stream), X, (long)N, mesh1, (int)n_mesh1, 1.0 / delta1, mesh2,
+                                          (int)n_mesh2, 1.0 / delta2, (int)m2, reinterpret_cast<long long*>(rows), data));
+  return check_launch("kron_evaluate_2d");
+}
+
+extern "C" int asvgp_kron_assemble(const double* K1, const double* K2, const double* S1, const double* S2,
+                                   const double* Ablk, int k, int64_t m1, int64_t m2, double noise_variance, double* Pb,
+                                   double* trace_out, asvgp_stream_t stream) {
+  if (!K1 || !K2 || !Ablk || k < 1 || k > ASVGP_MAX_ORDER || m1 < 1 || m2 < 1 || !(noise_variance > 0) || (!Pb && !trace_out) ||
+      (trace_out && (!S1 || !S2))) {
+    set_error("kron_assemble: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  hipStream_t st = as_stream(stream);
+  const long Mtot = (long)m1 * m2, LD = (long)k * m2 + k + 1;
+  hipError_t e = hipSuccess;
+  if (Pb) e = hipMemsetAsync(Pb, 0, sizeof(double) * Mtot * LD, st);
+  if (e == hipSuccess && trace_out) e = hipMemsetAsync(trace_out, 0, sizeof(double), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  long total = Mtot * kron_noff(k);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(kron_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, K1, K2, trace_out ? S1 : nullptr, S2,
+                     Ablk, k, (int)m1, (int)m2, noise_variance, LD, Pb, trace_out);
+  return check_launch("kron_assemble");
+}
+
+extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, double* rhs, double* logdet, int* info,
+                                        asvgp_stream_t stream) {
+  if (!Pb || !info || M < 1 || bw < 0) { set_error("blockband_cholesky: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  const long LD = bw + 1;
+  hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  for (long j0 = 0; j0 < M; j0 += BB_NB) {
+    hipLaunchKernelGGL(bb_panel_kernel, dim3(1), dim3(1024), 0, st, Pb, (long)M, (int)bw, LD, j0, rhs, info);
+    long nbk = (M - j0 < BB_NB) ? (M - j0) : BB_NB;
+    long r_lo = j0 + nbk, r_hi = j0 + nbk - 1 + bw;
+    if (r_hi > M - 1) r_hi = M - 1;
+    long nrows = r_hi - r_lo + 1;
+    if (nrows > 0) {
+      long nt = (nrows + 31) / 32;
+      hipLaunchKernelGGL(bb_update_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, Pb, (long)M, (int)bw, LD, j0);
+    }
+  }
+  if (logdet) {
+    e = hipMemsetAsync(logdet, 0, sizeof(double), st);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+    hipLaunchKernelGGL(bb_logdet_kernel, dim3(16), dim3(1024), 0, st, Pb, (long)M, LD, logdet);
+  }
+  return check_launch("blockband_cholesky");
+}
+
+extern "C" int asvgp_blockband_backsolve(const double* Lb, int64_t M, int64_t bw, double* x, asvgp_stream_t stream) {
+  if (!Lb || !x || M < 1 || bw < 0) { set_error("blockband_backsolve: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  const long LD = bw + 1;
+  for (long j0 = ((M - 1) / BB_NB) * BB_NB; j0 >= 0; j0 -= BB_NB)
+    hipLaunchKernelGGL(bb_backsolve_kernel, dim3(1), dim3(1024), 0, st, Lb, (long)M, (int)bw, LD, j0, x);
+  return check_launch("blockband_backsolve");
+}
+
+extern "C" int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
+                                    int64_t m1, const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                    const double* alpha, const double* S1, const double* S2, double* mean, double* qk,
+                                    asvgp_stream_t stream) {
+  if (!Xnew || !mesh1 || !mesh2 || !alpha || !mean || n < 0 || order < 1 || order > ASVGP_MAX_ORDER || (qk && (!S1 || !S2))) {
+    set_error("predict_kron2d: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  if (n == 0) return ASVGP_OK;
+  KRON_DISPATCH(order, hipLaunchKernelGGL(predict_kron2d_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                          as_stream(stream), Xnew, (long)n, mesh1, (int)n_mesh1, 1.0 / delta1, (int)m1, mesh2,
+                                          (int)n_mesh2, 1.0 / delta2, (int)m2, alpha, S1, S2, mean, qk));
+  return check_launch("predict_kron2d");
+}

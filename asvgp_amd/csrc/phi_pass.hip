@@ -7,6 +7,8 @@
 // cross-workgroup tree/atomic reduce into the packed stats buffer.
 //
 // HBM roofline: 16 B/point (x and y read once, fp64).  Everything else is on-chip.
+#include <stdlib.h>
+
 #include "asvgp_common.hpp"
 
 namespace asvgp {
@@ -88,6 +90,389 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
   double* out = partials + (size_t)blockIdx.x * (E + 1);
   for (int e = tid; e < E; e += PHI_THREADS) out[e] = lds[e];
   if (tid == 0) out[E] = tot;
+}
+
+
+// =================================================================================================
+// Phi pass v2: tile-local counting sort + per-cell moment accumulation in registers.
+//
+// The per-point LDS fp64 atomics of v1 (20 per point, ~30 cycles per wave-instruction under random
+// addresses) are replaced by:  (1) one returning u32 LDS atomic per point (rank inside its cell),
+// (2) an exclusive scan of the per-cell counts, (3) one 16-B LDS write of (s, y), s = t - 1/2,
+// (4) the thread that OWNS the cell (thread tau owns cells tau and tau+1024 of the chunk) reads its
+// points back and accumulates the 3k+2 sufficient statistics  S_p = sum s^p (p<=2k), T_p = sum y s^p (p<=k)
+// in registers - no fp64 atomics in the streaming loop.  After the last tile the moments are converted
+// once per workgroup into band / rhs entries (products of the piece polynomials expanded in s with exact
+// integer coefficients), flushed, and reduced across workgroups exactly like v1.
+// Cells holding more than HEAVY points of a tile (sorted / clustered inputs) are accumulated by the
+// whole wavefront cooperatively, so time-series order is not a worst case.
+// =================================================================================================
+// Workgroup barrier that orders LDS traffic only: global loads issued before it (the next tile's prefetch) stay
+// in flight across it.  __syncthreads() would make hipcc drain them with s_waitcnt vmcnt(0) (cdna guide, "Pipelining
+// across barriers"), serialising HBM time with compute.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int MOM_THREADS = 1024;
+constexpr int MOM_CELLS = 2048;   // cells per pass (2 per thread)
+constexpr int MOM_HEAVY = 40;
+
+using i128 = __int128;
+// Compile-time coefficient tables (constexpr constructor => guaranteed constant evaluation; every use below has
+// static indices after unrolling, so the entries fold into instruction literals).
+template <int K> struct MomTab {
+  double single[K + 1][K + 1];             // v_i(s + 1/2) = sum_p single[i][p] s^p
+  double pair[K + 1][K + 1][2 * K + 1];    // v_i v_j      = sum_p pair[i][j][p] s^p   (j >= i)
+  static constexpr long long pnum(int i, int q) {  // integer numerator of the t^q coefficient of piece i times K!
+    long long num = 0;
+    for (int j = 0; j <= i; ++j) {
+      long long term = binom(K + 1, j) * binom(K, q) * ipow(i - j, K - q);
+      num += (j & 1) ? -term : term;
+    }
+    return num;
+  }
+  constexpr MomTab() : single{}, pair{} {
+    long long m[K + 1][K + 1] = {};        // v_i(s + 1/2) = (1 / (K! 2^K)) sum_r m[i][r] s^r
+    for (int i = 0; i <= K; ++i)
+      for (int r = 0; r <= K; ++r) {
+        long long acc = 0;
+        for (int q = r; q <= K; ++q) acc += pnum(i, q) * binom(q, r) * (1LL << (K - q + r));
+        m[i][r] = acc;
+      }
+    const double d1 = (double)fact(K) * (double)(1LL << K);
+    const double d2 = (double)(fact(K) * fact(K)) * (double)(1LL << (2 * K));
+    for (int i = 0; i <= K; ++i) {
+      for (int p = 0; p <= K; ++p) single[i][p] = (double)m[i][p] / d1;
+      for (int j = i; j <= K; ++j)
+        for (int p = 0; p <= 2 * K; ++p) {
+          i128 acc = 0;
+          for (int r = 0; r <= K; ++r) {
+            int r2 = p - r;
+            if (r2 < 0 || r2 > K) continue;
+            acc += (i128)m[i][r] * (i128)m[j][r2];
+          }
+          pair[i][j][p] = (double)acc / d2;
+        }
+    }
+  }
+};
+template <int K> struct MomCoef {
+  static constexpr MomTab<K> tab{};
+};
+
+template <int K>
+__device__ __forceinline__ void mom_accumulate(double s, double y, double (&S)[2 * K + 1], double (&T)[K + 1]) {
+  double pw = 1.0;
+  S[0] += 1.0;
+  T[0] += y;
+#pragma unroll
+  for (int p = 1; p <= 2 * K; ++p) {
+    pw *= s;
+    S[p] += pw;
+    if (p <= K) T[p] = fma(y, pw, T[p]);
+  }
+}
+
+
+// one owner lane, one cell: light cells in a private loop, heavy cells (sorted / clustered input) by the whole wave
+template <int K>
+__device__ __forceinline__ void mom_own_cell(const double2* buf, unsigned n, unsigned o, int lane,
+                                             double (&S)[2 * K + 1], double (&T)[K + 1]) {
+  if (n <= MOM_HEAVY)
+    for (unsigned j = 0; j < n; ++j) { double2 p = buf[o + j]; mom_accumulate<K>(p.x, p.y, S, T); }
+  unsigned long long hv = __ballot(n > MOM_HEAVY);   // (callers pass n = 0 for lanes whose cell was handled already)
+  while (hv) {  // wave-uniform loop
+    const int h = __ffsll((long long)hv) - 1;
+    hv &= hv - 1;
+    const unsigned nh = __shfl(n, h, 64), oh = __shfl(o, h, 64);
+    double S2[2 * K + 1], T2[K + 1];
+#pragma unroll
+    for (int p = 0; p <= 2 * K; ++p) S2[p] = 0.0;
+#pragma unroll
+    for (int p = 0; p <= K; ++p) T2[p] = 0.0;
+    for (unsigned j = lane; j < nh; j += 64) { double2 p = buf[oh + j]; mom_accumulate<K>(p.x, p.y, S2, T2); }
+#pragma unroll
+    for (int p = 0; p <= 2 * K; ++p) { double t = wave_sum(S2[p]); S[p] += (lane == h) ? t : 0.0; }
+#pragma unroll
+    for (int p = 0; p <= K; ++p) { double t = wave_sum(T2[p]); T[p] += (lane == h) ? t : 0.0; }
+  }
+}
+
+// both cells of one owner lane in ONE loop (trip = max(nA, nB) instead of nA + nB, two independent FMA streams);
+// a missing point is fed as (s, y) = (0, 0), which only touches S_0 - masked explicitly.
+template <int K>
+__device__ __forceinline__ void mom_own_two_cells(const double2* buf, unsigned nA, unsigned oA, unsigned nB, unsigned oB,
+                                                  int lane, double (&SA)[2 * K + 1], double (&TA)[K + 1],
+                                                  double (&SB)[2 * K + 1], double (&TB)[K + 1]) {
+  const bool hvA = nA > MOM_HEAVY, hvB = nB > MOM_HEAVY;
+  const unsigned la = hvA ? 0u : nA, lb = hvB ? 0u : nB;
+  const unsigned n = la > lb ? la : lb;
+  for (unsigned j = 0; j < n; ++j) {
+    const bool a = j < la, b = j < lb;
+    double2 pa = a ? buf[oA + j] : make_double2(0.0, 0.0);
+    double2 pb = b ? buf[oB + j] : make_double2(0.0, 0.0);
+    double wa = pa.x, wb = pb.x;
+    SA[0] += a ? 1.0 : 0.0;
+    SB[0] += b ? 1.0 : 0.0;
+    TA[0] += pa.y;
+    TB[0] += pb.y;
+    SA[1] += wa; SB[1] += wb;
+    TA[1] = fma(pa.y, wa, TA[1]); TB[1] = fma(pb.y, wb, TB[1]);
+#pragma unroll
+    for (int p = 2; p <= 2 * K; ++p) {
+      wa *= pa.x; wb *= pb.x;
+      SA[p] += wa; SB[p] += wb;
+      if (p <= K) { TA[p] = fma(pa.y, wa, TA[p]); TB[p] = fma(pb.y, wb, TB[p]); }
+    }
+  }
+  if (__any(hvA)) mom_own_cell<K>(buf, hvA ? nA : 0u, oA, lane, SA, TA);
+  if (__any(hvB)) mom_own_cell<K>(buf, hvB ? nB : 0u, oB, lane, SB, TB);
+}
+
+// moments of cell c -> band / rhs contributions (exact integer-ratio coefficients, centred monomials)
+template <int K>
+__device__ __forceinline__ void mom_to_band(const double (&S)[2 * K + 1], const double (&T)[K + 1], int c, int ncols,
+                                            int do_band, double* band, double* rhs) {
+  if (S[0] == 0.0) return;
+#pragma unroll
+  for (int i = 0; i <= K; ++i) {
+    double r = 0.0;
+#pragma unroll
+    for (int p = 0; p <= K; ++p) r = fma(MomCoef<K>::tab.single[i][p], T[p], r);
+    lds_add(rhs + c + K - i, r);
+    if (do_band) {
+#pragma unroll
+      for (int j = i; j <= K; ++j) {
+        double b = 0.0;
+#pragma unroll
+        for (int p = 0; p <= 2 * K; ++p) b = fma(MomCoef<K>::tab.pair[i][j][p], S[p], b);
+        lds_add(band + (j - i) * ncols + c + K - j, b);
+      }
+    }
+  }
+}
+
+template <int K, int TP, bool VEC, int ablate = 0>
+__global__ __launch_bounds__(MOM_THREADS) void phi_moments_kernel(
+    const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
+    const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
+    int do_band, double* __restrict__ partials, long ppb) {
+  extern __shared__ double lds[];
+  constexpr int T = TP * MOM_THREADS;
+  double2* buf = reinterpret_cast<double2*>(lds);                      // T sorted (s, y)
+  unsigned* cnt = reinterpret_cast<unsigned*>(lds + 2 * T);            // MOM_CELLS
+  unsigned* off = cnt + MOM_CELLS;                                     // MOM_CELLS + 1
+  unsigned* wtot = off + MOM_CELLS + 1;                                // 16 wave totals (+pad)
+  double* red = reinterpret_cast<double*>(wtot + 32);                  // 16 doubles
+  int* flag = reinterpret_cast<int*>(red + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int NC = cell1 - cell0;
+
+  // ---- is the mesh table bit-identical to numpy's linspace arithmetic  i*step + a ?  (then no table lookups)
+  const double m0 = mesh_g[0];
+  const double step = (mesh_g[n_mesh - 1] - m0) / (double)(n_mesh - 1);
+  if (tid == 0) *flag = 1;
+  for (int e = tid; e < 2 * MOM_CELLS; e += MOM_THREADS) cnt[e] = 0;   // cnt and off
+  __syncthreads();
+  {
+    bool ok = true;
+    for (int e = tid; e < n_mesh - 1; e += MOM_THREADS) ok = ok && (__dadd_rn(__dmul_rn((double)e, step), m0) == mesh_g[e]);
+    if (!ok) *flag = 0;
+  }
+  __syncthreads();
+  const bool arith = (*flag != 0);
+  auto knot = [&](int i) -> double { return arith ? __dadd_rn(__dmul_rn((double)i, step), m0) : mesh_g[i]; };
+
+  // diagnostic variant 9: per-phase cycle stamps of thread 0 (written over this block's partial after the flush)
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+  auto stamp = [&](int i) {
+    if constexpr (ablate == 9) {
+      unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (i >= 0) ph[i] += t - tprev;
+      tprev = t;
+    }
+  };
+  double SA[2 * K + 1], TA[K + 1], SB[2 * K + 1], TB[K + 1];
+#pragma unroll
+  for (int p = 0; p <= 2 * K; ++p) { SA[p] = 0.0; SB[p] = 0.0; }
+#pragma unroll
+  for (int p = 0; p <= K; ++p) { TA[p] = 0.0; TB[p] = 0.0; }
+  double yy = 0.0;
+
+  const long beg = (long)blockIdx.x * ppb;
+  long end = beg + ppb;
+  if (end > N) end = N;
+
+  double xs[TP], ys[TP];
+  // point q of this thread: VEC -> pairs (base + 2*(q2*1024+tid) + {0,1}).  The tile is fetched in TP/2 slices so that
+  // no phase issues more than ~32 KB per CU at once (a whole tile exceeds what a CU keeps in flight and the issue blocks).
+  auto load_slice = [&](long base, int q0, int q1) {
+#pragma unroll
+    for (int q = 0; q < TP; q += 2) {
+      if (q < q0 || q >= q1) continue;
+      if (VEC) {
+        long i = base + 2 * ((long)(q >> 1) * MOM_THREADS + tid);
+        if (i + 1 < end) {
+          double2 xv = *reinterpret_cast<const double2*>(x + i);
+          double2 yv = *reinterpret_cast<const double2*>(y + i);
+          xs[q] = xv.x; xs[q + 1] = xv.y; ys[q] = yv.x; ys[q + 1] = yv.y;
+        } else {
+          xs[q] = (i < end) ? x[i] : __builtin_nan("");
+          ys[q] = (i < end) ? y[i] : 0.0;
+          xs[q + 1] = __builtin_nan(""); ys[q + 1] = 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          long i = base + (long)(q + u) * MOM_THREADS + tid;
+          xs[q + u] = (i < end) ? x[i] : __builtin_nan("");
+          ys[q + u] = (i < end) ? y[i * y_stride] : 0.0;
+        }
+      }
+    }
+  };
+
+  auto load_tile = [&](long base) { load_slice(base, 0, TP); };
+  constexpr int SL = (TP / 2 + 2) / 3 * 2;  // points per slice (3 slices)
+  if (beg < end) load_tile(beg);
+  for (long base = beg; base < end; base += T) {
+    stamp(-1);
+    // ---- P1: cell, centred coordinate, rank within the cell
+    double sv[TP], yv[TP];
+    int cr[TP];  // cell << 13 | rank   (rank < 8192), -1 = not in this chunk / out of range
+    {
+      int ci[TP];
+      bool slow = false;
+#pragma unroll
+      for (int q = 0; q < TP; ++q) {
+        const double xv = xs[q];
+        yv[q] = ys[q];
+        double g = floor((xv - m0) * inv_delta);
+        int i = (g < 0.0) ? 0 : ((g > (double)(n_mesh - 2)) ? (n_mesh - 2) : (int)g);   // NaN -> 0
+        // branch-free +-1 fix-up against the knots (the floor guess is off by at most one on a monotone mesh) ...
+        i -= (i > 0 && !(knot(i) < xv)) ? 1 : 0;
+        i += (i < n_mesh - 2 && knot(i + 1) < xv) ? 1 : 0;
+        // ... verified; anything else (wildly non-uniform table) takes the exact search below
+        const double lo = knot(i), hi = knot(i + 1);
+        const bool good = (lo < xv || i == 0) && (!(hi < xv) || i == n_mesh - 2);
+        slow = slow || (!good && xv == xv);
+        ci[q] = i;
+        sv[q] = fma(xv - lo, inv_delta, -0.5);
+      }
+      if (__any(slow)) {  // rare: exact searchsorted semantics by linear walk
+#pragma unroll
+        for (int q = 0; q < TP; ++q) {
+          const double xv = xs[q];
+          int i = ci[q];
+          while (i > 0 && !(knot(i) < xv)) --i;
+          while (i < n_mesh - 2 && knot(i + 1) < xv) ++i;
+          ci[q] = i;
+          sv[q] = fma(xv - knot(i), inv_delta, -0.5);
+        }
+      }
+      if constexpr (ablate == 1 || ablate == 2) {
+#pragma unroll
+        for (int q = 0; q < TP; ++q) yy += sv[q] + (double)ci[q] + yv[q];
+      } else {
+        unsigned rk[TP];
+#pragma unroll
+        for (int q = 0; q < TP; ++q) {  // all rank atomics of the tile in flight together
+          const int c = ci[q] - cell0;
+          const bool ok = (xs[q] == xs[q]) && c >= 0 && c < NC;
+          cr[q] = ok ? c : -1;
+          rk[q] = ok ? atomicAdd(&cnt[c], 1u) : 0u;
+          yy = ok ? fma(yv[q], yv[q], yy) : yy;
+        }
+#pragma unroll
+        for (int q = 0; q < TP; ++q) cr[q] = (cr[q] >= 0) ? ((cr[q] << 13) | (int)rk[q]) : -1;
+      }
+    }
+    if constexpr (ablate == 1 || ablate == 2) { if (base + T < end) load_tile(base + T); continue; }
+    lds_barrier();
+    stamp(0);
+    const bool more = base + T < end;
+    if constexpr (ablate == 3 || ablate == 4) { if (more) load_tile(base + T); }
+    if constexpr (ablate != 3 && ablate != 4) if (more) load_slice(base + T, 0, SL);  // prefetch the next tile in slices under the sort / owner phases
+    if constexpr (ablate == 3) {
+      lds_barrier();
+      cnt[tid] = 0; cnt[tid + MOM_THREADS] = 0;
+      lds_barrier();
+#pragma unroll
+      for (int q = 0; q < TP; ++q) yy += (double)(cr[q] & 8191);
+      continue;
+    }
+    // ---- P2: exclusive scan of cnt -> off   (thread t scans cells 2t, 2t+1)
+    {
+      unsigned c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+      unsigned v = c0 + c1, inc = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        unsigned o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      if (lane == 63) wtot[wv] = inc;
+      lds_barrier();
+      unsigned basew = 0;
+      for (int w = 0; w < wv; ++w) basew += wtot[w];
+      unsigned ex = basew + inc - v;
+      off[2 * tid] = ex;
+      off[2 * tid + 1] = ex + c0;
+    }
+    lds_barrier();
+    stamp(1);
+    if (more) load_slice(base + T, SL, 2 * SL);
+    // ---- P3: scatter (s, y) into cell order
+#pragma unroll
+    for (int q = 0; q < TP; ++q)
+      if (cr[q] >= 0) buf[off[cr[q] >> 13] + (cr[q] & 8191)] = make_double2(sv[q], yv[q]);
+    lds_barrier();
+    stamp(2);
+    if constexpr (ablate == 4) {
+      cnt[tid] = 0; cnt[tid + MOM_THREADS] = 0;
+      lds_barrier();
+      continue;
+    }
+    // ---- P4: owners accumulate their cells' moments
+    if (more) load_slice(base + T, 2 * SL, TP);
+    {
+      const unsigned nA = cnt[tid], oA = off[tid];
+      const unsigned nB = cnt[tid + MOM_THREADS], oB = off[tid + MOM_THREADS];
+      mom_own_two_cells<K>(buf, nA, oA, nB, oB, lane, SA, TA, SB, TB);
+      cnt[tid] = 0;
+      cnt[tid + MOM_THREADS] = 0;
+    }
+    stamp(3);
+    lds_barrier();
+    stamp(4);
+  }
+
+  // ---- moments -> band / rhs (LDS image aliases the sort buffers), then flush like v1
+  double tot = block_sum(yy, red);
+  __syncthreads();
+  const int E = (K + 2) * ncols;
+  for (int e = tid; e < E; e += MOM_THREADS) lds[e] = 0.0;
+  __syncthreads();
+  double* band = lds;
+  double* rhs = band + (K + 1) * ncols;
+  if constexpr (ablate == 5) {  // diagnostic: keep the moments alive, skip the conversion
+    double keep = 0.0;
+#pragma unroll
+    for (int p = 0; p <= 2 * K; ++p) keep += SA[p] + SB[p];
+#pragma unroll
+    for (int p = 0; p <= K; ++p) keep += TA[p] + TB[p];
+    if (tid < ncols) rhs[tid] = keep;
+  } else {
+    if (tid < NC) mom_to_band<K>(SA, TA, tid, ncols, do_band, band, rhs);
+    if (tid + MOM_THREADS < NC) mom_to_band<K>(SB, TB, tid + MOM_THREADS, ncols, do_band, band, rhs);
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * (E + 1);
+  for (int e = tid; e < E; e += MOM_THREADS) out[e] = lds[e];
+  if (tid == 0) out[E] = tot;
+  if constexpr (ablate == 9) {
+    __syncthreads();
+    if (tid == 0)
+      for (int i = 0; i < 6; ++i) out[i] = (double)ph[i];
+  }
 }
 
 // Sum the per-workgroup partials into the packed stats buffer (zeroed beforehand).
@@ -211,6 +596,8 @@ __global__ __launch_bounds__(1024) void predict_kernel(const double* __restrict_
 // Optional in-library timing of the dominant kernel: HIP events recorded on the launch stream right around
 // phi_accumulate_kernel (bench.py's roofline figure; must agree with the rocprofv3 kernel-trace average).
 constexpr int PROF_RING = 1024;
+static int g_phi_ablate = 0;   // diagnostic only (ASVGP_PHI_ABLATE): 1 loads, 2 +cell, 3 +rank atomics, 4 +scan/scatter
+static int g_phi_algo = 0;  // 0 auto (v2 moments), 1 = v1 LDS atomics, 2 = v2 moments
 static bool g_prof_on = false;
 static hipEvent_t g_prof_ev[PROF_RING][2];
 static bool g_prof_made = false;
@@ -232,6 +619,9 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
     return ASVGP_ERR_LDS_CAPACITY;
   }
   int cells_per_chunk = (M <= maxc) ? ncells : (maxc - K);
+  const bool v2 = (g_phi_algo != 1);
+  constexpr int TP = 6;
+  if (v2 && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
   long nblk = (N + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS);
   int G = (int)(nblk < 1 ? 1 : (nblk > PHI_MAX_BLOCKS ? PHI_MAX_BLOCKS : nblk));
   long ppb = (N + G - 1) / G;
@@ -249,13 +639,36 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
       size_t lds_bytes = sizeof(double) * ((size_t)(K + 2) * ncols + n_mesh + 16);
       int do_band = (dcol == 0);
       auto kern = vec ? phi_accumulate_kernel<K, true> : phi_accumulate_kernel<K, false>;
+      if (v2) {
+        size_t sort_bytes = (size_t)TP * MOM_THREADS * 16 + (size_t)(2 * MOM_CELLS + 1 + 32) * 4 + 16 * 8 + 64;
+        size_t band_bytes = sizeof(double) * (size_t)(K + 2) * ncols;
+        lds_bytes = sort_bytes > band_bytes ? sort_bytes : band_bytes;
+        auto k2 = vec ? phi_moments_kernel<K, TP, true> : phi_moments_kernel<K, TP, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+      }
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
       const bool prof = g_prof_on && g_prof_n < PROF_RING;
       if (prof) hipEventRecord(g_prof_ev[g_prof_n][0], st);
-      hipLaunchKernelGGL(kern, dim3(G), dim3(PHI_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh,
-                         inv_delta, cell0, cell1, ncols, do_band, partials, ppb);
+      if (v2) {
+        auto k2 = vec ? phi_moments_kernel<K, TP, true> : phi_moments_kernel<K, TP, false>;
+        if (K == 4 && vec && g_phi_ablate >= 1 && g_phi_ablate <= 9) {  // diagnostic builds (tools/phi_ablate.py)
+          if (g_phi_ablate == 1) k2 = phi_moments_kernel<4, TP, true, 1>;
+          if (g_phi_ablate == 2) k2 = phi_moments_kernel<4, TP, true, 2>;
+          if (g_phi_ablate == 3) k2 = phi_moments_kernel<4, TP, true, 3>;
+          if (g_phi_ablate == 4) k2 = phi_moments_kernel<4, TP, true, 4>;
+          if (g_phi_ablate == 5) k2 = phi_moments_kernel<4, TP, true, 5>;
+          if (g_phi_ablate == 9) k2 = phi_moments_kernel<4, TP, true, 9>;
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        }
+        hipLaunchKernelGGL(k2, dim3(G), dim3(MOM_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh, inv_delta,
+                           cell0, cell1, ncols, do_band, partials, ppb);
+      } else {
+        hipLaunchKernelGGL(kern, dim3(G), dim3(PHI_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh,
+                           inv_delta, cell0, cell1, ncols, do_band, partials, ppb);
+      }
       if (prof) { hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
       int E1 = (K + 2) * ncols + 1;
       int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
@@ -269,6 +682,14 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
 }  // namespace asvgp
 
 using namespace asvgp;
+
+extern "C" int asvgp_set_phi_algorithm(int algo) {
+  if (algo < 0 || algo > 2) { set_error("set_phi_algorithm: 0 auto, 1 LDS-atomic scatter, 2 counting-sort + moments"); return ASVGP_ERR_BAD_ARG; }
+  g_phi_algo = algo;
+  const char* ab = getenv("ASVGP_PHI_ABLATE");
+  g_phi_ablate = ab ? atoi(ab) : 0;
+  return ASVGP_OK;
+}
 
 extern "C" int asvgp_profile_enable(int on) {
   if (on && !g_prof_made) {

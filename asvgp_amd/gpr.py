@@ -7,10 +7,13 @@ Additions (not in the reference): elbo_and_grad() (analytic gradient, replacing 
 banded_matrices op gradients), fit() (L-BFGS-B driver, replacing gpflow.optimizers.Scipy), process_group= for
 N-sharded construction over RCCL.
 """
+import math
+
 import numpy as np
 import torch
 
 from . import kernels, utils
+from . import kernels as kernels_mod
 from ._lib import AsvgpError, check, f64c, get_lib, require_cuda, stream_ptr
 from .banded import NotPositiveDefiniteError
 from .dist import allreduce_stats
@@ -208,3 +211,180 @@ class GPR_1d:
         mean, var = self.predict_y(Xnew)
         Ynew = np.asarray(Ynew, dtype=np.float64).reshape(mean.shape)
         return -0.5 * (np.log(2 * np.pi * var) + (Ynew - mean) ** 2 / var)
+
+
+class GPR_kron:
+    """Drop-in for asvgp/gpr.py:239-359 (d = 2): GPR_kron((X[N,2], y[N,1]), kernels, bases) with elbo(),
+    maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew).  Never densifies: KufKfu is a block band
+    (asvgp_phi_accumulate_kron2d), Kuu = K1 (x) K2 is handled factor-wise (log|Kuu| = m2 log|K1| + m1 log|K2|, the trace
+    needs only band(K1^-1) (x) band(K2^-1)), and P = Kuu + KufKfu/sigma2 is a bandwidth k(m2+1) band matrix factorised by a
+    blocked band Cholesky - the reference runs dense O(M_tot^3) tf.linalg.cholesky (gpr.py:293)."""
+
+    def __init__(self, data, kernels, bases, process_group=None, distributed=None):
+        dev = bases[0].device
+        self.X, self.y = _to_device(data[0], dev), _to_device(data[1], dev)
+        self.n, self.d = self.X.shape[0], self.X.shape[1]
+        assert len(kernels) == len(bases) == self.d          # gpr.py:247
+        assert self.y.shape[1] == 1                          # gpr.py:248
+        if self.d != 2:
+            raise NotImplementedError("asvgp_amd.GPR_kron implements the d = 2 tensor product (all reference configs)")
+        for kern in kernels:
+            assert isinstance(kern, (kernels_mod.Matern12, kernels_mod.Matern32, kernels_mod.Matern52))
+        assert bases[0].order == bases[1].order
+        for i, bs in enumerate(bases):
+            if self.n:
+                lo, hi = torch.aminmax(self.X[:, i])
+                assert lo.item() >= bs.a and hi.item() <= bs.b
+        self.kernels, self.bases = kernels, bases
+        self.kernel = kernels[-1]                            # gpr.py:254 passes the leaked loop variable
+        self.likelihood = kernels_mod.Gaussian()
+        self.m, self.order = bases[0].m, bases[0].order      # gpr.py:260-261
+        self.bandwidth = int((self.m ** self.d - 1) * self.order / (self.m - 1))   # gpr.py:262 (as written)
+        self.true_bandwidth = self.order * (bases[1].m + 1)                       # SURVEY App. B-5
+        self.inducing_features = [SplineFeatures1D(kernels[i], bases[i]) for i in range(self.d)]
+        lib = get_lib()
+        m1, m2, k = bases[0].m, bases[1].m, self.order
+        self.Mtot = m1 * m2
+        self.noff = k * (2 * k + 1) + k + 1
+        self._stats = torch.empty(lib.asvgp_kron_stats_doubles(m1, m2, k), dtype=torch.float64, device=dev)
+        self.phi_pass()
+        if distributed is None:
+            distributed = process_group is not None
+        self.num_data = allreduce_stats(self._stats, self.n, process_group) if distributed else self.n
+        self.KufKfu_blockband = self._stats[:self.noff * self.Mtot].view(self.noff, self.Mtot)
+        self.Kuf_y = self._stats[self.noff * self.Mtot:self.noff * self.Mtot + self.Mtot].view(self.Mtot, 1)
+        self.tr_yTy = self._stats[-1]
+        self._info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._post = None
+
+    def phi_pass(self):
+        b1, b2 = self.bases
+        check(get_lib().asvgp_phi_accumulate_kron2d(self.X.data_ptr(), self.y.data_ptr(), self.n, b1.mesh.data_ptr(),
+                                                    b1.mesh.shape[0], b1.delta_np, b1.m, b2.mesh.data_ptr(),
+                                                    b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                                                    self._stats.data_ptr(), stream_ptr()), "phi_accumulate_kron2d")
+        return self._stats
+
+    @property
+    def Kuf(self):
+        """gpr.py:269 kron.make_kvs_sparse(Kuf): sparse (m1*m2, N) Khatri-Rao design matrix."""
+        from . import kronecker
+        return kronecker.make_kvs_sparse(self.bases, self.X)
+
+    def theta(self):
+        return [(float(k.variance), float(k.lengthscales)) for k in self.kernels], float(self.likelihood.variance)
+
+    def _factor(self, want_alpha):
+        """Kuu factors per dimension, trace term, wide-band Cholesky of P with the rhs riding along."""
+        from . import banded
+        lib = get_lib()
+        b1, b2 = self.bases
+        m1, m2, k = b1.m, b2.m, self.order
+        s = float(self.likelihood.variance)
+        Ks = [f.make_Kuu(kern) for f, kern in zip(self.inducing_features, self.kernels)]
+        Ls = [banded.cholesky_band(K) for K in Ks]
+        Ss = [banded.inverse_from_cholesky_band(L) for L in Ls]
+        logdet_K = m2 * torch.log(Ls[0][0] ** 2).sum() + m1 * torch.log(Ls[1][0] ** 2).sum()
+        bw = k * m2 + k
+        dev = self._stats.device
+        Pb = torch.empty(self.Mtot * (bw + 1), dtype=torch.float64, device=dev)
+        tr = torch.zeros(1, dtype=torch.float64, device=dev)
+        check(lib.asvgp_kron_assemble(Ks[0].data_ptr(), Ks[1].data_ptr(), Ss[0].data_ptr(), Ss[1].data_ptr(),
+                                      self.KufKfu_blockband.data_ptr(), k, m1, m2, s, Pb.data_ptr(), tr.data_ptr(),
+                                      stream_ptr()), "kron_assemble")
+        c = self.Kuf_y.reshape(-1).clone()
+        logdet_P = torch.zeros(1, dtype=torch.float64, device=dev)
+        check(lib.asvgp_blockband_cholesky(Pb.data_ptr(), self.Mtot, bw, c.data_ptr(), logdet_P.data_ptr(),
+                                           self._info.data_ptr(), stream_ptr()), "blockband_cholesky")
+        col = int(self._info.item())
+        if col:
+            raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite at column %d" % (col - 1))
+        alpha = None
+        if want_alpha:
+            alpha = c.clone()
+            check(lib.asvgp_blockband_backsolve(Pb.data_ptr(), self.Mtot, bw, alpha.data_ptr(), stream_ptr()),
+                  "blockband_backsolve")
+            alpha = alpha / s
+        return dict(Ks=Ks, Ls=Ls, Ss=Ss, logdet_K=logdet_K, logdet_P=logdet_P[0], trace=tr[0], c=c / s, Lb=Pb, bw=bw,
+                    alpha=alpha, s=s)
+
+    def elbo(self):
+        """gpr.py:282-308."""
+        f = self._factor(want_alpha=False)
+        s = f["s"]
+        N = float(self.num_data)
+        vprod = 1.0
+        for kern in self.kernels:
+            vprod *= float(kern.variance)                    # gpr.py:284: prod of K_diag
+        elbo = -0.5 * N * math.log(2 * math.pi * s)
+        elbo = elbo - 0.5 * f["logdet_P"] + 0.5 * f["logdet_K"] - 0.5 * self.tr_yTy / s
+        elbo = elbo + 0.5 * (f["c"] ** 2).sum() - 0.5 * N * vprod / s + 0.5 * f["trace"] / s
+        return elbo
+
+    def maximum_log_likelihood_objective(self):
+        return self.elbo()
+
+    def training_loss(self):
+        return -self.elbo()
+
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        """gpr.py:310-334: (mean, var) as numpy (n,1); var = prod v + |L_P^-1 phi*|^2 - phi*^T Kuu^-1 phi*."""
+        assert not full_output_cov
+        if full_cov:
+            raise NotImplementedError
+        mean, var = self.predict_f_device(Xnew)
+        return mean.cpu().numpy(), var.cpu().numpy()
+
+    predict_f_sparse = predict_f                              # gpr.py:336-359 computes the same moments with CHOLMOD
+
+    def predict_f_device(self, Xnew, chunk=4096):
+        lib = get_lib()
+        key = self.theta()
+        if self._post is None or self._post[0] != key:
+            self._post = (key, self._factor(want_alpha=True))
+        f = self._post[1]
+        b1, b2 = self.bases
+        X = _to_device(Xnew, self._stats.device)
+        n = X.shape[0]
+        mean = torch.empty(n, dtype=torch.float64, device=X.device)
+        qk = torch.empty(n, dtype=torch.float64, device=X.device)
+        check(lib.asvgp_predict_kron2d(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np, b1.m,
+                                       b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                                       f["alpha"].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(), mean.data_ptr(),
+                                       qk.data_ptr(), stream_ptr()), "predict_kron2d")
+        vprod = 1.0
+        for kern in self.kernels:
+            vprod *= float(kern.variance)
+        qp = self._quad_P(X, f, chunk)
+        var = vprod + qp - qk
+        return mean.reshape(-1, 1), var.reshape(-1, 1)
+
+    def _quad_P(self, X, f, chunk):
+        """phi*^T P^-1 phi* = |L_P^-1 phi*|^2 (gpr.py:320-330), by multi-right-hand-side forward substitution on the
+        wide-band factor, a chunk of test points at a time (first version: blocked solves through torch on unpacked
+        diagonal blocks; the planned replacement is the band-restricted selected inverse)."""
+        from . import kronecker
+        Lb, bw, M = f["Lb"].view(self.Mtot, f["bw"] + 1), f["bw"], self.Mtot
+        out = torch.empty(X.shape[0], dtype=torch.float64, device=X.device)
+        NB = 256
+        for c0 in range(0, X.shape[0], chunk):
+            Xc = X[c0:c0 + chunk]
+            rows, cols, data = kronecker.make_kvs_coo(self.bases, Xc)
+            Z = torch.zeros((M, Xc.shape[0]), dtype=torch.float64, device=X.device)
+            Z.index_put_((rows, cols), data, accumulate=True)
+            r_first = int(rows.min().item())
+            for j0 in range((r_first // NB) * NB, M, NB):
+                j1 = min(j0 + NB, M)
+                nb = j1 - j0
+                # unpack the nb x nb diagonal block and the (<= bw + nb) x nb panel below it from band storage
+                hi = min(j1 + bw, M)
+                r = torch.arange(j0, hi, device=X.device).reshape(-1, 1)
+                cc = torch.arange(j0, j1, device=X.device).reshape(1, -1)
+                d = r - cc
+                ok = (d >= 0) & (d <= bw)
+                blk = torch.where(ok, Lb[cc.expand_as(d), d.clamp(0, bw)], torch.zeros((), dtype=torch.float64, device=X.device))
+                Z[j0:j1] = torch.linalg.solve_triangular(blk[:nb], Z[j0:j1], upper=False)
+                if hi > j1:
+                    Z[j1:hi] -= blk[nb:] @ Z[j0:j1]
+            out[c0:c0 + chunk] = (Z * Z).sum(0)
+        return out

@@ -1,0 +1,30 @@
+"""Column-wise Kronecker (Khatri-Rao) helpers: mirror of asvgp/kronecker.py:7-33 on the HIP library (d = 2).
+Row index of the pair (i1, i2) is i1*m2 + i2, exactly make_kvs_two_sparse's `sparse_repeats` x `sparse_tile`."""
+import torch
+
+from ._lib import check, f64c, get_lib, require_cuda, stream_ptr
+
+
+def make_kvs_coo(bases, X):
+    """(rows, cols, data) of the (m1*m2, N) Khatri-Rao design matrix for X (N, 2); (k+1)^2 entries per point."""
+    b1, b2 = bases
+    assert b1.order == b2.order, "both bases must share the spline order (gpr.py:261)"
+    X = f64c(torch.as_tensor(X, device=b1.device))
+    require_cuda(X)
+    n, k = X.shape[0], b1.order
+    ne = (k + 1) ** 2
+    rows = torch.empty(ne * n, dtype=torch.int64, device=X.device)
+    data = torch.empty(ne * n, dtype=torch.float64, device=X.device)
+    check(get_lib().asvgp_kron_evaluate_2d(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np,
+                                           b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, k, rows.data_ptr(),
+                                           data.data_ptr(), stream_ptr()), "kron_evaluate_2d")
+    cols = torch.arange(n, dtype=torch.int64, device=X.device).repeat(ne)
+    return rows, cols, data
+
+
+def make_kvs_sparse(bases, X):
+    """kronecker.py:32-33 for d = 2: torch sparse CSR (m1*m2, N)."""
+    rows, cols, data = make_kvs_coo(bases, X)
+    n = cols.shape[0] // (bases[0].order + 1) ** 2
+    coo = torch.sparse_coo_tensor(torch.stack([rows, cols]), data, (bases[0].m * bases[1].m, n)).coalesce()
+    return coo.to_sparse_csr()

@@ -60,6 +60,11 @@ int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t
                             const double* mesh, int64_t n_mesh, double delta, int order, int64_t M,
                             double* stats, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
+/* Phi-pass algorithm: 0 = auto (2), 1 = per-point LDS fp64 atomic scatter into the band, 2 = tile-local counting sort
+ * + per-cell moment accumulation in registers (3k+2 sums per point, converted to band entries once per workgroup).
+ * Same statistics to fp64 rounding.  Process-wide, host-side. */
+int asvgp_set_phi_algorithm(int algo);
+
 /* basis.py:58-59  neighbour_index = relu(searchsorted_left(mesh, x) - 1)  (integer work, bit-exact) */
 int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,
                        int64_t* idx, asvgp_stream_t stream);
@@ -136,6 +141,40 @@ int asvgp_posterior_prepare_1d(const double* stats, const double* static_bands, 
 int asvgp_predict_1d(const double* xnew, int64_t n, const double* mesh, int64_t n_mesh, double delta, int order,
                      int64_t M, const double* alpha, const double* W, double variance, int64_t D, double* mean,
                      double* var, asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-D Kronecker (tensor-product) path   replaces kronecker.make_kvs_sparse kronecker.py:7-33 and the dense
+ * linear algebra of GPR_kron gpr.py:239-359 (KufKfu.todense(), tf.linalg.cholesky / triangular_solve / cholesky_solve).
+ * Basis pair (i1, i2) has row index i1*m2 + i2 (dim-0 major, as make_kvs_two_sparse).  Both bases share `order` = k
+ * (gpr.py:261 takes bases[0].order).  X: (N, 2) row-major, 16-byte aligned.
+ * kron stats (output of the Phi pass; the all-reduce payload): [ n_off*M_tot block band | M_tot rhs | 1 yy ],
+ * M_tot = m1*m2, n_off = k(2k+1)+k+1 lower offsets: (d1=0, d2=0..k) then (d1=1..k, d2=-k..k);
+ * entry  A[(i1+d1)*m2 + i2+d2, i1*m2 + i2]  at  stats[off*M_tot + i1*m2 + i2].
+ * Wide-band storage for P = K1 (x) K2 + A/s: column-major lower band Pb[col*(bw+1) + (row-col)], bw = k*m2 + k.
+ * ---------------------------------------------------------------------------------------------- */
+size_t asvgp_kron_stats_doubles(int64_t m1, int64_t m2, int k);
+int asvgp_phi_accumulate_kron2d(const double* X, const double* y, int64_t N, const double* mesh1, int64_t n_mesh1,
+                                double delta1, int64_t m1, const double* mesh2, int64_t n_mesh2, double delta2,
+                                int64_t m2, int order, double* stats, asvgp_stream_t stream);
+/* Khatri-Rao COO triplets: rows[e*N + n], data[e*N + n], e = a*(k+1)+b <-> basis pair (idx1+k-a, idx2+k-b) of point n */
+int asvgp_kron_evaluate_2d(const double* X, int64_t N, const double* mesh1, int64_t n_mesh1, double delta1,
+                           const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order, int64_t* rows,
+                           double* data, asvgp_stream_t stream);
+/* Pb (may be NULL) = K1 (x) K2 + Ablk/s in wide-band storage; trace_out (may be NULL) = tr((K1 (x) K2)^-1 A) from the
+ * 1-D inverse bands S1, S2 (gpr.py:307 trace(cholesky_solve(L_Kuu, KufKfu_dense))). */
+int asvgp_kron_assemble(const double* K1, const double* K2, const double* S1, const double* S2, const double* Ablk, int k,
+                        int64_t m1, int64_t m2, double noise_variance, double* Pb, double* trace_out,
+                        asvgp_stream_t stream);
+/* in-place blocked band Cholesky (gpr.py:293 tf.linalg.cholesky(P)); rhs (may be NULL, length M) is overwritten with
+ * L^-1 rhs (gpr.py:295 triangular_solve); logdet (may be NULL) = 2 sum log diag L; info = first bad column + 1. */
+int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, double* rhs, double* logdet, int* info,
+                             asvgp_stream_t stream);
+/* x <- L^-T x */
+int asvgp_blockband_backsolve(const double* Lb, int64_t M, int64_t bw, double* x, asvgp_stream_t stream);
+/* posterior mean phi*^T alpha and (qk may be NULL) phi*^T Kuu^-1 phi* = (phi1^T S1 phi1)(phi2^T S2 phi2) per test point */
+int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
+                         const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order, const double* alpha,
+                         const double* S1, const double* S2, double* mean, double* qk, asvgp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, HIP events are recorded on the launch stream immediately around

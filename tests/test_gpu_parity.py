@@ -454,3 +454,90 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
         np.testing.assert_allclose(mean, om, rtol=0, atol=pt)
         np.testing.assert_allclose(var, ov, rtol=0, atol=pt)
     assert abs(res[1][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
+
+
+@pytest.mark.parametrize("order,M,N,sort", [(1, 16, 5000, False), (2, 33, 7001, False), (3, 100, 20000, True), (4, 64, 20000, False),
+                                             (4, 1024, 100000, False), (4, 2048, 150001, True), (5, 200, 30000, False),
+                                             (6, 90, 10000, True), (4, 4096, 60000, False), (3, 3000, 50000, True)])
+def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
+    """v1 (per-point LDS atomic scatter) and v2 (counting sort + per-cell moments) give the same statistics; sorted
+    (time-series) inputs exercise v2's wave-cooperative heavy-cell path, clustered inputs its skew handling."""
+    rng = np.random.default_rng(M + N)
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    if sort:
+        x = np.sort(x)
+        x[N // 2:N // 2 + 3000] = x[N // 2]          # a few thousand identical points in one cell
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    bs = _mk_basis(A, order, 0, 1, M)
+    ob = O.Basis(order, 0, 1, M)
+    band, rhs, yy = O.sufficient_stats_direct(ob, x, y)
+    got = {}
+    try:
+        for algo in (1, 2):
+            A.set_phi_algorithm(algo)
+            m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), bs)
+            got[algo] = m._stats.cpu().numpy().copy()
+            assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= 1e-12 * np.max(np.abs(band)), algo
+            assert np.array_equal(m.KufKfu.cpu().numpy() == 0, band == 0), algo
+            np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)))
+            assert abs(m.tr_yTy.item() - yy) <= 1e-12 * yy
+    finally:
+        A.set_phi_algorithm(0)
+    assert np.max(np.abs(got[1] - got[2])) <= 1e-12 * np.max(np.abs(got[1]))
+
+
+# ------------------------------------------------------------------------------------------------ Kronecker 2-D
+def _blockband_to_dense(blk, k, m1, m2):
+    """unpack the lower block band [off][col] into a dense symmetric (m1*m2)^2 matrix (test helper)."""
+    M = m1 * m2
+    out = np.zeros((M, M))
+    offs = [(0, d2) for d2 in range(k + 1)] + [(d1, d2) for d1 in range(1, k + 1) for d2 in range(-k, k + 1)]
+    for o, (d1, d2) in enumerate(offs):
+        for i1 in range(m1 - d1):
+            for i2 in range(max(0, -d2), min(m2, m2 - d2)):
+                c = i1 * m2 + i2
+                r = (i1 + d1) * m2 + i2 + d2
+                out[r, c] = blk[o, c]
+                out[c, r] = blk[o, c]
+    return out
+
+
+def test_khatri_rao_vs_reference_fixture(A, golden_dir):
+    Kf = np.load(os.path.join(golden_dir, "kron_fixtures.npz"))
+    X = Kf["X"]
+    bases = [A.B3Spline(0, 1, 12), A.B3Spline(-1, 2, 14)]
+    KR = A.kronecker.make_kvs_sparse(bases, dev(X)).to_dense().cpu().numpy()
+    ref = Kf["dense"]
+    assert np.array_equal(np.abs(KR) > 1e-300, np.abs(ref) > 1e-300)       # row ids (dim-0 major): bit exact
+    np.testing.assert_allclose(KR, ref, rtol=0, atol=1e-15)
+    rows, cols, data = A.kronecker.make_kvs_coo(bases, dev(X))
+    assert int(rows.max()) < 12 * 14 and cols.shape[0] == 16 * X.shape[0]
+
+
+@pytest.mark.parametrize("order,m1,m2,N", [(3, 8, 9, 300), (4, 12, 13, 2000), (2, 10, 7, 500), (3, 20, 24, 5000)])
+def test_kron_statistics_elbo_predict_vs_oracle(A, order, m1, m2, N):
+    rng = np.random.default_rng(m1 * 100 + m2)
+    X = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(-0.999, 1.999, N)], axis=1)
+    y = (np.sin(12 * X[:, :1]) * np.cos(3 * X[:, 1:]) + 0.1 * rng.normal(size=(N, 1)))
+    B = getattr(A, "B%dSpline" % order)
+    bases = [B(0, 1, m1), B(-1, 2, m2)]
+    kerns = [A.Matern32(variance=1.1, lengthscales=0.3), A.Matern32(variance=0.7, lengthscales=0.6)]
+    model = A.GPR_kron((X, y), kerns, bases)
+    model.likelihood.variance.assign(0.05)
+    obases = [O.Basis(order, 0, 1, m1), O.Basis(order, -1, 2, m2)]
+    oe, parts = O.elbo_kron(obases, [1, 1], [(1.1, 0.3), (0.7, 0.6)], 0.05, X, y)
+    Ad = _blockband_to_dense(model.KufKfu_blockband.cpu().numpy(), order, m1, m2)
+    np.testing.assert_allclose(Ad, parts["A"], rtol=0, atol=1e-12 * np.max(np.abs(parts["A"])))
+    np.testing.assert_allclose(model.Kuf_y.cpu().numpy(), parts["b"], rtol=0, atol=1e-12 * np.max(np.abs(parts["b"])))
+    assert abs(model.tr_yTy.item() - np.sum(y * y)) <= 1e-12 * np.sum(y * y)
+    assert model.true_bandwidth == order * (m2 + 1)                         # SURVEY App. B-5
+    e = model.elbo().item()
+    yy = float(np.sum(y * y))
+    assert abs(e - oe) <= elbo_tol(oe, N, 1.1 * 0.7, 0.05, yy, bcr=True), (e, oe)
+    Xs = np.stack([rng.uniform(0.01, 0.99, 200), rng.uniform(-0.99, 1.99, 200)], axis=1)
+    om, ov = O.predict_f_kron(obases, [1, 1], [(1.1, 0.3), (0.7, 0.6)], 0.05, X, y, Xs)
+    mean, var = model.predict_f(Xs)
+    np.testing.assert_allclose(mean, om, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(var, ov, rtol=0, atol=1e-8)
+    with pytest.raises(AssertionError):
+        A.GPR_kron((X, y), kerns[:1], bases)                               # gpr.py:247
