@@ -597,7 +597,7 @@ __global__ __launch_bounds__(1024) void predict_kernel(const double* __restrict_
 // phi_accumulate_kernel (bench.py's roofline figure; must agree with the rocprofv3 kernel-trace average).
 constexpr int PROF_RING = 1024;
 static int g_phi_ablate = 0;   // diagnostic only (ASVGP_PHI_ABLATE): 1 loads, 2 +cell, 3 +rank atomics, 4 +scan/scatter
-static int g_phi_algo = 0;  // 0 auto (v2 moments), 1 = v1 LDS atomics, 2 = v2 moments
+static int g_phi_algo = 0;  // 0 auto (= 1 today: v1 measured 155 us vs v2 157 us at N=10M), 1 = v1 LDS atomics, 2 = v2 moments
 static bool g_prof_on = false;
 static hipEvent_t g_prof_ev[PROF_RING][2];
 static bool g_prof_made = false;
@@ -619,7 +619,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
     return ASVGP_ERR_LDS_CAPACITY;
   }
   int cells_per_chunk = (M <= maxc) ? ncells : (maxc - K);
-  const bool v2 = (g_phi_algo != 1);
+  const bool v2 = (g_phi_algo == 2);
   constexpr int TP = 6;
   if (v2 && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
   long nblk = (N + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS);

@@ -60,7 +60,7 @@ int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t
                             const double* mesh, int64_t n_mesh, double delta, int order, int64_t M,
                             double* stats, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
-/* Phi-pass algorithm: 0 = auto (2), 1 = per-point LDS fp64 atomic scatter into the band, 2 = tile-local counting sort
+/* Phi-pass algorithm: 0 = auto (currently 1), 1 = per-point LDS fp64 atomic scatter into the band, 2 = tile-local counting sort
  * + per-cell moment accumulation in registers (3k+2 sums per point, converted to band entries once per workgroup).
  * Same statistics to fp64 rounding.  Process-wide, host-side. */
 int asvgp_set_phi_algorithm(int algo);
