@@ -18,6 +18,7 @@ SIGNATURES = {
     "asvgp_phi_workspace_bytes": (_Z, [_L, _I, _L]),
     "asvgp_phi_accumulate_1d": (_I, [_P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
     "asvgp_set_phi_algorithm": (_I, [_I]),
+    "asvgp_set_phi_workgroups": (_I, [_I]),
     "asvgp_phi_index_1d": (_I, [_P, _L, _P, _L, _D, _P, _P]),
     "asvgp_phi_evaluate_1d": (_I, [_P, _L, _P, _L, _D, _I, _I, _P, _P, _P]),
     "asvgp_matern_coeffs": (_I, [_I, _D, _D, _c.POINTER(_D), _c.POINTER(_D), _c.POINTER(_I)]),
@@ -34,6 +35,8 @@ SIGNATURES = {
     "asvgp_elbo_workspace_bytes": (_Z, [_L, _I, _L]),
     "asvgp_set_band_algorithm": (_I, [_I]),
     "asvgp_elbo_grad_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_elbo_prior_chain_1d": (_I, [_P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _Z, _P]),
+    "asvgp_elbo_data_chain_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "asvgp_posterior_prepare_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "asvgp_predict_1d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),
     "asvgp_profile_enable": (_I, [_I]),

@@ -16,10 +16,15 @@
 //   T = double, or Dual for the forward-mode tangent (d/d lengthscale of band(Kuu^-1)).
 #pragma once
 #include "band_sweeps.hpp"
+#include "bcr_lane.hpp"
 
 namespace asvgp {
 
 constexpr int BCR_THREADS = 256;
+
+// barrier ordering LDS only: the forward pass' factor stores to the L2 workspace are re-read by the SAME thread in the
+// backward pass, so they need not be drained (s_waitcnt vmcnt(0)) at every level like __syncthreads() would.
+__device__ __forceinline__ void bcr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- small dense helpers (registers, fully unrolled) -------------------------------------------------------
 template <typename T, int B>
@@ -74,23 +79,33 @@ __device__ __forceinline__ void blk_solve_LT(const T (&L)[B][B], const T (&invd)
 }
 
 // ---- storage views ----------------------------------------------------------------------------------------
-// SoA array of T: element (field, slot) ; Dual keeps value and tangent planes apart so every access is 8 B / lane.
-template <typename T> struct Soa;
-template <> struct Soa<double> {
-  double* p; long n;  // n = slots
-  __device__ __forceinline__ double get(int f, long s) const { return p[(long)f * n + s]; }
-  __device__ __forceinline__ void set(int f, long s, double v) const { p[(long)f * n + s] = v; }
-  static __host__ __device__ constexpr int planes() { return 1; }
+// LDS: struct-of-arrays with a COMPILE-TIME slot count NS, so (field * NS + slot) * 8 folds into the ds_read/ds_write
+// immediate offset; Dual keeps value and tangent planes apart (every access 8 B / lane, conflict-free).
+template <typename T, int NS> struct Soa;
+template <int NS> struct Soa<double, NS> {
+  double* p;
+  __device__ __forceinline__ double get(int f, int s) const { return p[f * NS + s]; }
+  __device__ __forceinline__ void set(int f, int s, double v) const { p[f * NS + s] = v; }
 };
-template <> struct Soa<Dual> {
-  double* p; long n; long plane;  // plane = offset (in doubles) of the tangent plane
-  __device__ __forceinline__ Dual get(int f, long s) const { long o = (long)f * n + s; return {p[o], p[plane + o]}; }
-  __device__ __forceinline__ void set(int f, long s, Dual v) const { long o = (long)f * n + s; p[o] = v.v; p[plane + o] = v.d; }
-  static __host__ __device__ constexpr int planes() { return 2; }
+template <int NS> struct Soa<Dual, NS> {
+  double* p; double* q;  // q = tangent plane
+  __device__ __forceinline__ Dual get(int f, int s) const { return {p[f * NS + s], q[f * NS + s]}; }
+  __device__ __forceinline__ void set(int f, int s, Dual v) const { p[f * NS + s] = v.v; q[f * NS + s] = v.d; }
 };
-template <typename T> __device__ __forceinline__ Soa<T> make_soa(double* p, long slots, int fields);
-template <> __device__ __forceinline__ Soa<double> make_soa<double>(double* p, long slots, int) { return {p, slots}; }
-template <> __device__ __forceinline__ Soa<Dual> make_soa<Dual>(double* p, long slots, int fields) { return {p, slots, (long)fields * slots}; }
+// global workspace: struct-of-arrays over nodes with a compile-time node stride (coalesced across the lanes of a level,
+// field offsets are constants added on the scalar unit); `Rec` is the view of one node.
+template <typename T, int NN> struct Rec;
+template <int NN> struct Rec<double, NN> {
+  double* r;  // &plane0[node]
+  __device__ __forceinline__ double get(int f) const { return r[(long)f * NN]; }
+  __device__ __forceinline__ void set(int f, double v) const { r[(long)f * NN] = v; }
+};
+template <int NN> struct Rec<Dual, NN> {
+  double* r; double* q;
+  __device__ __forceinline__ Dual get(int f) const { return {r[(long)f * NN], q[(long)f * NN]}; }
+  __device__ __forceinline__ void set(int f, Dual v) const { r[(long)f * NN] = v.v; q[(long)f * NN] = v.d; }
+};
+
 
 template <int B, int NRHS> struct BcrLayout {
   // forward LDS fields per survivor slot
@@ -102,29 +117,37 @@ template <int B, int NRHS> struct BcrLayout {
 };
 template <typename T> __host__ __device__ constexpr int planes_of() { return sizeof(T) / sizeof(double); }
 
-template <typename T, int B, int NRHS>
-__host__ __device__ inline size_t bcr_lds_doubles(long nb) {
-  long slots = (nb + 1) / 2;
-  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::F_N * slots + (size_t)nb * B + 64;
+// slots held in LDS: the largest power of two whose survivor image (+ the rhs vector) fits in ~150 KB
+template <typename T, int B> __host__ __device__ constexpr int bcr_ns() {
+  int ns = 1024;
+  while ((long)planes_of<T>() * 2 * B * B * ns * 8 + (long)2 * ns * B * 8 + 1024 > 150 * 1024) ns >>= 1;
+  return ns;
 }
 template <typename T, int B, int NRHS>
-__host__ __device__ inline size_t bcr_ws_doubles(long nb) {
-  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::W_N * nb;
+__host__ __device__ inline size_t bcr_lds_doubles(long nb) {
+  if ((nb + 1) / 2 > bcr_ns<T, B>()) return (size_t)1 << 40;  // does not fit: callers fall back to the sweeps
+  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::F_N * bcr_ns<T, B>() + (size_t)nb * B + 64;
+}
+template <typename T, int B, int NRHS>
+__host__ __device__ inline size_t bcr_ws_doubles(long) {
+  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::W_N * 2 * bcr_ns<T, B>();
 }
 
 // block extraction from the lower band (B+1, M): D_n (lower part) and E(n) = A[n+1, n] (upper-triangular block)
 template <typename T, int B>
 __device__ __forceinline__ T band_D(const BandPtr<T>& A, int M, int n, int r, int c) {  // r >= c
   int col = n * B + c, row = n * B + r;
-  if (row >= M) return (r == c) ? Num<T>::make(1.0, 0.0) : Num<T>::zero();  // identity padding
-  return A.load((long)(r - c) * M + col, true);
+  const bool pad = row >= M;  // identity padding; the load itself is unconditional (clamped) so gathers batch up
+  T v = A.load((long)(r - c) * M + (pad ? 0 : col), true);
+  return pad ? ((r == c) ? Num<T>::make(1.0, 0.0) : Num<T>::zero()) : v;
 }
 template <typename T, int B>
 __device__ __forceinline__ T band_E(const BandPtr<T>& A, int M, int n, int r, int c) {  // A[(n+1)B + r, nB + c]
-  if (r > c) return Num<T>::zero();
+  if (r > c) return Num<T>::zero();   // compile-time after unrolling
   int col = n * B + c, row = (n + 1) * B + r;
-  if (row >= M) return Num<T>::zero();
-  return A.load((long)(B + r - c) * M + col, true);
+  const bool pad = row >= M;
+  T v = A.load((long)(B + r - c) * M + (pad ? 0 : col), true);
+  return pad ? Num<T>::zero() : v;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -134,31 +157,63 @@ __device__ __forceinline__ T band_E(const BandPtr<T>& A, int M, int n, int r, in
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int B, int NRHS>
 __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
-                          double* logdet, int* info) {
+                          double* logdet, int* info, double* stamps = nullptr) {
   using N = Num<T>;
   using Lay = BcrLayout<B, NRHS>;
   const int tid = threadIdx.x;
   const int nb = (M + B - 1) / B;
-  const long slots = (nb + 1) / 2;
-  Soa<T> F = make_soa<T>(lds, slots, Lay::F_N);                               // survivors: D | E | y
-  double* xs = lds + (size_t)planes_of<T>() * Lay::F_N * slots;               // x per node (NRHS = 1) in LDS
+  constexpr int NS = bcr_ns<T, B>();
+  Soa<T, NS> F;                                                               // survivors: D | E
+  F.p = lds;
+  if constexpr (planes_of<T>() == 2) F.q = lds + (size_t)Lay::F_N * NS;
+  double* xs = lds + (size_t)planes_of<T>() * Lay::F_N * NS;                  // y / z / x per row in LDS
   double* red = xs + (size_t)nb * B;                                          // 64 doubles scratch
-  Soa<T> W = make_soa<T>(ws, nb, Lay::W_N);
+  constexpr int NN = 2 * NS;                                                  // node stride of the workspace arrays
+  auto Wn = [&](int node) -> Rec<T, NN> {
+    Rec<T, NN> rec;
+    rec.r = ws + node;
+    if constexpr (planes_of<T>() == 2) rec.q = ws + (size_t)Lay::W_N * NN + node;
+    return rec;
+  };
   int bad = 0;
   double ld_acc = 0.0, dld_acc = 0.0;
   int levels = 0;
   while ((1 << levels) < nb) ++levels;
+  // lane-distributed mode for the narrow levels (bcr_lane.hpp): group of GS lanes per node, entry (r, c) per lane
+  constexpr int GS = GroupSize<B>::v;
+  constexpr int NG = BCR_THREADS / GS;
+  constexpr int BB = B * B;
+  constexpr int LANE_MAX_NODES = 2 * NG;   // at most two rounds per level in lane mode
+  const int grp = tid / GS, e = tid % GS;
+  const bool lane_on = e < BB;
+  const int r = lane_on ? e / B : 0, c = lane_on ? e % B : 0;
+  int nst = 0;
+  unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto stamp = [&]() {  // diagnostic: cycles since the previous stamp (thread 0)
+    if (stamps && tid == 0) {
+      unsigned long long t = __builtin_amdgcn_s_memtime();
+      stamps[nst++] = (double)(t - t_prev);
+      t_prev = t;
+    }
+  };
 
-  // pre-pass: even nodes -> LDS slots (D lower part + mirrored upper, y)
+  // pre-pass: even nodes -> LDS slots (D lower part + mirrored upper); all gathers issued before the first LDS store
   for (int n = 2 * tid; n < nb; n += 2 * BCR_THREADS) {
-    const long s = n >> 1;
+    const int s = n >> 1;
+    T tmp[B * (B + 1) / 2];
+    int e = 0;
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) tmp[e++] = band_D<T, B>(A, M, n, r, c);
+    e = 0;
 #pragma unroll
     for (int r = 0; r < B; ++r)
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
-        T v = band_D<T, B>(A, M, n, r, c);
-        F.set(Lay::F_D + r * B + c, s, v);
-        if (c != r) F.set(Lay::F_D + c * B + r, s, v);
+        F.set(Lay::F_D + r * B + c, s, tmp[e]);
+        if (c != r) F.set(Lay::F_D + c * B + r, s, tmp[e]);
+        ++e;
       }
   }
   // NRHS <= 1: y lives in xs[] indexed by row and is updated in place (y -> z -> x)
@@ -170,6 +225,105 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
   for (int l = 0; l < levels; ++l) {
     const int h = 1 << l;
     const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
+    if (ne <= LANE_MAX_NODES) {
+      for (int m0 = 0; m0 < ne; m0 += NG) {
+      const int m = m0 + grp;
+      const bool act = m < ne;
+      const int i = h + m * 2 * h, a = i - h, b = i + h;
+      const bool hasb = act && (b < nb);
+      T d = N::zero(), ua = N::zero(), ub = N::zero();
+      T invd[B];
+      double z = 0.0;
+      T upd_b = N::zero();
+      double yb_upd = 0.0;
+      if (act) {
+        if (lane_on) {
+          if (l == 0) {
+            const int rr = r >= c ? r : c, cc = r >= c ? c : r;
+            d = band_D<T, B>(A, M, i, rr, cc);
+            ua = band_E<T, B>(A, M, a, r, c);
+            ub = hasb ? band_E<T, B>(A, M, i, c, r) : N::zero();   // A[i,b] = E(i)^T
+          } else {
+            d = F.get(Lay::F_D + e, i >> 1);
+            ua = F.get(Lay::F_E + e, a >> 1);
+            ub = hasb ? F.get(Lay::F_E + c * B + r, i >> 1) : N::zero();
+          }
+          if (NRHS && c == 0) z = xs[i * B + r];
+        }
+        // --- Cholesky of D_i inside the group (lower part of d becomes L)
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+          T pj = gshfl<T>(d, j * B + j, GS);
+          if (!(N::val(pj) > 0.0) && !bad) bad = i * B + j + 1;
+          T ljj, inv;
+          N::sqrt_inv(pj, ljj, inv);
+          invd[j] = inv;
+          if (c == j) d = (r == j) ? ljj : ((r > j) ? d * inv : d);
+          T lrj = gshfl<T>(d, r * B + j, GS), lcj = gshfl<T>(d, c * B + j, GS);
+          if (c > j && r >= c) d = N::nfma(lrj, lcj, d);
+        }
+        // --- U_a = L^-1 A[i,a], U_b = L^-1 A[i,b], z = L^-1 y  (row rr finalised at step rr)
+#pragma unroll
+        for (int rr = 0; rr < B; ++rr) {
+#pragma unroll
+          for (int p = 0; p < rr; ++p) {
+            T lv = gshfl<T>(d, rr * B + p, GS);
+            T uap = gshfl<T>(ua, p * B + c, GS), ubp = gshfl<T>(ub, p * B + c, GS);
+            double zp = NRHS ? __shfl(z, p * B, GS) : 0.0;
+            if (r == rr) {
+              ua = N::nfma(lv, uap, ua);
+              ub = N::nfma(lv, ubp, ub);
+              z = fma(-N::val(lv), zp, z);
+            }
+          }
+          if (r == rr) { ua = ua * invd[rr]; ub = ub * invd[rr]; z = z * N::val(invd[rr]); }
+        }
+        // --- products
+        T upd_a = N::zero(), enew = N::zero();
+        double ya_upd = 0.0;
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+          T uar = gshfl<T>(ua, p * B + r, GS), uac = gshfl<T>(ua, p * B + c, GS);
+          T ubr = gshfl<T>(ub, p * B + r, GS), ubc = gshfl<T>(ub, p * B + c, GS);
+          upd_a = upd_a + uar * uac;
+          upd_b = upd_b + ubr * ubc;
+          enew = N::nfma(ubr, uac, enew);
+          if (NRHS) {
+            double zp = __shfl(z, p * B, GS);
+            ya_upd = fma(N::val(uar), zp, ya_upd);   // valid on lanes c == 0 (uar = ua[p][r])
+            yb_upd = fma(N::val(ubr), zp, yb_upd);
+          }
+        }
+        if (lane_on) {
+          // factors -> workspace record (128 contiguous bytes per matrix per group)
+          Wn(i).set(Lay::W_L + e, (r >= c) ? d : N::zero());
+          Wn(i).set(Lay::W_UA + e, ua);
+          Wn(i).set(Lay::W_UB + e, ub);
+          if (e < B) {
+            T iv = invd[0];
+#pragma unroll
+            for (int q = 1; q < B; ++q) iv = (e == q) ? invd[q] : iv;
+            Wn(i).set(Lay::W_I + e, iv);
+          }
+          if (NRHS && c == 0) xs[i * B + r] = z;
+          // phase A: left neighbour
+          const int sa = a >> 1;
+          F.set(Lay::F_D + e, sa, F.get(Lay::F_D + e, sa) - upd_a);
+          F.set(Lay::F_E + e, sa, enew);
+          if (NRHS && c == 0) xs[a * B + r] -= ya_upd;
+        }
+      }
+      bcr_lds_barrier();
+      if (hasb && lane_on) {  // phase B: right neighbour
+        const int sb = b >> 1;
+        F.set(Lay::F_D + e, sb, F.get(Lay::F_D + e, sb) - upd_b);
+        if (NRHS && c == 0) xs[b * B + r] -= yb_upd;
+      }
+      bcr_lds_barrier();
+      }
+      stamp();
+      continue;
+    }
     for (int m0 = 0; m0 < ne; m0 += BCR_THREADS) {   // more eliminated nodes than threads: several rounds
       const int m = m0 + tid;
       const bool act = m < ne;
@@ -208,12 +362,12 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
         // factors -> workspace (log-determinant terms are summed from the stored diagonals after the solve)
 #pragma unroll
         for (int r = 0; r < B; ++r) {
-          W.set(Lay::W_I + r, i, invd[r]);
+          Wn(i).set(Lay::W_I + r, invd[r]);
 #pragma unroll
           for (int c = 0; c < B; ++c) {
-            W.set(Lay::W_L + r * B + c, i, (c <= r) ? D[r][c] : N::zero());
-            W.set(Lay::W_UA + r * B + c, i, Ua[r][c]);
-            W.set(Lay::W_UB + r * B + c, i, Ub[r][c]);
+            Wn(i).set(Lay::W_L + r * B + c, (c <= r) ? D[r][c] : N::zero());
+            Wn(i).set(Lay::W_UA + r * B + c, Ua[r][c]);
+            Wn(i).set(Lay::W_UB + r * B + c, Ub[r][c]);
           }
         }
         if (NRHS) {
@@ -221,7 +375,7 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
           for (int r = 0; r < B; ++r) xs[i * B + r] = z[r];  // z_i overwrites y_i (read back in the backward pass)
         }
         // phase A: left neighbour a
-        const long sa = a >> 1;
+        const int sa = a >> 1;
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
@@ -251,9 +405,9 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
           }
         }
       }
-      __syncthreads();
+      bcr_lds_barrier();
       if (hasb) {  // phase B: right neighbour b
-        const long sb = b >> 1;
+        const int sb = b >> 1;
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
@@ -274,57 +428,159 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
           }
         }
       }
-      __syncthreads();
+      bcr_lds_barrier();
     }
+    stamp();
   }
 
-  // ---------------- root (node 0) ----------------
-  if (tid == 0) {
-    T D[B][B], invd[B], Li[B][B];
+  // ---------------- root (node 0): lane-distributed, group 0 ----------------
+  if (grp == 0) {
+    T d = lane_on ? F.get(Lay::F_D + e, 0) : N::zero();
+    T invd[B];
 #pragma unroll
-    for (int r = 0; r < B; ++r)
+    for (int j = 0; j < B; ++j) {
+      T pj = gshfl<T>(d, j * B + j, GS);
+      if (!(N::val(pj) > 0.0) && !bad) bad = j + 1;
+      T ljj, inv;
+      N::sqrt_inv(pj, ljj, inv);
+      invd[j] = inv;
+      if (c == j) d = (r == j) ? ljj : ((r > j) ? d * inv : d);
+      T lrj = gshfl<T>(d, r * B + j, GS), lcj = gshfl<T>(d, c * B + j, GS);
+      if (c > j && r >= c) d = N::nfma(lrj, lcj, d);
+    }
+    // X = L^-1 (forward, identity rhs), then Sigma_00 = L^-T X ; x_0 = L^-T L^-1 y_0
+    T xi = (r == c) ? N::make(1.0, 0.0) : N::zero();
+    double z = (NRHS && lane_on && c == 0) ? xs[r] : 0.0;
 #pragma unroll
-      for (int c = 0; c < B; ++c) D[r][c] = (c <= r) ? F.get(Lay::F_D + r * B + c, 0) : N::zero();
-    blk_chol<T, B>(D, invd, bad, 0);
+    for (int rr = 0; rr < B; ++rr) {
 #pragma unroll
-    for (int r = 0; r < B; ++r) W.set(Lay::W_L + r * B + r, 0, D[r][r]);
-    // Sigma_00 = L^-T L^-1
-#pragma unroll
-    for (int r = 0; r < B; ++r)
-#pragma unroll
-      for (int c = 0; c < B; ++c) Li[r][c] = (r == c) ? N::make(1.0, 0.0) : N::zero();
-    blk_solve_L<T, B, B>(D, invd, Li);
-    blk_solve_LT<T, B, B>(D, invd, Li);
-#pragma unroll
-    for (int r = 0; r < B; ++r)
-#pragma unroll
-      for (int c = 0; c < B; ++c) W.set(Lay::W_SD + r * B + c, 0, Li[r][c]);
-    if (NRHS) {
-      double z[B];
-#pragma unroll
-      for (int r = 0; r < B; ++r) {
-        double t = xs[r];
-#pragma unroll
-        for (int p = 0; p < r; ++p) t = fma(-N::val(D[r][p]), z[p], t);
-        z[r] = t * N::val(invd[r]);
+      for (int p = 0; p < rr; ++p) {
+        T lv = gshfl<T>(d, rr * B + p, GS);
+        T xp = gshfl<T>(xi, p * B + c, GS);
+        double zp = NRHS ? __shfl(z, p * B, GS) : 0.0;
+        if (r == rr) { xi = N::nfma(lv, xp, xi); z = fma(-N::val(lv), zp, z); }
       }
+      if (r == rr) { xi = xi * invd[rr]; z = z * N::val(invd[rr]); }
+    }
 #pragma unroll
-      for (int r = B - 1; r >= 0; --r) {
-        double t = z[r];
+    for (int rr = B - 1; rr >= 0; --rr) {
 #pragma unroll
-        for (int p = r + 1; p < B; ++p) t = fma(-N::val(D[p][r]), z[p], t);
-        z[r] = t * N::val(invd[r]);
+      for (int p = rr + 1; p < B; ++p) {
+        T lv = gshfl<T>(d, p * B + rr, GS);   // L[p][rr]
+        T xp = gshfl<T>(xi, p * B + c, GS);
+        double zp = NRHS ? __shfl(z, p * B, GS) : 0.0;
+        if (r == rr) { xi = N::nfma(lv, xp, xi); z = fma(-N::val(lv), zp, z); }
       }
-#pragma unroll
-      for (int r = 0; r < B; ++r) xs[r] = z[r];
+      if (r == rr) { xi = xi * invd[rr]; z = z * N::val(invd[rr]); }
+    }
+    if (lane_on) {
+      Wn(0).set(Lay::W_SD + e, xi);
+      Wn(0).set(Lay::W_L + e, (r >= c) ? d : N::zero());
+      if (NRHS && c == 0) xs[r] = z;
     }
   }
   __syncthreads();
+  stamp();
 
   // ---------------- backward: solve + selected inverse ----------------
   for (int l = levels - 1; l >= 0; --l) {
     const int h = 1 << l;
     const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
+    if (ne <= LANE_MAX_NODES) {
+      for (int m0 = 0; m0 < ne; m0 += NG) {
+      const int m = m0 + grp;
+      if (m < ne) {
+        const int i = h + m * 2 * h, a = i - h, b = i + h;
+        const bool hasb = b < nb;
+        T d = N::zero(), ga = N::zero(), gb = N::zero(), saa = N::zero(), sbb = N::zero(), sba = N::zero();
+        T invd[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) invd[q] = Wn(i).get(Lay::W_I + q);
+        const bool e_is_a = ((a / (2 * h)) & 1) != 0;
+        if (lane_on) {
+          d = Wn(i).get(Lay::W_L + e);
+          ga = Wn(i).get(Lay::W_UA + e);
+          gb = Wn(i).get(Lay::W_UB + e);
+          saa = Wn(a).get(Lay::W_SD + e);
+          if (hasb) {
+            sbb = Wn(b).get(Lay::W_SD + e);
+            sba = e_is_a ? Wn(a).get(Lay::W_CB + c * B + r) : Wn(b).get(Lay::W_CA + e);   // Sigma_ba[r][c]
+          }
+        }
+        if (NRHS) {  // t = z - U_a x_a - U_b x_b on lanes (r, 0), then x_i = L^-T t
+          double t = (lane_on && c == 0) ? xs[i * B + r] : 0.0;
+#pragma unroll
+          for (int p = 0; p < B; ++p) {
+            double uarp = N::val(gshfl<T>(ga, r * B + p, GS)), ubrp = N::val(gshfl<T>(gb, r * B + p, GS));
+            t = fma(-uarp, xs[a * B + p], t);
+            if (hasb) t = fma(-ubrp, xs[b * B + p], t);
+          }
+#pragma unroll
+          for (int rr = B - 1; rr >= 0; --rr) {
+#pragma unroll
+            for (int p = rr + 1; p < B; ++p) {
+              double lv = N::val(gshfl<T>(d, p * B + rr, GS));
+              double tp = __shfl(t, p * B, GS);
+              if (r == rr) t = fma(-lv, tp, t);
+            }
+            if (r == rr) t = t * N::val(invd[rr]);
+          }
+          if (lane_on && c == 0) xs[i * B + r] = t;
+        }
+        // G_a = L^-T U_a, G_b = L^-T U_b ; Dinv = L^-T L^-1
+        T xi = (r == c) ? N::make(1.0, 0.0) : N::zero();
+#pragma unroll
+        for (int rr = 0; rr < B; ++rr) {   // xi <- L^-1 I
+#pragma unroll
+          for (int p = 0; p < rr; ++p) {
+            T lv = gshfl<T>(d, rr * B + p, GS);
+            T xp = gshfl<T>(xi, p * B + c, GS);
+            if (r == rr) xi = N::nfma(lv, xp, xi);
+          }
+          if (r == rr) xi = xi * invd[rr];
+        }
+#pragma unroll
+        for (int rr = B - 1; rr >= 0; --rr) {
+#pragma unroll
+          for (int p = rr + 1; p < B; ++p) {
+            T lv = gshfl<T>(d, p * B + rr, GS);
+            T gap = gshfl<T>(ga, p * B + c, GS), gbp = gshfl<T>(gb, p * B + c, GS), xp = gshfl<T>(xi, p * B + c, GS);
+            if (r == rr) { ga = N::nfma(lv, gap, ga); gb = N::nfma(lv, gbp, gb); xi = N::nfma(lv, xp, xi); }
+          }
+          if (r == rr) { ga = ga * invd[rr]; gb = gb * invd[rr]; xi = xi * invd[rr]; }
+        }
+        // C_a = -(G_a S_aa + G_b S_ba), C_b = -(G_a S_ab + G_b S_bb)
+        T ca = N::zero(), cb = N::zero();
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+          T garp = gshfl<T>(ga, r * B + p, GS), gbrp = gshfl<T>(gb, r * B + p, GS);
+          T saapc = gshfl<T>(saa, p * B + c, GS), sbapc = gshfl<T>(sba, p * B + c, GS);
+          T sbacp = gshfl<T>(sba, c * B + p, GS), sbbpc = gshfl<T>(sbb, p * B + c, GS);
+          ca = N::nfma(garp, saapc, ca);
+          ca = N::nfma(gbrp, sbapc, ca);
+          cb = N::nfma(garp, sbacp, cb);
+          cb = N::nfma(gbrp, sbbpc, cb);
+        }
+        // S_ii = Dinv - C_a G_a^T - C_b G_b^T
+        T sii = xi;
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+          T carp = gshfl<T>(ca, r * B + p, GS), gacp = gshfl<T>(ga, c * B + p, GS);
+          T cbrp = gshfl<T>(cb, r * B + p, GS), gbcp = gshfl<T>(gb, c * B + p, GS);
+          sii = N::nfma(carp, gacp, sii);
+          sii = N::nfma(cbrp, gbcp, sii);
+        }
+        if (lane_on) {
+          Wn(i).set(Lay::W_SD + e, sii);
+          Wn(i).set(Lay::W_CA + e, ca);
+          Wn(i).set(Lay::W_CB + e, cb);
+        }
+      }
+      __syncthreads();
+      }
+      stamp();
+      continue;
+    }
     for (int m0 = 0; m0 < ne; m0 += BCR_THREADS) {
       const int m = m0 + tid;
       if (m < ne) {
@@ -333,12 +589,12 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
         T L[B][B], invd[B], Ga[B][B], Gb[B][B];
 #pragma unroll
         for (int r = 0; r < B; ++r) {
-          invd[r] = W.get(Lay::W_I + r, i);
+          invd[r] = Wn(i).get(Lay::W_I + r);
 #pragma unroll
           for (int c = 0; c < B; ++c) {
-            L[r][c] = W.get(Lay::W_L + r * B + c, i);
-            Ga[r][c] = W.get(Lay::W_UA + r * B + c, i);
-            Gb[r][c] = W.get(Lay::W_UB + r * B + c, i);
+            L[r][c] = Wn(i).get(Lay::W_L + r * B + c);
+            Ga[r][c] = Wn(i).get(Lay::W_UA + r * B + c);
+            Gb[r][c] = Wn(i).get(Lay::W_UB + r * B + c);
           }
         }
         if (NRHS) {  // x_i = L^-T (z - Ua x_a - Ub x_b)
@@ -372,11 +628,11 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
         for (int r = 0; r < B; ++r)
 #pragma unroll
           for (int c = 0; c < B; ++c) {
-            Saa[r][c] = W.get(Lay::W_SD + r * B + c, a);
+            Saa[r][c] = Wn(a).get(Lay::W_SD + r * B + c);
             if (hasb) {
-              Sbb[r][c] = W.get(Lay::W_SD + r * B + c, b);
+              Sbb[r][c] = Wn(b).get(Lay::W_SD + r * B + c);
               // Sigma_ba: e = a -> (C_a^b)^T ; e = b -> C_b^a
-              Sba[r][c] = e_is_a ? W.get(Lay::W_CB + c * B + r, a) : W.get(Lay::W_CA + r * B + c, b);
+              Sba[r][c] = e_is_a ? Wn(a).get(Lay::W_CB + c * B + r) : Wn(b).get(Lay::W_CA + r * B + c);
             } else {
               Sbb[r][c] = N::zero();
               Sba[r][c] = N::zero();
@@ -415,13 +671,14 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
               t = N::nfma(Ca[r][p], Ga[c][p], t);
               t = N::nfma(Cb[r][p], Gb[c][p], t);
             }
-            W.set(Lay::W_SD + r * B + c, i, t);
-            W.set(Lay::W_CA + r * B + c, i, Ca[r][c]);
-            W.set(Lay::W_CB + r * B + c, i, Cb[r][c]);
+            Wn(i).set(Lay::W_SD + r * B + c, t);
+            Wn(i).set(Lay::W_CA + r * B + c, Ca[r][c]);
+            Wn(i).set(Lay::W_CB + r * B + c, Cb[r][c]);
           }
       }
       __syncthreads();
     }
+    stamp();
   }
 
   // ---------------- outputs: band of the inverse, x, logdet, info ----------------
@@ -431,7 +688,7 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
         int row = n * B + r, col = n * B + c;
-        if (row < M) S.store((long)(r - c) * M + col, W.get(Lay::W_SD + r * B + c, n));
+        if (row < M) S.store((long)(r - c) * M + col, Wn(n).get(Lay::W_SD + r * B + c));
       }
     if (n + 1 < nb) {  // Sigma[(n+1)B + r, nB + c], r <= c : from the odd member of the pair
 #pragma unroll
@@ -439,7 +696,7 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
 #pragma unroll
         for (int c = r; c < B; ++c) {
           int row = (n + 1) * B + r, col = n * B + c;
-          T v = (n & 1) ? W.get(Lay::W_CB + c * B + r, n) : W.get(Lay::W_CA + r * B + c, n + 1);
+          T v = (n & 1) ? Wn(n).get(Lay::W_CB + c * B + r) : Wn(n + 1).get(Lay::W_CA + r * B + c);
           if (row < M) S.store((long)(B + r - c) * M + col, v);
         }
     }
@@ -456,13 +713,14 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
     for (int r = tid; r < M; r += BCR_THREADS) x[r] = xs[r];
   // log|A| = 2 sum log diag(L_i) over all nodes, off the dependent chain (padding rows have L = 1)
   for (int e = tid; e < nb * B; e += BCR_THREADS) {
-    T d = W.get(Lay::W_L + (e % B) * B + (e % B), e / B);
+    T d = Wn(e / B).get(Lay::W_L + (e % B) * B + (e % B));
     ld_acc += 2.0 * log(N::val(d));
     dld_acc += 2.0 * N::tan(d) / N::val(d);
   }
   // reductions
   double tot = block_sum(ld_acc, red);
   double dtot = block_sum(dld_acc, red);
+  stamp();
   if (tid == 0) {
     logdet[0] = tot;
     logdet[1] = dtot;

@@ -9,11 +9,14 @@
 //   phase 1  factor   : block0 dual Cholesky(Kuu) (gpr.py:56) | block1 Cholesky(P) + c = L_P^-1 b (gpr.py:73-75)
 //   phase 2  inverse  : block0 dual Takahashi(Kuu) (gpr.py:59) | block1 Takahashi(P) + alpha = L_P^-T c
 //   phase 3  finalize : log-dets (gpr.py:57,74), band traces (gpr.py:60-70), 7-term bound (gpr.py:78-87), gradient
-#include "bcr.hpp"
+#include <stdlib.h>
+
+#include "bcr16.hpp"
 
 namespace asvgp {
 
-static int g_band_algo = 0;  // 0 auto (BCR when it fits the LDS), 1 sequential sweeps, 2 force BCR
+static int g_band_algo = 0;  // 0 auto (= 2 when it fits the LDS), 1 sequential sweeps, 2 hybrid BCR (one thread per node on
+                             // wide levels, lane-distributed on narrow levels), 3 fully lane-distributed BCR
 
 struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]; int n; };
 
@@ -31,7 +34,7 @@ __global__ void elbo_prepare_kernel(const double* __restrict__ S, KuuCoefs2 cf, 
   }
   Kuu[e] = acc;
   if (dK) dK[e] = dacc;
-  P[e] = __dadd_rn(__ddiv_rn(A[e], s), acc);  // gpr.py:72  KufKfu / sigma2 + Kuu
+  if (P) P[e] = __dadd_rn(__ddiv_rn(A[e], s), acc);  // gpr.py:72  KufKfu / sigma2 + Kuu
 }
 
 template <int K, bool TANGENT, bool RHS>
@@ -72,34 +75,65 @@ template <int K, bool TANGENT>
 __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu, const double* dK, const double* P,
                                                                const double* b, int M, double* wsK, double* wsP,
                                                                double* SK, double* dSK, double* SP, double* x,
-                                                               double* logdets, int* info) {
+                                                               double* logdets, int* info, int do_stamps,
+                                                               int first_chain) {
   extern __shared__ double lds[];
-  if (blockIdx.x == 0) {
-    if (TANGENT) bcr_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info);
-    else bcr_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info);
+  double* st = do_stamps ? logdets + 8 : nullptr;  // diagnostic: 24 stamps per chain after the 4 log-det slots
+  if (blockIdx.x + first_chain == 0) {
+    if (TANGENT) bcr_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
+    else bcr_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
   } else {
-    bcr_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1);
+    bcr_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
+  }
+}
+
+// the same with the lane-distributed solver (bcr16.hpp), 1024 threads per chain
+template <int K, bool TANGENT>
+__global__ __launch_bounds__(BCR16_THREADS) void elbo_bcr16_kernel(const double* Kuu, const double* dK, const double* P,
+                                                                   const double* b, int M, double* wsK, double* wsP,
+                                                                   double* SK, double* dSK, double* SP, double* x,
+                                                                   double* logdets, int* info, int do_stamps,
+                                                                   int first_chain) {
+  extern __shared__ double lds[];
+  double* st = do_stamps ? logdets + 8 : nullptr;
+  if (blockIdx.x + first_chain == 0) {
+    if (TANGENT) bcr16_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
+    else bcr16_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
+  } else {
+    bcr16_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
   }
 }
 
 // sym-band quadratic form helper: x^T sym(S) x over columns handled by this thread
-__device__ __forceinline__ double quad_col(const double* S, long M, int k, long j, const double* x, long D, long d) {
+// (branch-free: out-of-range neighbours are clamped and their band entry is a structural zero of the right-padded band)
+template <int KT>
+__device__ __forceinline__ double quad_col(const double* S, long M, long j, const double* x, long D, long d) {
   double xj = x[j * D + d];
   double a = S[j] * xj * xj;
-  for (int r = 1; r <= k; ++r)
-    if (j + r < M) a = fma(2.0 * S[(long)r * M + j] * xj, x[(j + r) * D + d], a);
+#pragma unroll
+  for (int r = 1; r <= KT; ++r) {
+    long jr = (j + r < M) ? j + r : M - 1;
+    double sv = (j + r < M) ? S[(long)r * M + j] : 0.0;
+    a = fma(2.0 * sv * xj, x[jr * D + d], a);
+  }
   return a;
 }
 
 struct ElboScalars { double v, l, s, N; };
 
-__global__ __launch_bounds__(1024) void elbo_finalize_kernel(
+template <int KT>
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(
     const double* __restrict__ stats, const double* __restrict__ Kuu, const double* __restrict__ dK,
     const double* __restrict__ LK, const double* __restrict__ LP, const double* __restrict__ SK,
     const double* __restrict__ dSK, const double* __restrict__ SP, const double* __restrict__ c,
-    const double* __restrict__ alpha, const double* __restrict__ logdets, long M, int k, long D, ElboScalars th,
-    double* __restrict__ out) {
+    const double* __restrict__ alpha, const double* __restrict__ logdets, long M, int k_rt, long D, ElboScalars th,
+    double alpha_scale, double* __restrict__ gacc, unsigned* __restrict__ ticket, double* __restrict__ out) {
+  // grid of FIN_BLOCKS workgroups (a single one is limited by one CU's L1 bandwidth: ~740 KB of bands at M = 2048);
+  // partial sums meet in `gacc` through device-scope atomics, the last workgroup to arrive writes the result and
+  // re-arms gacc / ticket for the next call.
   __shared__ double scratch[16];
+  constexpr int k = KT;   // compile-time bandwidth: the per-column loops unroll and their loads issue together
+  (void)k_rt;
   const double* A = stats;
   const double* b = stats + (long)(k + 1) * M;
   const double yy = stats[(long)(k + 1) * M + M * D];
@@ -107,12 +141,13 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  for (long j = threadIdx.x; j < M; j += blockDim.x) {
+  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (long)gridDim.x * blockDim.x) {
     if (!logdets) {
       double lk = LK[j], lp = LP[j];
       acc[LOGK] += log(lk * lk);  // gpr.py:57  log(square(L[0,:]))
       acc[LOGP] += log(lp * lp);  // gpr.py:74
     }
+#pragma unroll
     for (int r = 0; r <= k; ++r) {
       long o = (long)r * M + j;
       double w = (r == 0) ? 1.0 : 2.0;
@@ -130,9 +165,9 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
         double cv = c[j * D + d];
         acc[CC] = fma(cv, cv, acc[CC]);
       }
-      acc[AKA] += quad_col(Kuu, M, k, j, alpha, D, d);
-      acc[ADKA] += quad_col(dK, M, k, j, alpha, D, d);
-      acc[AAA] += quad_col(A, M, k, j, alpha, D, d);
+      acc[AKA] += quad_col<KT>(Kuu, M, j, alpha, D, d);
+      acc[ADKA] += quad_col<KT>(dK, M, j, alpha, D, d);
+      acc[AAA] += quad_col<KT>(A, M, j, alpha, D, d);
       acc[BA] = fma(b[j * D + d], alpha[j * D + d], acc[BA]);
     }
   }
@@ -151,8 +186,28 @@ __global__ __launch_bounds__(1024) void elbo_finalize_kernel(
     for (int i = 0; i < NACC; ++i) tot[i] = wave_sum(lane < nw ? part[lane][i] : 0.0);
   }
   (void)scratch;
+  __shared__ int is_last;
   if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+      if (tot[i] != 0.0) __hip_atomic_fetch_add(gacc + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x == 0) {
+    __threadfence();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) tot[i] = __hip_atomic_load(gacc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) __hip_atomic_store(gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double v = th.v, s = th.s, N = th.N, Dd = (double)D;
+    // `alpha` may still be the unscaled solve x = P^-1 b (BCR path): alpha = x * alpha_scale; quadratic forms scale^2
+    tot[AKA] *= alpha_scale * alpha_scale; tot[ADKA] *= alpha_scale * alpha_scale; tot[AAA] *= alpha_scale * alpha_scale;
+    tot[BA] *= alpha_scale;
     if (logdets) {  // BCR path: log-dets come from the elimination, |c|^2 = b^T P^-1 b / s^2 = (b . alpha) / s
       tot[LOGK] = logdets[0];
       tot[LOGP] = logdets[2];
@@ -188,14 +243,14 @@ __global__ void scale_kernel(double* __restrict__ x, double f, long n) {
 }
 
 struct Ws {
-  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha, *logdets, *bcrK, *bcrP;
+  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha, *logdets, *fin, *bcrK, *bcrP;
 };
-static size_t bcr_ws_total(long M, int k) {  // factor workspaces of both chains (Dual + double)
-  long nb = (M + k - 1) / k;
-  return (size_t)3 * (7 * k * k + k) * nb + 64;
+static size_t bcr_ws_total(long M, int k) {  // factor workspaces of both chains (Dual + double), fixed node stride
+  (void)M;
+  return (size_t)3 * (7 * k * k + k) * 2048 + 64;
 }
 static size_t ws_doubles(long M, int k, long D) {
-  return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64 + bcr_ws_total(M, k);
+  return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64 + 32 + bcr_ws_total(M, k);
 }
 static Ws carve(void* ws, long M, int k, long D) {
   double* p = static_cast<double*>(ws);
@@ -205,37 +260,45 @@ static Ws carve(void* ws, long M, int k, long D) {
   w.LP = p; p += E; w.SK = p; p += E; w.dSK = p; p += E; w.SP = p; p += E;
   w.c = p; p += (size_t)M * D; w.alpha = p; p += (size_t)M * D;
   w.logdets = p; p += 64;
-  long nb = (M + k - 1) / k;
-  w.bcrK = p; p += (size_t)2 * (7 * k * k + k) * nb;
+  w.fin = p; p += 32;   // 14 partial-sum slots + the arrival ticket of elbo_finalize_kernel (zero between calls)
+  w.bcrK = p; p += (size_t)2 * (7 * k * k + k) * 2048;
   w.bcrP = p;
   return w;
 }
 
 template <int K, bool TANGENT>
 static int run_chains(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
-                      Ws w, int* info, hipStream_t st, bool& use_bcr) {
+                      Ws w, int* info, hipStream_t st, bool& use_bcr, int part = 0, bool scale_alpha = true) {
   KuuCoefs2 cf;
   for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
   int rc = asvgp_matern_coeffs(kind, v, l, cf.c, cf.dc, &cf.n);
   if (rc) return rc;
   const long E = (long)(K + 1) * M;
   const double* A = stats;
-  const double* b = stats + E;
-  hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s, w.Kuu,
-                     w.dK, w.P);
+  const double* b = stats ? stats + E : nullptr;
   const long nb = (M + K - 1) / K;
   size_t ldsK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0>(nb) : bcr_lds_doubles<double, K, 0>(nb));
   size_t ldsP = sizeof(double) * bcr_lds_doubles<double, K, 1>(nb);
   size_t lds_bytes = ldsK > ldsP ? ldsK : ldsP;
   const bool fits = lds_bytes <= 160 * 1024 - 256;
-  use_bcr = (D == 1) && (g_band_algo == 2 || (g_band_algo == 0 && fits));
+  use_bcr = (D == 1) && (g_band_algo == 2 || g_band_algo == 3 || (g_band_algo == 0 && fits));
+  const bool lane16 = (g_band_algo == 3);   // auto = hybrid BCR (bcr.hpp: thread-per-node wide levels, lane-distributed narrow levels)
+  if (part != 0 && !use_bcr) {   // split scheduling exists for the BCR path only: the sweeps run as one unit in the data call
+    if (part == 1) return ASVGP_OK;
+    part = 0;
+  }
+  // Kuu/dKuu (theta only) are written by the prior part, P = A/s + Kuu by the data part (which re-forms Kuu in registers)
+  hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s,
+                     part == 2 ? w.LK : w.Kuu, part == 2 ? (double*)nullptr : w.dK, part == 1 ? (double*)nullptr : w.P);
   if (use_bcr) {
     if (!fits) { set_error("BCR forced but needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
-    auto kern = elbo_bcr_kernel<K, TANGENT>;
+    auto kern = lane16 ? elbo_bcr16_kernel<K, TANGENT> : elbo_bcr_kernel<K, TANGENT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-    hipLaunchKernelGGL(kern, dim3(2), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK, w.P, b, (int)M, w.bcrK, w.bcrP, w.SK,
-                       w.dSK, w.SP, w.alpha, w.logdets, info);
+    hipLaunchKernelGGL(kern, dim3(part == 0 ? 2 : 1), dim3(lane16 ? BCR16_THREADS : BCR_THREADS), lds_bytes, st, w.Kuu, w.dK, w.P, b, (int)M, w.bcrK,
+                       w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info, getenv("ASVGP_BCR_STAMPS") ? 1 : 0,
+                       part == 2 ? 1 : 0);
+    if (part == 1) return check_launch("elbo prior chain");
   } else if (D == 1) {
     hipLaunchKernelGGL((elbo_factor_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.Kuu, w.dK, w.P, w.LK, w.dLK,
                        w.LP, b, w.c, (int)M, info);
@@ -252,20 +315,23 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   // c = L_P^-1 b / s (gpr.py:75), alpha = P^-1 b / s
   long n = M * D;
   if (!use_bcr) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.c, 1.0 / s, n);
-  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
+  if (!use_bcr || scale_alpha)   // (the BCR + ELBO path leaves alpha unscaled and lets the finalize apply 1/s)
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
   return check_launch("elbo chains");
 }
 
 template <int K> struct ElboLauncher {
   static int run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
-                 double* out, int* info, void* ws, hipStream_t st) {
+                 double* out, int* info, void* ws, hipStream_t st, int part) {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
-    int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st, bcr);
-    if (rc) return rc;
+    int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false);
+    if (rc || part == 1) return rc;
     ElboScalars th{v, l, s, (double)N};
-    hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(1024), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK, w.dSK,
-                       w.SP, w.c, w.alpha, bcr ? w.logdets : (const double*)nullptr, M, K, D, th, out);
+    const int fin_blocks = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
+    hipLaunchKernelGGL(elbo_finalize_kernel<K>, dim3(fin_blocks), dim3(256), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK,
+                       w.dSK, w.SP, w.c, w.alpha, bcr ? w.logdets : (const double*)nullptr, M, K, D, th,
+                       bcr ? 1.0 / s : 1.0, w.fin, reinterpret_cast<unsigned*>(w.fin + 16), out);
     return check_launch("elbo_grad_1d");
   }
 };
@@ -289,7 +355,7 @@ template <int K> struct PostLauncher {
 using namespace asvgp;
 
 extern "C" int asvgp_set_band_algorithm(int algo) {
-  if (algo < 0 || algo > 2) { set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 block cyclic reduction"); return ASVGP_ERR_BAD_ARG; }
+  if (algo < 0 || algo > 3) { set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 BCR one thread per node, 3 BCR lane-distributed"); return ASVGP_ERR_BAD_ARG; }
   g_band_algo = algo;
   return ASVGP_OK;
 }
@@ -319,7 +385,34 @@ extern "C" int asvgp_elbo_grad_1d(const double* stats, const double* static_band
                         workspace_bytes, info, "elbo_grad_1d");
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
-#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 0);
+  switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
+#undef ELBO_CASE
+  return ASVGP_ERR_UNSUPPORTED;
+}
+
+extern "C" int asvgp_elbo_prior_chain_1d(const double* static_bands, int kind, double variance, double lengthscale,
+                                         double noise_variance, int64_t M, int k, int64_t D, int* info, void* workspace,
+                                         size_t workspace_bytes, asvgp_stream_t stream) {
+  int rc = elbo_args_ok(static_bands, static_bands, static_bands, M, k, D, variance, lengthscale, noise_variance, workspace,
+                        workspace_bytes, info, "elbo_prior_chain_1d");
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(nullptr, static_bands, kind, variance, lengthscale, noise_variance, 0, (long)M, (long)D, nullptr, info, workspace, st, 1);
+  switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
+#undef ELBO_CASE
+  return ASVGP_ERR_UNSUPPORTED;
+}
+
+extern "C" int asvgp_elbo_data_chain_1d(const double* stats, const double* static_bands, int kind, double variance,
+                                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                                        double* out, int* info, void* workspace, size_t workspace_bytes,
+                                        asvgp_stream_t stream) {
+  int rc = elbo_args_ok(stats, static_bands, out, M, k, D, variance, lengthscale, noise_variance, workspace,
+                        workspace_bytes, info, "elbo_data_chain_1d");
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 2);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
 #undef ELBO_CASE
   return ASVGP_ERR_UNSUPPORTED;

@@ -48,8 +48,10 @@ template <int K, bool VEC>
 __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
     const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
     const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
-    int do_band, double* __restrict__ partials, long ppb) {
+    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n) {
   extern __shared__ double lds[];
+  // the packed stats buffer is zeroed here (it is only touched again by phi_reduce_kernel, after this kernel)
+  if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
   double* band = lds;                      // (K+1) x ncols
   double* rhs = band + (K + 1) * ncols;    // ncols
   double* mesh = rhs + ncols;              // n_mesh
@@ -255,8 +257,9 @@ template <int K, int TP, bool VEC, int ablate = 0>
 __global__ __launch_bounds__(MOM_THREADS) void phi_moments_kernel(
     const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
     const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
-    int do_band, double* __restrict__ partials, long ppb) {
+    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n) {
   extern __shared__ double lds[];
+  if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
   constexpr int T = TP * MOM_THREADS;
   double2* buf = reinterpret_cast<double2*>(lds);                      // T sorted (s, y)
   unsigned* cnt = reinterpret_cast<unsigned*>(lds + 2 * T);            // MOM_CELLS
@@ -596,9 +599,12 @@ __global__ __launch_bounds__(1024) void predict_kernel(const double* __restrict_
 // Optional in-library timing of the dominant kernel: HIP events recorded on the launch stream right around
 // phi_accumulate_kernel (bench.py's roofline figure; must agree with the rocprofv3 kernel-trace average).
 constexpr int PROF_RING = 1024;
+static int g_phi_blocks = 0;   // 0 = PHI_MAX_BLOCKS; fewer leaves CUs free for a concurrent prior-chain kernel
 static int g_phi_ablate = 0;   // diagnostic only (ASVGP_PHI_ABLATE): 1 loads, 2 +cell, 3 +rank atomics, 4 +scan/scatter
 static int g_phi_algo = 0;  // 0 auto (= 1 today: v1 measured 155 us vs v2 157 us at N=10M), 1 = v1 LDS atomics, 2 = v2 moments
 static bool g_prof_on = false;
+static int g_prof_every = 1;     // instrument every n-th Phi launch (events perturb the stream: keep them sparse)
+static long g_prof_calls = 0;
 static hipEvent_t g_prof_ev[PROF_RING][2];
 static bool g_prof_made = false;
 static long g_prof_n = 0;
@@ -623,12 +629,14 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
   constexpr int TP = 6;
   if (v2 && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
   long nblk = (N + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS);
-  int G = (int)(nblk < 1 ? 1 : (nblk > PHI_MAX_BLOCKS ? PHI_MAX_BLOCKS : nblk));
+  const long gmax = (g_phi_blocks > 0 && g_phi_blocks < PHI_MAX_BLOCKS) ? g_phi_blocks : PHI_MAX_BLOCKS;
+  int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
   long ppb = (N + G - 1) / G;
   ppb = ((ppb + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS)) * (2 * PHI_THREADS);
   const double inv_delta = 1.0 / delta;
-  hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * ((K + 1) * M + M * D + 1), st);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  hipError_t e = hipSuccess;
+  const long zero_n = (K + 1) * M + M * D + 1;
+  bool zeroed = false;   // the first launched kernel zeroes the stats buffer
   for (long dcol = 0; dcol < D; ++dcol) {
     const double* yd = y + dcol;
     bool vec = (D == 1) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(yd) & 15) == 0);
@@ -650,7 +658,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-      const bool prof = g_prof_on && g_prof_n < PROF_RING;
+      const bool prof = g_prof_on && g_prof_n < PROF_RING && (g_prof_calls++ % g_prof_every == 0);
       if (prof) hipEventRecord(g_prof_ev[g_prof_n][0], st);
       if (v2) {
         auto k2 = vec ? phi_moments_kernel<K, TP, true> : phi_moments_kernel<K, TP, false>;
@@ -664,11 +672,12 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         }
         hipLaunchKernelGGL(k2, dim3(G), dim3(MOM_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh, inv_delta,
-                           cell0, cell1, ncols, do_band, partials, ppb);
+                           cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
       } else {
         hipLaunchKernelGGL(kern, dim3(G), dim3(PHI_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh,
-                           inv_delta, cell0, cell1, ncols, do_band, partials, ppb);
+                           inv_delta, cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
       }
+      zeroed = true;
       if (prof) { hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
       int E1 = (K + 2) * ncols + 1;
       int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
@@ -691,14 +700,22 @@ extern "C" int asvgp_set_phi_algorithm(int algo) {
   return ASVGP_OK;
 }
 
+extern "C" int asvgp_set_phi_workgroups(int n) {
+  if (n < 0 || n > PHI_MAX_BLOCKS) { set_error("set_phi_workgroups: 0 (default, one per CU) .. %d", PHI_MAX_BLOCKS); return ASVGP_ERR_BAD_ARG; }
+  g_phi_blocks = n;
+  return ASVGP_OK;
+}
+
 extern "C" int asvgp_profile_enable(int on) {
   if (on && !g_prof_made) {
     for (int i = 0; i < PROF_RING; ++i)
       for (int j = 0; j < 2; ++j)
-        if (hipEventCreate(&g_prof_ev[i][j]) != hipSuccess) { set_error("hipEventCreate failed"); return ASVGP_ERR_HIP; }
+        if (hipEventCreateWithFlags(&g_prof_ev[i][j], hipEventReleaseToDevice) != hipSuccess) { set_error("hipEventCreate failed"); return ASVGP_ERR_HIP; }
     g_prof_made = true;
   }
   g_prof_on = on != 0;
+  g_prof_every = on > 1 ? on : 1;   // on = n > 1: every n-th launch
+  g_prof_calls = 0;
   g_prof_n = 0;
   return ASVGP_OK;
 }

@@ -62,7 +62,7 @@ class GPR_1d:
         self.KufKfu = self._stats[:(k + 1) * M].view(k + 1, M)
         self.Kuf_y = self._stats[(k + 1) * M:(k + 1) * M + M * D].view(M, D)
         self.tr_yTy = self._stats[-1]
-        self._elbo_ws = torch.empty(lib.asvgp_elbo_workspace_bytes(M, k, D) // 8, dtype=torch.float64, device=dev)
+        self._elbo_ws = torch.zeros(lib.asvgp_elbo_workspace_bytes(M, k, D) // 8, dtype=torch.float64, device=dev)  # zero-init: finalize's arrival slots
         self._out = torch.zeros(8, dtype=torch.float64, device=dev)
         self._info = torch.zeros(2, dtype=torch.int32, device=dev)
         self._post = None
@@ -95,6 +95,27 @@ class GPR_1d:
                                            self.num_data, b.m, self.bandwidth, self.D, self._out.data_ptr(),
                                            self._info.data_ptr(), self._elbo_ws.data_ptr(),
                                            self._elbo_ws.numel() * 8, stream_ptr()), "elbo_grad_1d")
+        return self._out
+
+    # -- the same computation split for scheduling (asvgp_elbo_prior_chain_1d / asvgp_elbo_data_chain_1d) ------------
+    def launch_prior_chain(self):
+        """Enqueue the theta-only half (Kuu, its l-tangent, band(Kuu^-1), log|Kuu|) on the CURRENT stream.  It does not
+        read the statistics, so it may run on a side stream while the Phi pass / all-reduce are in flight."""
+        v, l, s = self.theta()
+        S = self.inducing_features.static_stack(self.kernel.kind)
+        check(get_lib().asvgp_elbo_prior_chain_1d(S.data_ptr(), self.kernel.kind, v, l, s, self.basis.m, self.bandwidth,
+                                                  self.D, self._info.data_ptr(), self._elbo_ws.data_ptr(),
+                                                  self._elbo_ws.numel() * 8, stream_ptr()), "elbo_prior_chain_1d")
+
+    def launch_data_chain(self):
+        """Enqueue the data half (P chain + finalize) on the current stream; it must be ordered after launch_prior_chain
+        for the same theta (same stream, or current_stream().wait_event(...))."""
+        v, l, s = self.theta()
+        S = self.inducing_features.static_stack(self.kernel.kind)
+        check(get_lib().asvgp_elbo_data_chain_1d(self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s,
+                                                 self.num_data, self.basis.m, self.bandwidth, self.D, self._out.data_ptr(),
+                                                 self._info.data_ptr(), self._elbo_ws.data_ptr(),
+                                                 self._elbo_ws.numel() * 8, stream_ptr()), "elbo_data_chain_1d")
         return self._out
 
     def _check_pd(self):

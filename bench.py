@@ -33,6 +33,21 @@ def synth(N, seed=1234):
     return x, y
 
 
+def measured_traffic(n_local):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
+    KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B streaming reads at 64 B).  The PMC passes
+    cannot run inside this process; the committed summary profiles/r01_phi_traffic.json is used when it was taken on
+    the same per-rank workload, otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_phi_traffic.json")
+    try:
+        d = json.load(open(path))
+        if int(d["points_per_launch"]) == int(n_local):
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sample_n, M, theta):
     """The reference's CPU steps restated in numpy/scipy (oracle/, kind 'port'): piece polynomials -> csr_matrix ->
     Phi@y, Phi@Phi.T -> band (gpr.py:39-44) + one banded ELBO+gradient, on a bounded sample, single core."""
@@ -57,8 +72,11 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--features", type=int, default=2048)
     ap.add_argument("--sorted", action="store_true", help="secondary case: time-series (sorted) inputs")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
+    ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
+    ap.add_argument("--phase-events", type=int, default=10, help="record per-phase events on every n-th step (0 = never)")
     args = ap.parse_args()
 
     import torch
@@ -76,6 +94,8 @@ def main():
     from asvgp_amd import _lib
     from asvgp_amd.dist import shard_bounds
     lib = _lib.get_lib()
+    lib.asvgp_set_phi_workgroups(248)   # 31 of 32 CUs per XCD: workgroups are dealt per XCD, so the concurrently
+                                        # running prior chain (second stream) finds a free CU wherever it lands
 
     N, M = args.points, args.features
     theta = (1.0, 0.05, 0.01)
@@ -92,13 +112,21 @@ def main():
     model.num_data = N
     stats = model._stats
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
+    ev = lambda: torch.cuda.Event(enable_timing=True)   # (timing events cost ~25 us of stream time each here: sampled)
     marks = []
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream(priority=-1)   # the theta-only prior chain runs here, concurrently with the Phi pass;
+                                            # high priority so that it is dispatched (one CU) ahead of the Phi grid
+    prior_done = torch.cuda.Event()
 
     def step(record=False):
         if record:
             e0, e1, e2, e3 = ev(), ev(), ev(), ev()
             e0.record()
+        side.wait_stream(main)          # previous step's finalize has consumed the prior-chain buffers
+        with torch.cuda.stream(side):
+            model.launch_prior_chain()
+            prior_done.record(side)
         model.phi_pass()
         if record:
             e1.record()
@@ -106,7 +134,8 @@ def main():
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         if record:
             e2.record()
-        model._launch_elbo()
+        main.wait_event(prior_done)
+        model.launch_data_chain()
         if record:
             e3.record()
             marks.append((e0, e1, e2, e3))
@@ -117,10 +146,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    lib.asvgp_profile_enable(1)
+    if not os.environ.get("ASVGP_BENCH_NOPROF"):
+        lib.asvgp_profile_enable(args.kernel_events)   # HIP events around every n-th Phi kernel launch of the timed region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(record=True)
+    for it in range(args.steps):
+        step(record=(args.phase_events > 0 and it % args.phase_events == 0))
+        if args.sync_each_step:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -134,9 +166,12 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    t_phi = np.mean([a.elapsed_time(b) for a, b, _, _ in marks]) * 1e3
-    t_comm = np.mean([b.elapsed_time(c) for _, b, c, _ in marks]) * 1e3
-    t_band = np.mean([c.elapsed_time(d) for _, _, c, d in marks]) * 1e3
+    if marks:
+        t_phi = np.mean([a.elapsed_time(b) for a, b, _, _ in marks]) * 1e3
+        t_comm = np.mean([b.elapsed_time(c) for _, b, c, _ in marks]) * 1e3
+        t_band = np.mean([c.elapsed_time(d) for _, _, c, d in marks]) * 1e3
+    else:
+        t_phi = t_comm = t_band = 0.0
     out4 = model._out.cpu().numpy()
 
     if rank == 0:
@@ -159,10 +194,11 @@ def main():
                                    % (N, "sorted" if args.sorted else "unsorted", M),
                        "parallelism": "dp%d (contiguous N-shards, one all-reduce of the %d-double band buffer)" % (world, stats.numel()),
                        "points_per_rank": n_local},
-            "phases_us": {"phi_pass": t_phi, "band_allreduce": t_comm, "elbo_grad_band_algebra": t_band},
+            "phases_us": {"phi_pass": t_phi, "band_allreduce": t_comm, "data_chain_after_stats": t_band,
+                          "note": "the theta-only prior chain (Kuu, tangent) runs on a second stream under the Phi pass"},
             "phi_pass_mpoints_per_s": n_local * world / (t_phi * 1e-6) / 1e6 if t_phi > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "phi_accumulate_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
                          "kernel_us": kern_us, "launches": launches.value,
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local},
             "elbo": float(out4[0]), "grad": [float(v) for v in out4[1:4]],

@@ -64,6 +64,9 @@ int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t
  * + per-cell moment accumulation in registers (3k+2 sums per point, converted to band entries once per workgroup).
  * Same statistics to fp64 rounding.  Process-wide, host-side. */
 int asvgp_set_phi_algorithm(int algo);
+/* workgroups of the Phi-pass kernel: 0 = default (256, one per CU); a smaller number leaves CUs free so that a
+ * concurrently enqueued asvgp_elbo_prior_chain_1d (second stream) is resident at the same time. */
+int asvgp_set_phi_workgroups(int n);
 
 /* basis.py:58-59  neighbour_index = relu(searchsorted_left(mesh, x) - 1)  (integer work, bit-exact) */
 int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,
@@ -120,14 +123,28 @@ int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, dou
  * out (device, 8 doubles): [elbo, d/d variance, d/d lengthscale, d/d noise variance, log|Kuu|, log|P|,
  *                           trace(Kuu^-1 PhiPhi^T), |c|^2].
  * ---------------------------------------------------------------------------------------------- */
-size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D);
+size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D);   /* the workspace must be zero-filled ONCE by the caller
+                                                                     (cross-workgroup arrival slots are re-armed by every call) */
 /* band algorithm of the two fused drivers below: 0 = auto (block cyclic reduction, O(log M) dependent levels, when both
  * chains fit the 160 KiB LDS and D == 1; otherwise the sequential single-wave sweeps), 1 = sequential sweeps,
- * 2 = block cyclic reduction or ASVGP_ERR_LDS_CAPACITY.  Process-wide, host-side. */
+ * 2 = block cyclic reduction, hybrid (one thread per k x k node on wide levels, one lane per block entry on narrow
+ * levels; the auto choice); 3 = block cyclic reduction, lane-distributed on every level; 2/3 return
+ * ASVGP_ERR_LDS_CAPACITY when the chains do not fit.  Process-wide, host-side. */
 int asvgp_set_band_algorithm(int algo);
 int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind, double variance,
                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                        double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+
+/* The same computation split for scheduling: the PRIOR chain touches only theta (Kuu, dKuu/dl, band(Kuu^-1) and its
+ * tangent, log|Kuu|) and may be enqueued on another stream concurrently with the Phi pass; the DATA chain
+ * (P = Kuu + A/s factor/solve/inverse + the finalize) needs `stats` and must be ordered after the prior chain of the same
+ * theta and workspace (stream order or an event).  elbo_prior_chain + elbo_data_chain == elbo_grad_1d. */
+int asvgp_elbo_prior_chain_1d(const double* static_bands, int kind, double variance, double lengthscale,
+                              double noise_variance, int64_t M, int k, int64_t D, int* info, void* workspace,
+                              size_t workspace_bytes, asvgp_stream_t stream);
+int asvgp_elbo_data_chain_1d(const double* stats, const double* static_bands, int kind, double variance,
+                             double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                             double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Posterior   replaces GPR_1d.predict_f gpr.py:91-120 (CHOLMOD natural-ordering solves)
@@ -181,7 +198,7 @@ int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int
  * every Phi-pass kernel launch (up to 1024 launches); asvgp_profile_read synchronises on them and returns the
  * summed kernel time in milliseconds and the number of launches, then resets the ring.  Host-side, not stream-ordered.
  * ---------------------------------------------------------------------------------------------- */
-int asvgp_profile_enable(int on);
+int asvgp_profile_enable(int on);   /* 0 off, 1 every launch, n > 1 every n-th launch (events perturb the stream) */
 int asvgp_profile_read(double* phi_kernel_ms_sum_host, int64_t* launches_host);
 
 #ifdef __cplusplus

@@ -429,7 +429,7 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
     xs = rng.uniform(0.001, 0.999, 500).reshape(-1, 1)
     res = {}
     try:
-        for algo in (1, 2):
+        for algo in (1, 2, 3):
             A.set_band_algorithm(algo)
             model._post = None
             r = model.elbo_and_grad().cpu().numpy()
@@ -444,9 +444,9 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
     cond = kuu_cond(ob, kd, v, l)
     big = 0.5 * N * v / s + 0.5 * yy / s
     eps_c = 2.2e-16 * cond                       # what fp64 can resolve of the cancelling O(N v / s) terms
-    for algo in (1, 2):
+    for algo in (1, 2, 3):
         r, mean, var = res[algo]
-        tol = elbo_tol(oe, N, v, s, yy, bcr=(algo == 2)) + eps_c * big
+        tol = elbo_tol(oe, N, v, s, yy, bcr=(algo != 1)) + eps_c * big
         assert abs(r[0] - oe) <= tol, (algo, r[0], oe, cond)
         gt = max(1e-6, 50 * eps_c)
         np.testing.assert_allclose(r[1:4], og, rtol=gt, atol=gt * np.max(np.abs(og)), err_msg="algo %d cond %.1e" % (algo, cond))
@@ -454,6 +454,7 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
         np.testing.assert_allclose(mean, om, rtol=0, atol=pt)
         np.testing.assert_allclose(var, ov, rtol=0, atol=pt)
     assert abs(res[1][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
+    assert abs(res[3][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
 
 
 @pytest.mark.parametrize("order,M,N,sort", [(1, 16, 5000, False), (2, 33, 7001, False), (3, 100, 20000, True), (4, 64, 20000, False),
@@ -541,3 +542,86 @@ def test_kron_statistics_elbo_predict_vs_oracle(A, order, m1, m2, N):
     np.testing.assert_allclose(var, ov, rtol=0, atol=1e-8)
     with pytest.raises(AssertionError):
         A.GPR_kron((X, y), kerns[:1], bases)                               # gpr.py:247
+
+
+# ------------------------------------------------------------------------------------------------ N-shards + band all-reduce
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                       # both ranks share the one GPU of the test box; gloo moves the band
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import asvgp_amd as A
+    from asvgp_amd.dist import shard_bounds
+    rng = np.random.default_rng(2024)
+    N, M = 200_001, 512
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    lo, hi = shard_bounds(N, world, rank)
+    model = A.GPR_1d((x[lo:hi].reshape(-1, 1), y[lo:hi]), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M),
+                     process_group=dist.group.WORLD)
+    model.likelihood.variance.assign(0.01)
+    r = model.elbo_and_grad().cpu().numpy()
+    q.put((rank, model.num_data, model._stats.cpu().numpy(), r))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_model_matches_single_rank(A):
+    """contiguous N-shards, local Phi pass, ONE sum of the packed band buffer, global N; here with 2 ranks on
+    one GPU over gloo (the 8-GPU RCCL run is the driver's); compared within the fp64 tolerance, never bit-exactly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(2024)
+    N, M = 200_001, 512
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    single = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    single.likelihood.variance.assign(0.01)
+    r1 = single.elbo_and_grad().cpu().numpy()
+    s1 = single._stats.cpu().numpy()
+    for rank, n_glob, stats, r in res:
+        assert n_glob == N
+        assert np.max(np.abs(stats - s1)) <= 1e-12 * np.max(np.abs(s1))
+        assert abs(r[0] - r1[0]) <= elbo_tol(r1[0], N, 1.0, 0.01, float(s1[-1]), bcr=True)
+        np.testing.assert_allclose(r[1:4], r1[1:4], rtol=1e-6)
+
+
+def test_split_prior_and_data_chain_equals_fused_call(A):
+    """asvgp_elbo_prior_chain_1d (side stream) + asvgp_elbo_data_chain_1d == asvgp_elbo_grad_1d."""
+    rng = np.random.default_rng(8)
+    N, M = 30000, 1024
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.01), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    fused = model.elbo_and_grad().cpu().numpy()
+    model._out.zero_()
+    side = torch.cuda.Stream()
+    done = torch.cuda.Event()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.launch_prior_chain()
+        done.record(side)
+    model.phi_pass()
+    torch.cuda.current_stream().wait_event(done)
+    split = model.launch_data_chain()[:4].cpu().numpy()
+    model._check_pd()
+    np.testing.assert_allclose(split, fused, rtol=1e-12)
+    for algo in (1, 2, 3):  # the sequential-sweep path goes through the same entry points (prior is a no-op there)
+        A.set_band_algorithm(algo)
+        try:
+            model.launch_prior_chain()
+            r = model.launch_data_chain()[:4].cpu().numpy()
+        finally:
+            A.set_band_algorithm(0)
+        np.testing.assert_allclose(r, fused, rtol=1e-6)
