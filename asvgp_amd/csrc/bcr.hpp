@@ -134,15 +134,22 @@ __host__ __device__ inline size_t bcr_ws_doubles(long) {
 }
 
 // block extraction from the lower band (B+1, M): D_n (lower part) and E(n) = A[n+1, n] (upper-triangular block)
-template <typename T, int B>
-__device__ __forceinline__ T band_D(const BandPtr<T>& A, int M, int n, int r, int c) {  // r >= c
+// P = A / s + Kuu formed on the fly with the reference's rounding sequence (gpr.py:72): lets the data chain skip its
+// elementwise prepare kernel (Kuu is already in the workspace from the prior chain).
+struct BandSumP {
+  const double* A; const double* Kuu; double s;
+  __device__ __forceinline__ double load(long off, bool ok) const { return ok ? __dadd_rn(__ddiv_rn(A[off], s), Kuu[off]) : 0.0; }
+};
+
+template <typename T, int B, typename Src>
+__device__ __forceinline__ T band_D(const Src& A, int M, int n, int r, int c) {  // r >= c
   int col = n * B + c, row = n * B + r;
   const bool pad = row >= M;  // identity padding; the load itself is unconditional (clamped) so gathers batch up
   T v = A.load((long)(r - c) * M + (pad ? 0 : col), true);
   return pad ? ((r == c) ? Num<T>::make(1.0, 0.0) : Num<T>::zero()) : v;
 }
-template <typename T, int B>
-__device__ __forceinline__ T band_E(const BandPtr<T>& A, int M, int n, int r, int c) {  // A[(n+1)B + r, nB + c]
+template <typename T, int B, typename Src>
+__device__ __forceinline__ T band_E(const Src& A, int M, int n, int r, int c) {  // A[(n+1)B + r, nB + c]
   if (r > c) return Num<T>::zero();   // compile-time after unrolling
   int col = n * B + c, row = (n + 1) * B + r;
   const bool pad = row >= M;
@@ -155,8 +162,8 @@ __device__ __forceinline__ T band_E(const BandPtr<T>& A, int M, int n, int r, in
 //   A: lower band (B+1, M);  rhs: (M) or null (NRHS = 0);  ws: bcr_ws_doubles;  lds: bcr_lds_doubles
 //   out: S lower band of A^-1 (B+1, M), x = A^-1 rhs (M), logdet (1), info (first bad column + 1)
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int B, int NRHS>
-__device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
+template <typename T, int B, int NRHS, typename Src = BandPtr<T>>
+__device__ void bcr_solve(Src A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
                           double* logdet, int* info, double* stamps = nullptr) {
   using N = Num<T>;
   using Lay = BcrLayout<B, NRHS>;
@@ -205,7 +212,7 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
 #pragma unroll
     for (int r = 0; r < B; ++r)
 #pragma unroll
-      for (int c = 0; c <= r; ++c) tmp[e++] = band_D<T, B>(A, M, n, r, c);
+      for (int c = 0; c <= r; ++c) tmp[e++] = band_D<T, B, Src>(A, M, n, r, c);
     e = 0;
 #pragma unroll
     for (int r = 0; r < B; ++r)
@@ -240,9 +247,9 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
         if (lane_on) {
           if (l == 0) {
             const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-            d = band_D<T, B>(A, M, i, rr, cc);
-            ua = band_E<T, B>(A, M, a, r, c);
-            ub = hasb ? band_E<T, B>(A, M, i, c, r) : N::zero();   // A[i,b] = E(i)^T
+            d = band_D<T, B, Src>(A, M, i, rr, cc);
+            ua = band_E<T, B, Src>(A, M, a, r, c);
+            ub = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();   // A[i,b] = E(i)^T
           } else {
             d = F.get(Lay::F_D + e, i >> 1);
             ua = F.get(Lay::F_E + e, a >> 1);
@@ -338,9 +345,9 @@ __device__ void bcr_solve(BandPtr<T> A, const double* rhs, int M, double* ws, do
 #pragma unroll
           for (int c = 0; c < B; ++c) {
             if (l == 0) {
-              D[r][c] = (c <= r) ? band_D<T, B>(A, M, i, r, c) : N::zero();
-              Ua[r][c] = band_E<T, B>(A, M, a, r, c);
-              Ub[r][c] = hasb ? band_E<T, B>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
+              D[r][c] = (c <= r) ? band_D<T, B, Src>(A, M, i, r, c) : N::zero();
+              Ua[r][c] = band_E<T, B, Src>(A, M, a, r, c);
+              Ub[r][c] = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
             } else {
               D[r][c] = (c <= r) ? F.get(Lay::F_D + r * B + c, i >> 1) : N::zero();
               Ua[r][c] = F.get(Lay::F_E + r * B + c, a >> 1);

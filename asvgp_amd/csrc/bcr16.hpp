@@ -87,7 +87,7 @@ __device__ void bcr16_solve(BandPtr<T> A, const double* rhs, int M, double* ws, 
   for (int n = 2 * grp; n < nb; n += 2 * NG) {
     if (lane_on) {
       const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-      fset(n >> 1, Lay::F_D + e, band_D<T, B>(A, M, n, rr, cc));
+      fset(n >> 1, Lay::F_D + e, band_D<T, B, BandPtr<T>>(A, M, n, rr, cc));
     }
   }
   if (NRHS)
@@ -113,9 +113,9 @@ __device__ void bcr16_solve(BandPtr<T> A, const double* rhs, int M, double* ws, 
         if (lane_on) {
           if (l == 0) {
             const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-            d = band_D<T, B>(A, M, i, rr, cc);
-            ua = band_E<T, B>(A, M, a, r, c);
-            ub = hasb ? band_E<T, B>(A, M, i, c, r) : N::zero();   // A[i,b] = E(i)^T
+            d = band_D<T, B, BandPtr<T>>(A, M, i, rr, cc);
+            ua = band_E<T, B, BandPtr<T>>(A, M, a, r, c);
+            ub = hasb ? band_E<T, B, BandPtr<T>>(A, M, i, c, r) : N::zero();   // A[i,b] = E(i)^T
           } else {
             d = fget(i >> 1, Lay::F_D + e);
             ua = fget(a >> 1, Lay::F_E + e);

@@ -76,12 +76,14 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu
                                                                const double* b, int M, double* wsK, double* wsP,
                                                                double* SK, double* dSK, double* SP, double* x,
                                                                double* logdets, int* info, int do_stamps,
-                                                               int first_chain) {
+                                                               int first_chain, double pfly_s) {
   extern __shared__ double lds[];
   double* st = do_stamps ? logdets + 8 : nullptr;  // diagnostic: 24 stamps per chain after the 4 log-det slots
   if (blockIdx.x + first_chain == 0) {
     if (TANGENT) bcr_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
     else bcr_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
+  } else if (pfly_s > 0.0) {   // P = A/s + Kuu formed inside the gathers (P then points at A = the statistics band)
+    bcr_solve<double, K, 1, BandSumP>(BandSumP{P, Kuu, pfly_s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
   } else {
     bcr_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
   }
@@ -288,16 +290,23 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
     part = 0;
   }
   // Kuu/dKuu (theta only) are written by the prior part, P = A/s + Kuu by the data part (which re-forms Kuu in registers)
-  hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s,
-                     part == 2 ? w.LK : w.Kuu, part == 2 ? (double*)nullptr : w.dK, part == 1 ? (double*)nullptr : w.P);
+  const bool pfly = (part == 2) && use_bcr && !lane16;   // data chain of the split call: P formed inside the BCR gathers
+  if (!pfly)
+    hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s,
+                       part == 2 ? w.LK : w.Kuu, part == 2 ? (double*)nullptr : w.dK, part == 1 ? (double*)nullptr : w.P);
   if (use_bcr) {
     if (!fits) { set_error("BCR forced but needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
-    auto kern = lane16 ? elbo_bcr16_kernel<K, TANGENT> : elbo_bcr_kernel<K, TANGENT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = lane16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_bcr16_kernel<K, TANGENT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-    hipLaunchKernelGGL(kern, dim3(part == 0 ? 2 : 1), dim3(lane16 ? BCR16_THREADS : BCR_THREADS), lds_bytes, st, w.Kuu, w.dK, w.P, b, (int)M, w.bcrK,
-                       w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info, getenv("ASVGP_BCR_STAMPS") ? 1 : 0,
-                       part == 2 ? 1 : 0);
+    if (lane16)
+      hipLaunchKernelGGL((elbo_bcr16_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR16_THREADS), lds_bytes, st, w.Kuu, w.dK,
+                         w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
+                         getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0);
+    else
+      hipLaunchKernelGGL((elbo_bcr_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
+                         pfly ? A : w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
+                         getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0, pfly ? s : 0.0);
     if (part == 1) return check_launch("elbo prior chain");
   } else if (D == 1) {
     hipLaunchKernelGGL((elbo_factor_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.Kuu, w.dK, w.P, w.LK, w.dLK,

@@ -348,6 +348,34 @@ class GPR_kron:
     def training_loss(self):
         return -self.elbo()
 
+    @property
+    def trainable_parameters(self):
+        ps = []
+        for kern in self.kernels:
+            ps += [kern.variance, kern.lengthscales]
+        return ps + [self.likelihood.variance]
+
+    def fit(self, maxiter=200):
+        """eNATL60.py:88-89 opt.minimize(model_kron.training_loss, ...): L-BFGS-B on the unconstrained parameters.  Interim:
+        the gradient is a 2-point finite difference of elbo() (the analytic one needs the band-restricted inverse of P,
+        DESIGN.md 4.4), i.e. 2 d + 2 bound evaluations per iteration."""
+        from scipy.optimize import minimize
+        params = self.trainable_parameters
+
+        def fun(u):
+            for p, ui in zip(params, u):
+                p.unconstrained = float(ui)
+            try:
+                return -float(self.elbo().item())
+            except NotPositiveDefiniteError:
+                return np.inf
+
+        u0 = np.array([p.unconstrained for p in params])
+        res = minimize(fun, u0, jac="2-point", method="L-BFGS-B", options=dict(maxiter=maxiter, eps=1e-6))
+        for p, ui in zip(params, res.x):
+            p.unconstrained = float(ui)
+        return res
+
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
         """gpr.py:310-334: (mean, var) as numpy (n,1); var = prod v + |L_P^-1 phi*|^2 - phi*^T Kuu^-1 phi*."""
         assert not full_output_cov

@@ -625,3 +625,16 @@ def test_split_prior_and_data_chain_equals_fused_call(A):
         finally:
             A.set_band_algorithm(0)
         np.testing.assert_allclose(r, fused, rtol=1e-6)
+
+
+def test_kron_fit_improves_bound(A):
+    rng = np.random.default_rng(12)
+    N = 1500
+    X = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(0.001, 0.999, N)], axis=1)
+    y = (np.sin(6 * X[:, :1]) * np.cos(4 * X[:, 1:]) + 0.1 * rng.normal(size=(N, 1)))
+    model = A.GPR_kron((X, y), [A.Matern32(), A.Matern32()], [A.B3Spline(0, 1, 10), A.B3Spline(0, 1, 11)])
+    e0 = model.elbo().item()
+    res = model.fit(maxiter=15)
+    e1 = model.elbo().item()
+    assert e1 > e0 + 1.0 and np.isfinite(e1)
+    assert float(model.likelihood.variance) < 0.5      # started at 1.0, the data noise is 0.01
