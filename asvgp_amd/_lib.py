@@ -35,6 +35,7 @@ SIGNATURES = {
     "asvgp_elbo_workspace_bytes": (_Z, [_L, _I, _L]),
     "asvgp_set_band_algorithm": (_I, [_I]),
     "asvgp_elbo_grad_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_elbo_chain_sync": (_I, [_I]),
     "asvgp_elbo_prior_chain_1d": (_I, [_P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _Z, _P]),
     "asvgp_elbo_data_chain_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "asvgp_posterior_prepare_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),

@@ -15,6 +15,11 @@
 
 namespace asvgp {
 
+// optional fine-grained ordering between the prior chain (stream A) and the data chain (stream B), owned by the library:
+// evK = Kuu assembled (the P chain may start), evP = prior chain complete (the finalize may start).
+static bool g_sync_on = false;
+static hipEvent_t g_evK = nullptr, g_evP = nullptr;
+
 static int g_band_algo = 0;  // 0 auto (= 2 when it fits the LDS), 1 sequential sweeps, 2 hybrid BCR (one thread per node on
                              // wide levels, lane-distributed on narrow levels), 3 fully lane-distributed BCR
 
@@ -294,6 +299,8 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   if (!pfly)
     hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s,
                        part == 2 ? w.LK : w.Kuu, part == 2 ? (double*)nullptr : w.dK, part == 1 ? (double*)nullptr : w.P);
+  if (g_sync_on && part == 1) (void)hipEventRecord(g_evK, st);
+  if (g_sync_on && part == 2) (void)hipStreamWaitEvent(st, g_evK, 0);
   if (use_bcr) {
     if (!fits) { set_error("BCR forced but needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
     hipError_t e = lane16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_bcr16_kernel<K, TANGENT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -307,7 +314,10 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
       hipLaunchKernelGGL((elbo_bcr_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          pfly ? A : w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
                          getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0, pfly ? s : 0.0);
-    if (part == 1) return check_launch("elbo prior chain");
+    if (part == 1) {
+      if (g_sync_on) (void)hipEventRecord(g_evP, st);
+      return check_launch("elbo prior chain");
+    }
   } else if (D == 1) {
     hipLaunchKernelGGL((elbo_factor_kernel<K, TANGENT, true>), dim3(2), dim3(64), 0, st, w.Kuu, w.dK, w.P, w.LK, w.dLK,
                        w.LP, b, w.c, (int)M, info);
@@ -336,6 +346,7 @@ template <int K> struct ElboLauncher {
     bool bcr = false;
     int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false);
     if (rc || part == 1) return rc;
+    if (g_sync_on && part == 2 && bcr) (void)hipStreamWaitEvent(st, g_evP, 0);
     ElboScalars th{v, l, s, (double)N};
     const int fin_blocks = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
     hipLaunchKernelGGL(elbo_finalize_kernel<K>, dim3(fin_blocks), dim3(256), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK,
@@ -366,6 +377,18 @@ using namespace asvgp;
 extern "C" int asvgp_set_band_algorithm(int algo) {
   if (algo < 0 || algo > 3) { set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 BCR one thread per node, 3 BCR lane-distributed"); return ASVGP_ERR_BAD_ARG; }
   g_band_algo = algo;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_elbo_chain_sync(int enable) {
+  if (enable && !g_evK) {
+    if (hipEventCreateWithFlags(&g_evK, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&g_evP, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
+      set_error("elbo_chain_sync: hipEventCreate failed");
+      return ASVGP_ERR_HIP;
+    }
+  }
+  g_sync_on = enable != 0;
   return ASVGP_OK;
 }
 

@@ -85,15 +85,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        # RCCL over xGMI ("nccl" is RCCL on ROCm); ASVGP_BENCH_BACKEND=gloo only for rehearsing the script on one GPU
+        dist.init_process_group(os.environ.get("ASVGP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     import asvgp_amd as A
     from asvgp_amd import _lib
     from asvgp_amd.dist import shard_bounds
     lib = _lib.get_lib()
+    lib.asvgp_elbo_chain_sync(1)        # prior chain / data chain ordered by library-internal events
     lib.asvgp_set_phi_workgroups(248)   # 31 of 32 CUs per XCD: workgroups are dealt per XCD, so the concurrently
                                         # running prior chain (second stream) finds a free CU wherever it lands
 
@@ -126,7 +128,6 @@ def main():
         side.wait_stream(main)          # previous step's finalize has consumed the prior-chain buffers
         with torch.cuda.stream(side):
             model.launch_prior_chain()
-            prior_done.record(side)
         model.phi_pass()
         if record:
             e1.record()
@@ -134,8 +135,7 @@ def main():
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         if record:
             e2.record()
-        main.wait_event(prior_done)
-        model.launch_data_chain()
+        model.launch_data_chain()       # waits (inside the library) for Kuu, then for the prior chain before the finalize
         if record:
             e3.record()
             marks.append((e0, e1, e2, e3))

@@ -139,6 +139,11 @@ int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind
  * tangent, log|Kuu|) and may be enqueued on another stream concurrently with the Phi pass; the DATA chain
  * (P = Kuu + A/s factor/solve/inverse + the finalize) needs `stats` and must be ordered after the prior chain of the same
  * theta and workspace (stream order or an event).  elbo_prior_chain + elbo_data_chain == elbo_grad_1d. */
+/* asvgp_elbo_chain_sync(1): the library orders the two calls itself with internal events - the prior chain records
+ * "Kuu assembled" and "prior chain complete" on its stream, the data chain waits for the first before factorising P and
+ * for the second before the finalize - so the caller needs no event of its own and the P chain overlaps the rest of the
+ * prior chain.  One prior/data pair in flight per process (the events are process-wide). */
+int asvgp_elbo_chain_sync(int enable);
 int asvgp_elbo_prior_chain_1d(const double* static_bands, int kind, double variance, double lengthscale,
                               double noise_variance, int64_t M, int k, int64_t D, int* info, void* workspace,
                               size_t workspace_bytes, asvgp_stream_t stream);

@@ -617,6 +617,20 @@ def test_split_prior_and_data_chain_equals_fused_call(A):
     split = model.launch_data_chain()[:4].cpu().numpy()
     model._check_pd()
     np.testing.assert_allclose(split, fused, rtol=1e-12)
+    # library-internal ordering (asvgp_elbo_chain_sync): no caller-side event
+    from asvgp_amd import _lib
+    _lib.get_lib().asvgp_elbo_chain_sync(1)
+    try:
+        model._out.zero_()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model.launch_prior_chain()
+        model.phi_pass()
+        split2 = model.launch_data_chain()[:4].cpu().numpy()
+        torch.cuda.current_stream().wait_stream(side)
+    finally:
+        _lib.get_lib().asvgp_elbo_chain_sync(0)
+    np.testing.assert_allclose(split2, fused, rtol=1e-12)
     for algo in (1, 2, 3):  # the sequential-sweep path goes through the same entry points (prior is a no-op there)
         A.set_band_algorithm(algo)
         try:
