@@ -78,6 +78,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// wave64 sum on the VALU only (DPP row shifts + row broadcasts, no LDS crossbar): every lane gets the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_step_add(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = dpp_step_add<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_step_add<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_step_add<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_step_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
+  v = dpp_step_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_step_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return readlane_f64(v, 63);
+}
+
 // block-wide sum of one double per thread; result valid in thread 0.  scratch: >= blockDim/64 doubles of LDS
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);

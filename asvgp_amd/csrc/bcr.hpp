@@ -163,7 +163,7 @@ __device__ __forceinline__ T band_E(const Src& A, int M, int n, int r, int c) { 
 //   out: S lower band of A^-1 (B+1, M), x = A^-1 rhs (M), logdet (1), info (first bad column + 1)
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int B, int NRHS, typename Src = BandPtr<T>>
-__device__ void bcr_solve(Src A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
+__device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
                           double* logdet, int* info, double* stamps = nullptr) {
   using N = Num<T>;
   using Lay = BcrLayout<B, NRHS>;

@@ -22,15 +22,9 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 }
 
 template <int K>
-__device__ __forceinline__ void phi_point(double xv, double yv, const double* mesh, int n_mesh, double m0,
-                                          double inv_delta, int cell0, int cell1, int ncols, bool do_band,
-                                          double* band, double* rhs, double& yy) {
-  int idx = neighbour_index(xv, mesh, n_mesh, m0, inv_delta);
-  if (idx < cell0 || idx >= cell1) return;
-  double t = (xv - mesh[idx]) * inv_delta;
+__device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int ncols, bool do_band, double* band, double* rhs) {
   double v[K + 1];
   bspline_pieces<K>(t, v);
-  int cb = idx - cell0;  // local column of basis row `idx`; piece i lives on row idx + K - i
 #pragma unroll
   for (int i = 0; i <= K; ++i) lds_add(rhs + cb + K - i, v[i] * yv);
   if (do_band) {
@@ -40,7 +34,73 @@ __device__ __forceinline__ void phi_point(double xv, double yv, const double* me
       for (int j = i; j <= K; ++j)  // row_i = idx+K-i >= row_j = idx+K-j: sub-diagonal d = j-i, column row_j
         lds_add(band + (j - i) * ncols + cb + K - j, v[i] * v[j]);
   }
-  yy = fma(yv, yv, yy);
+}
+
+// Two points per lane (NP = 2, a 16-B pair) or one (NP = 1).  Must be called by whole wavefronts (wave-wide votes).
+// Time-series / sorted inputs put a whole wavefront into ONE cell: 64 same-address LDS atomics would serialise
+// (1.0 ms for the sorted N = 10M case).  When every point of the wave sits in the same cell, the 20 products are
+// summed in-lane over the pair, reduced across the wave on the VALU (DPP) and committed by one lane.
+template <int K, int NP>
+__device__ __forceinline__ void phi_points(const double (&xv)[NP], const double (&yv)[NP], bool valid, const double* mesh,
+                                           int n_mesh, double m0, double inv_delta, int cell0, int cell1, int ncols,
+                                           bool do_band, double* band, double* rhs, double& yy) {
+  int idx[NP];
+  bool in[NP];
+  bool all_in = true;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    idx[q] = valid ? neighbour_index(xv[q], mesh, n_mesh, m0, inv_delta) : -1;
+    in[q] = valid && idx[q] >= cell0 && idx[q] < cell1;
+    all_in = all_in && in[q];
+  }
+  const int idx0 = __builtin_amdgcn_readfirstlane(idx[0]);
+  bool same = all_in;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) same = same && (idx[q] == idx0);
+  if (__all(same)) {  // wave-uniform branch
+    const int cb = idx0 - cell0;
+    const double u = mesh[idx0];
+    double accr[K + 1], accb[(K + 1) * (K + 2) / 2];
+#pragma unroll
+    for (int i = 0; i <= K; ++i) accr[i] = 0.0;
+#pragma unroll
+    for (int e = 0; e < (K + 1) * (K + 2) / 2; ++e) accb[e] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      double v[K + 1];
+      bspline_pieces<K>((xv[q] - u) * inv_delta, v);
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i <= K; ++i) {
+        accr[i] = fma(v[i], yv[q], accr[i]);
+#pragma unroll
+        for (int j = i; j <= K; ++j) accb[e++] += v[i] * v[j];
+      }
+      yy = fma(yv[q], yv[q], yy);
+    }
+    const bool commit = (threadIdx.x & 63) == 0;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+      double r = wave_sum_dpp(accr[i]);
+      if (commit) lds_add(rhs + cb + K - i, r);
+#pragma unroll
+      for (int j = i; j <= K; ++j) {
+        if (do_band) {
+          double b = wave_sum_dpp(accb[e]);
+          if (commit) lds_add(band + (j - i) * ncols + cb + K - j, b);
+        }
+        ++e;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+    if (in[q]) {
+      phi_scatter<K>((xv[q] - mesh[idx[q]]) * inv_delta, yv[q], idx[q] - cell0, ncols, do_band, band, rhs);
+      yy = fma(yv[q], yv[q], yy);
+    }
 }
 
 // One workgroup per CU; block b owns points [b*ppb, (b+1)*ppb).  VEC: 16-B loads of (x0,x1),(y0,y1).
@@ -71,21 +131,31 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
     const double2* y2 = reinterpret_cast<const double2*>(y);
     const long pend = end >> 1;  // pairs [beg/2, pend)
     long p = (beg >> 1) + tid;
-    double2 xa, ya;
+    double2 xa = make_double2(0.0, 0.0), ya = xa;
     if (p < pend) { xa = x2[p]; ya = y2[p]; }
-    while (p < pend) {
+    // wave-convergent loop (phi_point uses wave-wide votes): iterate while ANY lane of the wave has a pair left
+    while (__any(p < pend)) {
+      const bool have = p < pend;
       long pn = p + PHI_THREADS;
       double2 xb = xa, yb = ya;
       if (pn < pend) { xa = x2[pn]; ya = y2[pn]; }   // prefetch next pair before the LDS-atomic burst
-      phi_point<K>(xb.x, yb.x, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
-      phi_point<K>(xb.y, yb.y, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+      const double xp[2] = {xb.x, xb.y}, yp[2] = {yb.x, yb.y};
+      phi_points<K, 2>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
       p = pn;
     }
-    if ((end & 1) && tid == 0 && end > beg)  // odd tail point (only the last block can have one)
-      phi_point<K>(x[end - 1], y[end - 1], mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+    {  // odd tail point (only the last block can have one); whole wave 0 enters, one lane is valid
+      const bool tail = (end & 1) && end > beg;
+      if (tail && tid < 64) {
+        const double xp[1] = {tid == 0 ? x[end - 1] : 0.0}, yp[1] = {tid == 0 ? y[end - 1] : 0.0};
+        phi_points<K, 1>(xp, yp, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+      }
+    }
   } else {
-    for (long i = beg + tid; i < end; i += PHI_THREADS)
-      phi_point<K>(x[i], y[i * y_stride], mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+    for (long i = beg + tid; __any(i < end); i += PHI_THREADS) {
+      const bool have = i < end;
+      const double xp[1] = {have ? x[i] : 0.0}, yp[1] = {have ? y[i * y_stride] : 0.0};
+      phi_points<K, 1>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+    }
   }
   double tot = block_sum(yy, scratch);  // contains the barrier that orders the LDS atomics before the flush
   __syncthreads();
