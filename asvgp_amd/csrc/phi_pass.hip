@@ -21,8 +21,69 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f64, no return
 }
 
-template <int K>
-__device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int ncols, bool do_band, double* band, double* rhs) {
+// ---- fixed-point band accumulation (phi algorithm 3) -------------------------------------------------------------
+// ds_add_f64 retires one wave-instruction per ~21 cycles under random addresses, ds_add_u64 per ~11 (the plain
+// ds_write_b64 rate: tools/micro/lds_atomic_rate.hip).  The band products v_i v_j are non-negative and bounded by a
+// compile-time constant per sub-diagonal, so they are accumulated as 64-bit integers: product * 2^(s0 + g_d), where
+// 2^-g_d bounds the products of diagonal d and s0 = 62 - ceil(log2(points per workgroup)) keeps the per-workgroup sum
+// below 2^62.  Rounding error per addend <= 2^-(s0+1) of the diagonal's largest product (s0 >= 42 for N <= 2^20 per
+// workgroup, 47 at the north-star size), unbiased, and the sums are order-independent (bit-reproducible per workgroup).
+// Conversion is one v_add_f64 with the magic constant C_d = 1.5 * 2^(52 - s0 - g_d): the low mantissa bits of
+// (p + C_d) are round-to-nearest(p * 2^(s0+g_d)); C_d has a zero low word, so only the high words are subtracted.
+template <int K> struct FxTab {
+  int g[K + 1];
+  constexpr FxTab() : g{} {
+    double cf[K + 1][K + 1] = {};
+    for (int i = 0; i <= K; ++i)
+      for (int p = 0; p <= K; ++p) cf[i][p] = piece_coef<K, 0>(i, p);
+    for (int d = 0; d <= K; ++d) {
+      double mx = 0.0;
+      for (int i = 0; i + d <= K; ++i)
+        for (int q = 0; q <= 32; ++q) {
+          const double t = q / 32.0;
+          double a = cf[i][K], b = cf[i + d][K];
+          for (int p = K - 1; p >= 0; --p) { a = a * t + cf[i][p]; b = b * t + cf[i + d][p]; }
+          if (a * b > mx) mx = a * b;
+        }
+      double bound = mx * 1.25;    // grid maximum + margin; one further spare bit is kept in s0
+      int gd = 0;
+      while (bound * 2.0 <= 1.0 && gd < 40) { bound *= 2.0; ++gd; }
+      g[d] = gd;
+    }
+  }
+};
+template <int K> struct FxCoef { static constexpr FxTab<K> tab{}; };
+
+__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u64, no return
+}
+// p >= ~0 (tiny negative rounding noise is fine), p * 2^(s0+g) < 2^51;  chi = high word of C
+__device__ __forceinline__ unsigned long long fx_convert(double p, int chi) {
+  const double q = p + __hiloint2double(chi, 0);
+  return ((unsigned long long)(unsigned)(__double2hiint(q) - chi) << 32) | (unsigned)__double2loint(q);
+}
+template <int K> __device__ __forceinline__ int fx_chi(int s0, int d) {   // wave-uniform (SALU)
+  return ((1075 - s0 - FxCoef<K>::tab.g[d]) << 20) | 0x80000;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_step_add_u64(unsigned long long v) {
+  unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, true);
+  unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, true);
+  return v + (((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long wave_sum_dpp_u64(unsigned long long v) {
+  v = dpp_step_add_u64<0x111, 0xf>(v);
+  v = dpp_step_add_u64<0x112, 0xf>(v);
+  v = dpp_step_add_u64<0x114, 0xf>(v);
+  v = dpp_step_add_u64<0x118, 0xf>(v);
+  v = dpp_step_add_u64<0x142, 0xa>(v);
+  v = dpp_step_add_u64<0x143, 0xc>(v);
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int K, bool FX>
+__device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int ncols, bool do_band, double* band, double* rhs, int s0) {
   double v[K + 1];
   bspline_pieces<K>(t, v);
 #pragma unroll
@@ -31,8 +92,11 @@ __device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int nco
 #pragma unroll
     for (int i = 0; i <= K; ++i)
 #pragma unroll
-      for (int j = i; j <= K; ++j)  // row_i = idx+K-i >= row_j = idx+K-j: sub-diagonal d = j-i, column row_j
-        lds_add(band + (j - i) * ncols + cb + K - j, v[i] * v[j]);
+      for (int j = i; j <= K; ++j) {  // row_i = idx+K-i >= row_j = idx+K-j: sub-diagonal d = j-i, column row_j
+        if (FX) lds_add_u64(reinterpret_cast<unsigned long long*>(band) + (j - i) * ncols + cb + K - j,
+                            fx_convert(v[i] * v[j], fx_chi<K>(s0, j - i)));
+        else lds_add(band + (j - i) * ncols + cb + K - j, v[i] * v[j]);
+      }
   }
 }
 
@@ -40,10 +104,10 @@ __device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int nco
 // Time-series / sorted inputs put a whole wavefront into ONE cell: 64 same-address LDS atomics would serialise
 // (1.0 ms for the sorted N = 10M case).  When every point of the wave sits in the same cell, the 20 products are
 // summed in-lane over the pair, reduced across the wave on the VALU (DPP) and committed by one lane.
-template <int K, int NP>
+template <int K, int NP, bool FX>
 __device__ __forceinline__ void phi_points(const double (&xv)[NP], const double (&yv)[NP], bool valid, const double* mesh,
                                            int n_mesh, double m0, double inv_delta, int cell0, int cell1, int ncols,
-                                           bool do_band, double* band, double* rhs, double& yy) {
+                                           bool do_band, double* band, double* rhs, double& yy, int s0) {
   int idx[NP];
   bool in[NP];
   bool all_in = true;
@@ -87,8 +151,13 @@ __device__ __forceinline__ void phi_points(const double (&xv)[NP], const double 
 #pragma unroll
       for (int j = i; j <= K; ++j) {
         if (do_band) {
-          double b = wave_sum_dpp(accb[e]);
-          if (commit) lds_add(band + (j - i) * ncols + cb + K - j, b);
+          if (FX) {   // in-lane pair sum < 2^(s0+1) <= 2^51 after scaling: still inside the magic-constant range
+            unsigned long long b = wave_sum_dpp_u64(fx_convert(accb[e], fx_chi<K>(s0, j - i)));
+            if (commit) lds_add_u64(reinterpret_cast<unsigned long long*>(band) + (j - i) * ncols + cb + K - j, b);
+          } else {
+            double b = wave_sum_dpp(accb[e]);
+            if (commit) lds_add(band + (j - i) * ncols + cb + K - j, b);
+          }
         }
         ++e;
       }
@@ -98,17 +167,17 @@ __device__ __forceinline__ void phi_points(const double (&xv)[NP], const double 
 #pragma unroll
   for (int q = 0; q < NP; ++q)
     if (in[q]) {
-      phi_scatter<K>((xv[q] - mesh[idx[q]]) * inv_delta, yv[q], idx[q] - cell0, ncols, do_band, band, rhs);
+      phi_scatter<K, FX>((xv[q] - mesh[idx[q]]) * inv_delta, yv[q], idx[q] - cell0, ncols, do_band, band, rhs, s0);
       yy = fma(yv[q], yv[q], yy);
     }
 }
 
 // One workgroup per CU; block b owns points [b*ppb, (b+1)*ppb).  VEC: 16-B loads of (x0,x1),(y0,y1).
-template <int K, bool VEC>
+template <int K, bool VEC, bool FX>
 __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
     const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
     const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
-    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n) {
+    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n, int s0) {
   extern __shared__ double lds[];
   // the packed stats buffer is zeroed here (it is only touched again by phi_reduce_kernel, after this kernel)
   if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
@@ -140,27 +209,42 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
       double2 xb = xa, yb = ya;
       if (pn < pend) { xa = x2[pn]; ya = y2[pn]; }   // prefetch next pair before the LDS-atomic burst
       const double xp[2] = {xb.x, xb.y}, yp[2] = {yb.x, yb.y};
-      phi_points<K, 2>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+      phi_points<K, 2, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, s0);
       p = pn;
     }
     {  // odd tail point (only the last block can have one); whole wave 0 enters, one lane is valid
       const bool tail = (end & 1) && end > beg;
       if (tail && tid < 64) {
         const double xp[1] = {tid == 0 ? x[end - 1] : 0.0}, yp[1] = {tid == 0 ? y[end - 1] : 0.0};
-        phi_points<K, 1>(xp, yp, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+        phi_points<K, 1, FX>(xp, yp, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, s0);
       }
     }
   } else {
     for (long i = beg + tid; __any(i < end); i += PHI_THREADS) {
       const bool have = i < end;
       const double xp[1] = {have ? x[i] : 0.0}, yp[1] = {have ? y[i * y_stride] : 0.0};
-      phi_points<K, 1>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy);
+      phi_points<K, 1, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, s0);
     }
   }
   double tot = block_sum(yy, scratch);  // contains the barrier that orders the LDS atomics before the flush
   __syncthreads();
   double* out = partials + (size_t)blockIdx.x * (E + 1);
-  for (int e = tid; e < E; e += PHI_THREADS) out[e] = lds[e];
+  if (FX) {
+    const int nb = (K + 1) * ncols;   // integer band image -> double (exact to 53 bits), then the power-of-two unscale
+    for (int e = tid; e < E; e += PHI_THREADS) {
+      double v = lds[e];
+      if (e < nb) {
+        const int d = e / ncols;
+        int gd = FxCoef<K>::tab.g[0];
+#pragma unroll
+        for (int q = 1; q <= K; ++q) gd = (d == q) ? FxCoef<K>::tab.g[q] : gd;
+        v = ldexp((double)(long long)reinterpret_cast<const unsigned long long*>(lds)[e], -(s0 + gd));
+      }
+      out[e] = v;
+    }
+  } else {
+    for (int e = tid; e < E; e += PHI_THREADS) out[e] = lds[e];
+  }
   if (tid == 0) out[E] = tot;
 }
 
@@ -671,7 +755,7 @@ __global__ __launch_bounds__(1024) void predict_kernel(const double* __restrict_
 constexpr int PROF_RING = 1024;
 static int g_phi_blocks = 0;   // 0 = PHI_MAX_BLOCKS; fewer leaves CUs free for a concurrent prior-chain kernel
 static int g_phi_ablate = 0;   // diagnostic only (ASVGP_PHI_ABLATE): 1 loads, 2 +cell, 3 +rank atomics, 4 +scan/scatter
-static int g_phi_algo = 0;  // 0 auto (= 1 today: v1 measured 155 us vs v2 157 us at N=10M), 1 = v1 LDS atomics, 2 = v2 moments
+static int g_phi_algo = 0;  // 0 auto (= 3: 110 us at N=10M, vs 158 us for 1 and 166 us for 2), 1 = fp64 LDS atomics, 2 = moments, 3 = fixed-point band
 static bool g_prof_on = false;
 static int g_prof_every = 1;     // instrument every n-th Phi launch (events perturb the stream: keep them sparse)
 static long g_prof_calls = 0;
@@ -716,7 +800,11 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
       int ncols = cell1 - cell0 + K;
       size_t lds_bytes = sizeof(double) * ((size_t)(K + 2) * ncols + n_mesh + 16);
       int do_band = (dcol == 0);
-      auto kern = vec ? phi_accumulate_kernel<K, true> : phi_accumulate_kernel<K, false>;
+      const bool fx = (g_phi_algo == 3 || g_phi_algo == 0);
+      auto kern = fx ? (vec ? phi_accumulate_kernel<K, true, true> : phi_accumulate_kernel<K, false, true>)
+                     : (vec ? phi_accumulate_kernel<K, true, false> : phi_accumulate_kernel<K, false, false>);
+      int s0 = 50;   // 62 - ceil(log2(points per workgroup)), at most 50 (magic-constant conversion range)
+      { long c = 2; int lg = 1; while (c < ppb) { c <<= 1; ++lg; } if (62 - lg < s0) s0 = 62 - lg; }
       if (v2) {
         size_t sort_bytes = (size_t)TP * MOM_THREADS * 16 + (size_t)(2 * MOM_CELLS + 1 + 32) * 4 + 16 * 8 + 64;
         size_t band_bytes = sizeof(double) * (size_t)(K + 2) * ncols;
@@ -745,7 +833,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
                            cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
       } else {
         hipLaunchKernelGGL(kern, dim3(G), dim3(PHI_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh,
-                           inv_delta, cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
+                           inv_delta, cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n, s0);
       }
       zeroed = true;
       if (prof) { hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
@@ -763,7 +851,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
 using namespace asvgp;
 
 extern "C" int asvgp_set_phi_algorithm(int algo) {
-  if (algo < 0 || algo > 2) { set_error("set_phi_algorithm: 0 auto, 1 LDS-atomic scatter, 2 counting-sort + moments"); return ASVGP_ERR_BAD_ARG; }
+  if (algo < 0 || algo > 3) { set_error("set_phi_algorithm: 0 auto, 1 fp64 LDS-atomic scatter, 2 counting-sort + moments, 3 fixed-point band scatter"); return ASVGP_ERR_BAD_ARG; }
   g_phi_algo = algo;
   const char* ab = getenv("ASVGP_PHI_ABLATE");
   g_phi_ablate = ab ? atoi(ab) : 0;
