@@ -3,7 +3,7 @@ own model/operator surface.  See DESIGN.md / INTEGRATION.md.  There is no CPU fa
 ROCm device every compute entry point raises."""
 from . import banded, basis, dist, inducing_features, kernels, utils  # noqa: F401
 from .basis import B1Spline, B2Spline, B3Spline, B4Spline, B5Spline, B6Spline  # noqa: F401
-from .gpr import GPR_1d, GPR_kron  # noqa: F401
+from .gpr import GPR_1d, GPR_additive, GPR_kron  # noqa: F401
 from . import kronecker  # noqa: F401
 from .inducing_features import SplineFeatures1D  # noqa: F401
 from .kernels import Gaussian, Matern12, Matern32, Matern52  # noqa: F401

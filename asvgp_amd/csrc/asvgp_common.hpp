@@ -78,6 +78,19 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f64, no return
+}
+
+__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u64, no return
+}
+// fixed-point conversion (see phi_pass.hip): p >= ~0 (tiny negative rounding noise is fine), p * 2^(s0+g) < 2^51;  chi = high word of C
+__device__ __forceinline__ unsigned long long fx_convert(double p, int chi) {
+  const double q = p + __hiloint2double(chi, 0);
+  return ((unsigned long long)(unsigned)(__double2hiint(q) - chi) << 32) | (unsigned)__double2loint(q);
+}
+
 // wave64 sum on the VALU only (DPP row shifts + row broadcasts, no LDS crossbar): every lane gets the total.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_step_add(double v) {

@@ -17,10 +17,6 @@ constexpr int PHI_THREADS = 1024;
 constexpr int PHI_MAX_BLOCKS = 256;           // one 1024-thread workgroup per CU (LDS-limited)
 constexpr size_t PHI_LDS_BUDGET = 160 * 1024 - 512;
 
-__device__ __forceinline__ void lds_add(double* p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f64, no return
-}
-
 // ---- fixed-point band accumulation (phi algorithm 3) -------------------------------------------------------------
 // ds_add_f64 retires one wave-instruction per ~21 cycles under random addresses, ds_add_u64 per ~11 (the plain
 // ds_write_b64 rate: tools/micro/lds_atomic_rate.hip).  The band products v_i v_j are non-negative and bounded by a
@@ -54,14 +50,6 @@ template <int K> struct FxTab {
 };
 template <int K> struct FxCoef { static constexpr FxTab<K> tab{}; };
 
-__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u64, no return
-}
-// p >= ~0 (tiny negative rounding noise is fine), p * 2^(s0+g) < 2^51;  chi = high word of C
-__device__ __forceinline__ unsigned long long fx_convert(double p, int chi) {
-  const double q = p + __hiloint2double(chi, 0);
-  return ((unsigned long long)(unsigned)(__double2hiint(q) - chi) << 32) | (unsigned)__double2loint(q);
-}
 template <int K> __device__ __forceinline__ int fx_chi(int s0, int d) {   // wave-uniform (SALU)
   return ((1075 - s0 - FxCoef<K>::tab.g[d]) << 20) | 0x80000;
 }

@@ -437,3 +437,208 @@ class GPR_kron:
                     Z[j1:hi] -= blk[nb:] @ Z[j0:j1]
             out[c0:c0 + chunk] = (Z * Z).sum(0)
         return out
+
+
+class GPR_additive:
+    """Drop-in for asvgp/gpr.py:139-236: GPR_additive((X[N,d], y[N,1]), kernels, bases) with elbo(),
+    maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew), fit().
+
+    Kuf = vstack(Kuf_i) is never built (gpr.py:169-172 vstack + SpGEMM + todense): the banded diagonal blocks, Kuf_i y and
+    y^T y come from the 1-D Phi pass per dimension (asvgp_phi_accumulate_1d), the dense cross blocks Kuf_i Kuf_j^T from
+    asvgp_phi_cross_2d; all of them live in ONE flat buffer so that N-shards need a single all-reduce.  The M_tot^3 part
+    (Cholesky of P = blockdiag(Kuu_i) + KufKfu / sigma2, gpr.py:191-194) stays dense as in the reference (rocSOLVER through
+    torch.linalg); log|Kuu| and tr(Kuu^-1 KufKfu) use the banded operators block by block."""
+
+    def __init__(self, data, kernels, bases, process_group=None, distributed=None):
+        dev = bases[0].device
+        self.X, self.y = _to_device(data[0], dev), _to_device(data[1], dev)
+        self.n, self.d = self.X.shape[0], self.X.shape[1]
+        assert len(kernels) == len(bases) == self.d          # gpr.py:147
+        assert self.y.shape[1] == 1                          # gpr.py:148
+        for kern in kernels:                                 # gpr.py:151-152
+            assert isinstance(kern, (kernels_mod.Matern12, kernels_mod.Matern32, kernels_mod.Matern52))
+        require_cuda(self.X, self.y)
+        self.kernel = kernels[-1]                            # gpr.py:155 passes the leaked loop variable
+        self.likelihood = kernels_mod.Gaussian()
+        self.bases, self.kernels = bases, kernels
+        self.inducing_features = [SplineFeatures1D(kernels[i], bases[i]) for i in range(self.d)]
+        bandwidths = [bs.order for bs in bases]              # gpr.py:162-165
+        assert all(x == bandwidths[0] for x in bandwidths)
+        self.bandwidth = k = bases[0].order
+        for i, bs in enumerate(bases):
+            if self.n:
+                lo, hi = torch.aminmax(self.X[:, i])
+                assert lo.item() > bs.a and hi.item() < bs.b
+        lib = get_lib()
+        ms = [bs.m for bs in bases]
+        self.offsets = [0]
+        for m in ms:
+            self.offsets.append(self.offsets[-1] + m)
+        self.Mtot = self.offsets[-1]
+        # flat statistics buffer: per dimension [(k+1) m_i band | m_i rhs | yy], then the cross blocks (i < j) row-major
+        self._diag_off, self._cross_off, o = [], {}, 0
+        for m in ms:
+            self._diag_off.append(o)
+            o += (k + 2) * m + 1
+        for i in range(self.d):
+            for j in range(i + 1, self.d):
+                self._cross_off[(i, j)] = o
+                o += ms[i] * ms[j]
+        self._stats = torch.empty(o, dtype=torch.float64, device=dev)
+        self._cols = [self.X[:, i].contiguous() for i in range(self.d)]
+        wsb = max([lib.asvgp_phi_workspace_bytes(m, k, 1) for m in ms] +
+                  [lib.asvgp_phi_cross_workspace_bytes(ms[i], ms[j]) for (i, j) in self._cross_off] + [8])
+        self._ws = torch.empty(wsb // 8 + 1, dtype=torch.float64, device=dev)
+        self._wsb = wsb
+        self.phi_pass()
+        if distributed is None:
+            distributed = process_group is not None
+        self.num_data = allreduce_stats(self._stats, self.n, process_group) if distributed else self.n
+        self.tr_yTy = self._stats[self._diag_off[0] + (k + 2) * ms[0]]      # gpr.py:168
+        self._info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dense = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def phi_pass(self):
+        lib, k = get_lib(), self.bandwidth
+        for i, bs in enumerate(self.bases):
+            out = self._stats[self._diag_off[i]:]
+            check(lib.asvgp_phi_accumulate_1d(self._cols[i].data_ptr(), self.y.data_ptr(), self.n, 1, bs.mesh.data_ptr(),
+                                              bs.mesh.shape[0], bs.delta_np, k, bs.m, out.data_ptr(), self._ws.data_ptr(),
+                                              self._wsb, stream_ptr()), "phi_accumulate_1d")
+        for (i, j), o in self._cross_off.items():
+            bi, bj = self.bases[i], self.bases[j]
+            check(lib.asvgp_phi_cross_2d(self._cols[i].data_ptr(), self._cols[j].data_ptr(), self.n, bi.mesh.data_ptr(),
+                                         bi.mesh.shape[0], bi.delta_np, bi.m, bj.mesh.data_ptr(), bj.mesh.shape[0],
+                                         bj.delta_np, bj.m, k, self._stats[o:].data_ptr(), self._ws.data_ptr(), self._wsb,
+                                         stream_ptr()), "phi_cross_2d")
+        self._dense = None
+        return self._stats
+
+    def _band(self, i):
+        k, m, o = self.bandwidth, self.bases[i].m, self._diag_off[i]
+        return self._stats[o:o + (k + 1) * m].view(k + 1, m)
+
+    @property
+    def KufKfu(self):
+        """gpr.py:171: dense (M_tot, M_tot) Kuf @ Kuf.T assembled from the banded diagonal and dense cross blocks."""
+        if self._dense is None:
+            A = torch.zeros((self.Mtot, self.Mtot), dtype=torch.float64, device=self._stats.device)
+            for i in range(self.d):
+                a, b = self.offsets[i], self.offsets[i + 1]
+                A[a:b, a:b] = utils.band_to_dense_sym(self._band(i))
+            for (i, j), o in self._cross_off.items():
+                mi, mj = self.bases[i].m, self.bases[j].m
+                C = self._stats[o:o + mi * mj].view(mi, mj)
+                A[self.offsets[i]:self.offsets[i + 1], self.offsets[j]:self.offsets[j + 1]] = C
+                A[self.offsets[j]:self.offsets[j + 1], self.offsets[i]:self.offsets[i + 1]] = C.t()
+            self._dense = A
+        return self._dense
+
+    @property
+    def Kuf_y(self):
+        """gpr.py:172: (M_tot, 1)."""
+        k = self.bandwidth
+        parts = [self._stats[o + (k + 1) * bs.m:o + (k + 2) * bs.m] for o, bs in zip(self._diag_off, self.bases)]
+        return torch.cat(parts).reshape(-1, 1)
+
+    def theta(self):
+        return [(float(kn.variance), float(kn.lengthscales)) for kn in self.kernels], float(self.likelihood.variance)
+
+    def _factor(self):
+        from . import banded
+        s = float(self.likelihood.variance)
+        Ks = [f.make_Kuu(kn) for f, kn in zip(self.inducing_features, self.kernels)]
+        Ls = [banded.cholesky_band(K) for K in Ks]
+        logdet_K = sum(torch.log(L[0] ** 2).sum() for L in Ls)                      # gpr.py:187 (block diagonal)
+        trace = sum(banded.band_trace_sym(banded.inverse_from_cholesky_band(L), self._band(i))
+                    for i, L in enumerate(Ls))                                      # gpr.py:208: only diagonal blocks count
+        P = self.KufKfu / s
+        for i, K in enumerate(Ks):
+            a, b = self.offsets[i], self.offsets[i + 1]
+            P[a:b, a:b] += utils.band_to_dense_sym(K)
+        L, info = torch.linalg.cholesky_ex(P)                                       # gpr.py:192
+        if int(info.item()):
+            raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite at column %d" % (int(info.item()) - 1))
+        c = torch.linalg.solve_triangular(L, self.Kuf_y, upper=False) / s           # gpr.py:194
+        return dict(Ks=Ks, Ls=Ls, logdet_K=logdet_K, trace=trace, L=L, c=c, s=s)
+
+    def elbo(self):
+        """gpr.py:177-209."""
+        f = self._factor()
+        s, N = f["s"], float(self.num_data)
+        vsum = sum(float(kn.variance) for kn in self.kernels)                      # gpr.py:181
+        elbo = -0.5 * N * math.log(2 * math.pi * s)
+        elbo = elbo - 0.5 * torch.log(torch.diagonal(f["L"]) ** 2).sum() + 0.5 * f["logdet_K"] - 0.5 * self.tr_yTy / s
+        elbo = elbo + 0.5 * (f["c"] ** 2).sum() - 0.5 * N * vsum / s + 0.5 * f["trace"] / s
+        return elbo
+
+    def maximum_log_likelihood_objective(self):
+        return self.elbo().sum()                                                    # gpr.py:174-175
+
+    def training_loss(self):
+        return -self.maximum_log_likelihood_objective()
+
+    @property
+    def trainable_parameters(self):
+        ps = []
+        for kn in self.kernels:
+            ps += [kn.variance, kn.lengthscales]
+        return ps + [self.likelihood.variance]
+
+    def fit(self, maxiter=200):
+        """L-BFGS-B on the softplus-unconstrained parameters; central-difference gradient of the bound (the reference
+        relies on TF autodiff through its dense ops; the M_tot^3 factorisation dominates either way)."""
+        from scipy.optimize import minimize
+        params = self.trainable_parameters
+
+        def val(u):
+            for p, ui in zip(params, u):
+                p.unconstrained = float(ui)
+            try:
+                return -float(self.elbo())
+            except NotPositiveDefiniteError:
+                return float("inf")
+
+        def fun(u):
+            f0 = val(u)
+            g = np.zeros_like(u)
+            for i in range(len(u)):
+                h = 1e-5 * max(1.0, abs(u[i]))
+                up, um = u.copy(), u.copy()
+                up[i] += h
+                um[i] -= h
+                g[i] = (val(up) - val(um)) / (2 * h)
+            return f0, g
+
+        u0 = np.array([p.unconstrained for p in params])
+        res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
+        for p, ui in zip(params, res.x):
+            p.unconstrained = float(ui)
+        return res
+
+    def predict_f_device(self, Xnew, chunk=8192):
+        from . import banded
+        Xn = _to_device(Xnew, self._stats.device)
+        assert Xn.shape[1] == self.d
+        f = self._factor()
+        vsum = sum(float(kn.variance) for kn in self.kernels)
+        means, vars_ = [], []
+        for lo in range(0, Xn.shape[0], chunk):
+            xs = Xn[lo:lo + chunk]
+            Kus = torch.cat([bs.evaluate_basis(xs[:, i:i + 1].contiguous(), sparse=False) for i, bs in enumerate(self.bases)], 0)
+            tmp = torch.linalg.solve_triangular(f["L"], Kus, upper=False)            # gpr.py:226
+            means.append(tmp.t() @ f["c"])                                          # gpr.py:227
+            q = torch.zeros(xs.shape[0], dtype=torch.float64, device=xs.device)
+            for i, Lb in enumerate(f["Ls"]):                                         # gpr.py:228: Kuu.solve, block by block
+                Ki = Kus[self.offsets[i]:self.offsets[i + 1]]
+                w = banded.solve_triang_mat(Lb, Ki)
+                q += (w * w).sum(0)
+            vars_.append(vsum + (tmp * tmp).sum(0) - q)                             # gpr.py:230-232
+        mean = torch.cat(means, 0) if means else torch.zeros((0, 1), dtype=torch.float64, device=Xn.device)
+        var = torch.cat(vars_, 0) if vars_ else torch.zeros(0, dtype=torch.float64, device=Xn.device)
+        return mean, var.reshape(-1, 1).repeat(1, self.y.shape[1])                  # gpr.py:233-234
+
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        mean, var = self.predict_f_device(Xnew)
+        return mean.cpu().numpy(), var.cpu().numpy()

@@ -201,6 +201,18 @@ int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int
                          const double* S1, const double* S2, double* mean, double* qk, asvgp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Additive model (GPR_additive, gpr.py:139-236): Kuf = vstack(Kuf_1 .. Kuf_d), so Kuf Kuf^T (gpr.py:170-171) has the
+ * 1-D banded blocks of asvgp_phi_accumulate_1d on its diagonal and dense cross blocks
+ *   out[r, c] = sum_n phi_i(x_i[n])[r] * phi_j(x_j[n])[c]        (m_i x m_j, row-major, overwritten)
+ * off it.  x_i, x_j: contiguous columns of X (N).  workspace: asvgp_phi_cross_workspace_bytes(m_i, m_j) bytes (per-
+ * workgroup partial images; unused when the block exceeds the LDS and is accumulated with L2 atomics instead).
+ * ---------------------------------------------------------------------------------------------- */
+size_t asvgp_phi_cross_workspace_bytes(int64_t m_i, int64_t m_j);
+int asvgp_phi_cross_2d(const double* x_i, const double* x_j, int64_t N, const double* mesh_i, int64_t n_mesh_i,
+                       double delta_i, int64_t m_i, const double* mesh_j, int64_t n_mesh_j, double delta_j, int64_t m_j,
+                       int order, double* out, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, HIP events are recorded on the launch stream immediately around
  * every Phi-pass kernel launch (up to 1024 launches); asvgp_profile_read synchronises on them and returns the
  * summed kernel time in milliseconds and the number of launches, then resets the ring.  Host-side, not stream-ordered.

@@ -621,6 +621,55 @@ def predict_f_kron(bases, kinds, thetas, s, X, y, Xnew):
     return mean, np.tile(var.reshape(-1, 1), (1, y.shape[1]))
 
 # --------------------------------------------------------------------------------------
+# Additive model (gpr.py:139-236): Kuf = vstack(Kuf_i), Kuu = blockdiag(Kuu_i), dense algebra as the reference
+# --------------------------------------------------------------------------------------
+
+def additive_stats(bases, X, y):
+    """gpr.py:167-172: Kuf = sparse.vstack(Kuf_i); KufKfu = (Kuf @ Kuf.T).todense(); Kuf_y = Kuf @ y."""
+    import scipy.sparse as sp
+    Kuf = sp.vstack([bs.evaluate_basis(X[:, i:i + 1]) for i, bs in enumerate(bases)]).tocsr()
+    return (Kuf @ Kuf.T).toarray(), np.asarray(Kuf @ y), float(np.sum(np.square(y)))
+
+
+def _blockdiag(mats):
+    n = sum(m.shape[0] for m in mats)
+    out = np.zeros((n, n))
+    o = 0
+    for m in mats:
+        out[o:o + m.shape[0], o:o + m.shape[0]] = m
+        o += m.shape[0]
+    return out
+
+
+def elbo_additive(bases, kinds, thetas, s, X, y):
+    """gpr.py:177-209: sum K_diag = N * sum v_i (gpr.py:181,207); log|Kuu| of the block-diagonal operator (gpr.py:187);
+    dense Cholesky of P (gpr.py:191-194); tr(Kuu^-1 KufKfu) (gpr.py:208)."""
+    N, D = X.shape[0], y.shape[1]
+    A, b, yy = additive_stats(bases, X, y)
+    Kuu = _blockdiag([band_to_dense_sym(make_Kuu(bs, kd, v, l)) for bs, kd, (v, l) in zip(bases, kinds, thetas)])
+    sign, logdetK = np.linalg.slogdet(Kuu)
+    P = Kuu + A / s
+    LP = np.linalg.cholesky(P)
+    c = np.linalg.solve(LP, b) / s
+    vsum = float(np.sum([v for v, _ in thetas]))
+    elbo = (-0.5 * N * D * np.log(2 * np.pi * s) - 0.5 * D * np.sum(np.log(np.square(np.diag(LP)))) + 0.5 * D * logdetK
+            - 0.5 * yy / s + 0.5 * np.sum(np.square(c)) - 0.5 * N * D * vsum / s
+            + 0.5 * D * np.trace(np.linalg.solve(Kuu, A)) / s)
+    return float(elbo), dict(A=A, b=b, Kuu=Kuu, P=P, LP=LP, c=c)
+
+
+def predict_f_additive(bases, kinds, thetas, s, X, y, Xnew):
+    """gpr.py:211-236."""
+    import scipy.sparse as sp
+    _, parts = elbo_additive(bases, kinds, thetas, s, X, y)
+    Kus = sp.vstack([bs.evaluate_basis(Xnew[:, i:i + 1]) for i, bs in enumerate(bases)]).toarray()
+    tmp = np.linalg.solve(parts["LP"], Kus)
+    mean = tmp.T @ parts["c"]
+    var = float(np.sum([v for v, _ in thetas])) + np.sum(np.square(tmp), 0) - np.sum(np.linalg.solve(parts["Kuu"], Kus) * Kus, 0)
+    return mean, np.tile(var.reshape(-1, 1), (1, y.shape[1]))
+
+
+# --------------------------------------------------------------------------------------
 # Parameter transforms + L-BFGS-B driver (example.py:28-33; GPflow Scipy optimiser / softplus / 1e-6 shift)
 # --------------------------------------------------------------------------------------
 

@@ -657,3 +657,85 @@ def test_kron_fit_improves_bound(A):
     e1 = model.elbo().item()
     assert e1 > e0 + 1.0 and np.isfinite(e1)
     assert float(model.likelihood.variance) < 0.5      # started at 1.0, the data noise is 0.01
+
+
+# ------------------------------------------------------------------------------------------------ additive model
+def _additive_case(A, rng, N, specs):
+    d = len(specs)
+    X = rng.uniform(0.001, 0.999, (N, d))
+    y = (np.sin(6 * X[:, 0]) + (X[:, 1] ** 2 if d > 1 else 0) - (np.cos(5 * X[:, 2]) if d > 2 else 0)
+         + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    bases = [_mk_basis(A, o, 0, 1, m) for (o, m, _, _, _) in specs]
+    obases = [O.Basis(o, 0, 1, m) for (o, m, _, _, _) in specs]
+    kerns = [_kernel(A, kd, v, l) for (_, _, kd, v, l) in specs]
+    kinds = [kd for (_, _, kd, _, _) in specs]
+    thetas = [(v, l) for (_, _, _, v, l) in specs]
+    return X, y, bases, obases, kerns, kinds, thetas
+
+
+@pytest.mark.parametrize("specs,N", [([(3, 20, 1, 1.0, 0.3), (3, 24, 1, 0.8, 0.5), (3, 16, 0, 1.2, 0.4)], 3001),
+                                     ([(4, 30, 2, 0.9, 0.4), (4, 17, 1, 1.1, 0.6)], 5000),
+                                     ([(2, 12, 0, 1.0, 0.5), (2, 9, 1, 0.7, 0.3), (2, 10, 1, 1.0, 0.4), (2, 11, 0, 0.5, 0.8)], 800)])
+def test_additive_statistics_elbo_predict_vs_oracle(A, specs, N):
+    """GPR_additive (gpr.py:139-236): vstack'ed design matrix -> banded diagonal + dense cross blocks; bound and
+    posterior against the dense oracle."""
+    rng = np.random.default_rng(N)
+    X, y, bases, obases, kerns, kinds, thetas = _additive_case(A, rng, N, specs)
+    s = 0.05
+    model = A.GPR_additive((X, y), kerns, bases)
+    model.likelihood.variance.assign(s)
+    Aref, bref, yy = O.additive_stats(obases, X, y)
+    got = model.KufKfu.cpu().numpy()
+    assert got.shape == Aref.shape
+    assert np.max(np.abs(got - Aref)) <= 1e-12 * np.max(np.abs(Aref))
+    assert (got[Aref == 0] == 0).all()                      # outside the bands of the diagonal blocks
+    np.testing.assert_allclose(model.Kuf_y.cpu().numpy(), bref, rtol=0, atol=1e-12 * np.max(np.abs(bref)))
+    assert abs(model.tr_yTy.item() - yy) <= 1e-12 * yy
+    oe, _ = O.elbo_additive(obases, kinds, thetas, s, X, y)
+    e = model.elbo().item()
+    vs = sum(v for v, _ in thetas)
+    assert abs(e - oe) <= elbo_tol(oe, N, vs, s, yy), (e, oe)
+    assert abs(model.maximum_log_likelihood_objective().item() - e) == 0 and model.training_loss().item() == -e
+    Xs = rng.uniform(0.01, 0.99, (300, len(specs)))
+    om, ov = O.predict_f_additive(obases, kinds, thetas, s, X, y, Xs)
+    mean, var = model.predict_f(Xs)
+    assert mean.shape == (300, 1) and var.shape == (300, 1)
+    np.testing.assert_allclose(mean, om, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(var, ov, rtol=0, atol=1e-8)
+
+
+def test_additive_cross_block_beyond_lds_and_errors(A):
+    """m_i * m_j above the LDS image limit takes the L2-atomic path; the block equals Phi_i Phi_j^T either way."""
+    rng = np.random.default_rng(5)
+    N = 20000
+    X = rng.uniform(0.001, 0.999, (N, 2))
+    y = rng.normal(size=(N, 1))
+    bases = [A.B3Spline(0, 1, 150), A.B3Spline(0, 1, 140)]          # 21000 doubles > 160 KB
+    model = A.GPR_additive((X, y), [A.Matern32(), A.Matern32()], bases)
+    P0 = bases[0].evaluate_basis(dev(X[:, :1].copy()), sparse=False)
+    P1 = bases[1].evaluate_basis(dev(X[:, 1:].copy()), sparse=False)
+    C = (P0 @ P1.t()).cpu().numpy()
+    got = model.KufKfu.cpu().numpy()[:150, 150:]
+    assert np.max(np.abs(got - C)) <= 1e-12 * np.max(np.abs(C))
+    small = A.GPR_additive((X, y), [A.Matern32(), A.Matern32()], [A.B3Spline(0, 1, 50), A.B3Spline(0, 1, 40)])
+    Q0 = small.bases[0].evaluate_basis(dev(X[:, :1].copy()), sparse=False)
+    Q1 = small.bases[1].evaluate_basis(dev(X[:, 1:].copy()), sparse=False)
+    C2 = (Q0 @ Q1.t()).cpu().numpy()
+    assert np.max(np.abs(small.KufKfu.cpu().numpy()[:50, 50:] - C2)) <= 1e-12 * np.max(np.abs(C2))
+    with pytest.raises(AssertionError):
+        A.GPR_additive((X, y), [A.Matern32()], bases)                              # gpr.py:147
+    with pytest.raises(AssertionError):
+        A.GPR_additive((X, y), [A.Matern32(), A.Matern32()], [A.B3Spline(0, 1, 20), A.B2Spline(0, 1, 20)])   # gpr.py:165
+
+
+def test_additive_fit_improves_bound(A):
+    rng = np.random.default_rng(3)
+    N = 1200
+    X = rng.uniform(0.001, 0.999, (N, 2))
+    y = (np.sin(6 * X[:, :1]) + np.cos(4 * X[:, 1:]) + 0.1 * rng.normal(size=(N, 1)))
+    model = A.GPR_additive((X, y), [A.Matern32(), A.Matern32()], [A.B3Spline(0, 1, 14), A.B3Spline(0, 1, 15)])
+    e0 = model.elbo().item()
+    model.fit(maxiter=12)
+    e1 = model.elbo().item()
+    assert e1 > e0 + 1.0 and np.isfinite(e1)
+    assert float(model.likelihood.variance) < 0.5

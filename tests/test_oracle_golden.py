@@ -253,3 +253,24 @@ def test_kron_elbo_matches_direct_dense():
     sign, ld = np.linalg.slogdet(C)
     direct = -0.5 * (300 * np.log(2 * np.pi) + ld + float(y.T @ np.linalg.solve(C, y))) - 0.5 / s * (300 * 0.7 - np.trace(Qff))
     assert abs(e - direct) < 1e-8 * abs(direct)
+
+
+def test_additive_oracle_reduces_to_1d_model():
+    """gpr.py:139-236 with d = 1 is the 1-D model of gpr.py:19-136: same bound, same posterior (dense vs banded route)."""
+    rng = np.random.default_rng(2)
+    N = 400
+    X = rng.uniform(0.01, 0.99, (N, 1))
+    y = (np.sin(8 * X) + 0.1 * rng.normal(size=(N, 1)))
+    bs = O.Basis(3, 0, 1, 25)
+    v, l, s = 0.9, 0.3, 0.04
+    ea, parts = O.elbo_additive([bs], [1], [(v, l)], s, X, y)
+    Ab, b, yy = O.sufficient_stats_direct(bs, X[:, 0], y)
+    e1 = O.elbo_1d(O.make_Kuu(bs, 1, v, l), Ab, b, yy, N, v, s)
+    e1 = e1[0] if isinstance(e1, tuple) else e1
+    assert abs(ea - e1) <= 1e-9 * abs(e1)
+    assert np.max(np.abs(parts["A"] - O.band_to_dense_sym(Ab))) <= 1e-13 * np.max(np.abs(Ab))
+    xs = rng.uniform(0.05, 0.95, (50, 1))
+    ma, va = O.predict_f_additive([bs], [1], [(v, l)], s, X, y, xs)
+    m1, v1 = O.predict_f_1d(bs, 1, Ab, b, v, l, s, xs)
+    np.testing.assert_allclose(ma, m1, atol=1e-9)
+    np.testing.assert_allclose(va, v1, atol=1e-9)

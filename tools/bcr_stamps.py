@@ -1,6 +1,6 @@
 """Diagnostic: per-level cycle stamps of the two BCR chains (ASVGP_BCR_STAMPS=1)."""
 import os, sys
-os.environ["ASVGP_BCR_STAMPS"] = "1"
+os.environ["ASVGP_BCR_STAMPS"] = sys.argv[1] if len(sys.argv) > 1 else "1"   # 2 = stamp a second, warm pass
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import asvgp_amd as A
