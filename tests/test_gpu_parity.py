@@ -739,3 +739,26 @@ def test_additive_fit_improves_bound(A):
     e1 = model.elbo().item()
     assert e1 > e0 + 1.0 and np.isfinite(e1)
     assert float(model.likelihood.variance) < 0.5
+
+
+# ------------------------------------------------------------------------------------------------ experiment adapters
+def test_experiment_adapters_metrics_and_timing_rows(A):
+    """electricity.py:128-141 / eNATL60.py:82-123 scaffolding on synthetic stand-ins: metric definitions, timing keys."""
+    from asvgp_amd import experiments as E
+    from scipy.stats import norm
+    rng = np.random.default_rng(0)
+    t, m, v = rng.normal(size=50), rng.normal(size=50), rng.uniform(0.1, 2, 50)
+    assert abs(E.NLL(t, m, v) - float(np.mean(-norm.logpdf(t, loc=m, scale=np.sqrt(v))))) < 1e-12   # eNATL60.py:33-36
+    assert abs(E.MSE(t, m) - float(np.mean((t - m) ** 2))) < 1e-15
+    X = rng.uniform(0.001, 0.999, (6000, 1))
+    y = np.sin(12 * X) + 0.1 * rng.normal(size=X.shape)
+    Xtr, Xte, ytr, yte = E.train_test_split(X, y, test_size=0.05, random_state=1)
+    assert Xte.shape[0] == 300 and Xtr.shape[0] == 5700
+    r = E.run_band_gpr_1d(Xtr, ytr, Xte, yte, A.Matern52(), A.B3Spline(0, 1, 60), maxiter=60)
+    assert r["mse"] < 0.02 and r["nlpd"] < 0.0 and r["total_time"] >= r["opt_time"] > 0
+    Xk, yk = E.synthetic_ssh(5000)
+    rk = E.run_kron(Xk[:4500], yk[:4500], Xk[4500:], yk[4500:], [A.Matern32(), A.Matern32()],
+                    [A.B3Spline(-80, -25, 12), A.B3Spline(15, 55, 12)], maxiter=8, predict_chunk=200)
+    for key in ("num_train", "num_test", "spline_order", "time_precomp", "time_opt", "time_total", "nll", "mse", "GP"):
+        assert key in rk
+    assert rk["num_test"] == 500 and rk["spline_order"] == 3 and rk["mse"] < 0.05 and np.isfinite(rk["nll"])
