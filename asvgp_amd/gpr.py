@@ -386,6 +386,12 @@ class GPR_kron:
 
     predict_f_sparse = predict_f                              # gpr.py:336-359 computes the same moments with CHOLMOD
 
+    def predict_f_sparse(self, Xnew, full_cov=False, full_output_cov=False):
+        """gpr.py:336-359: the CHOLMOD route of the same posterior; here both entry points share the band solver.
+        Returns (mean (n,1), var (n,1))."""
+        mean, var = self.predict_f(Xnew, full_cov, full_output_cov)
+        return mean, var[:, :1]
+
     def predict_f_device(self, Xnew, chunk=4096):
         lib = get_lib()
         key = self.theta()

@@ -28,3 +28,47 @@ def make_kvs_sparse(bases, X):
     n = cols.shape[0] // (bases[0].order + 1) ** 2
     coo = torch.sparse_coo_tensor(torch.stack([rows, cols]), data, (bases[0].m * bases[1].m, n)).coalesce()
     return coo.to_sparse_csr()
+
+
+def _coo(A):
+    A = A.to_sparse_coo() if A.layout != torch.sparse_coo else A
+    return A.coalesce()
+
+
+def sparse_repeats(A, repeats):
+    """kronecker.py:7-15: every row r of A becomes rows r*repeats + i, i = 0..repeats-1 (torch sparse in / CSR out)."""
+    A = _coo(A)
+    r, c = A.indices()
+    i = torch.arange(repeats, device=r.device).repeat_interleave(r.shape[0])
+    rows = i + r.repeat(repeats) * repeats
+    out = torch.sparse_coo_tensor(torch.stack([rows, c.repeat(repeats)]), A.values().repeat(repeats),
+                                  (repeats * A.shape[0], A.shape[1]))
+    return out.coalesce().to_sparse_csr()
+
+
+def sparse_tile(A, repeats):
+    """kronecker.py:17-25: A stacked `repeats` times."""
+    A = _coo(A)
+    r, c = A.indices()
+    i = torch.arange(repeats, device=r.device).repeat_interleave(r.shape[0])
+    rows = r.repeat(repeats) + i * A.shape[0]
+    out = torch.sparse_coo_tensor(torch.stack([rows, c.repeat(repeats)]), A.values().repeat(repeats),
+                                  (repeats * A.shape[0], A.shape[1]))
+    return out.coalesce().to_sparse_csr()
+
+
+def make_kvs_two_sparse(A, B):
+    """kronecker.py:27-30: column-wise Kronecker product of two sparse design matrices (generic route; the fused kernel
+    behind make_kvs_sparse(bases, X) is what the model uses)."""
+    M1 = sparse_repeats(A, B.shape[0]).to_dense()
+    M2 = sparse_tile(B, A.shape[0]).to_dense()
+    return (M1 * M2).to_sparse_csr()
+
+
+def kron_log_determinant(Kuu, M, d):
+    """kronecker.py:35-40: log|K_1 (x) ... (x) K_d| = sum_i (M^d / M) log|K_i| with equal sizes M (the reference
+    multiplies by the whole list N instead of its element n - unused there; the intended formula is implemented)."""
+    from . import banded
+    L = [banded.cholesky_band(kuu) for kuu in Kuu]
+    logdets = [torch.log(l[0, :] ** 2).sum() for l in L]
+    return sum((float(M) ** d / float(M)) * ld for ld in logdets)

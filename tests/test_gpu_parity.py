@@ -762,3 +762,46 @@ def test_experiment_adapters_metrics_and_timing_rows(A):
     for key in ("num_train", "num_test", "spline_order", "time_precomp", "time_opt", "time_total", "nll", "mse", "GP"):
         assert key in rk
     assert rk["num_test"] == 500 and rk["spline_order"] == 3 and rk["mse"] < 0.05 and np.isfinite(rk["nll"])
+
+
+def test_utils_and_kronecker_helper_mirrors(A):
+    """utils.py:35-57 and kronecker.py:7-40 helper functions (drop-in completeness): dense / sparse Kronecker forms."""
+    from asvgp_amd import kronecker as KR, utils as U
+    b1, b2 = A.B3Spline(0, 1, 9), A.B3Spline(0, 1, 9)
+    k1, k2 = A.Matern32(variance=0.9, lengthscales=0.4), A.Matern32(variance=1.1, lengthscales=0.3)
+    K1 = A.SplineFeatures1D(k1, b1).make_Kuu(k1)
+    K2 = A.SplineFeatures1D(k2, b2).make_Kuu(k2)
+    o1, o2 = O.Basis(3, 0, 1, 9), O.Basis(3, 0, 1, 9)
+    D1 = O.band_to_dense_sym(O.make_Kuu(o1, 1, 0.9, 0.4))
+    D2 = O.band_to_dense_sym(O.make_Kuu(o2, 1, 1.1, 0.3))
+    Kd, Ld = U.bands_to_kron_cholesky([K1, K2], 3)
+    ref = np.kron(D1, D2)
+    np.testing.assert_allclose(Kd.cpu().numpy(), ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    refL = np.kron(np.linalg.cholesky(D1), np.linalg.cholesky(D2))
+    np.testing.assert_allclose(Ld.cpu().numpy(), refL, rtol=1e-9, atol=1e-9 * np.abs(refL).max())
+    np.testing.assert_allclose(U.bands_to_sparse([K1, K2], 3).to_dense().cpu().numpy(), ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    ld = KR.kron_log_determinant([K1, K2], 9, 2).item()
+    assert abs(ld - np.linalg.slogdet(ref)[1]) <= 1e-9 * abs(ld)
+    tfb = U.band_to_tfband(K1).cpu().numpy()                   # row r holds super-diagonal r, left-padded by r
+    for r in range(4):
+        np.testing.assert_allclose(tfb[r, r:], np.diagonal(D1, r), rtol=1e-14)
+    kb = U.band_to_kron_band([K1, K2], 3).cpu().numpy()
+    refkb = O.pack_dense_matrix_to_banded(np.kron(np.tril(D1), np.tril(D2)), 3, 0)
+    np.testing.assert_allclose(kb, refkb, rtol=1e-13, atol=1e-13 * np.abs(refkb).max())
+    # generic sparse Khatri-Rao route == fused kernel == reference fixture semantics (row i1*m2 + i2)
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0.01, 0.99, (40, 2))
+    P1 = b1.evaluate_basis(dev(X[:, :1].copy()))
+    P2 = b2.evaluate_basis(dev(X[:, 1:].copy()))
+    generic = KR.make_kvs_two_sparse(P1, P2).to_dense().cpu().numpy()
+    fused = KR.make_kvs_sparse([b1, b2], dev(X)).to_dense().cpu().numpy()
+    np.testing.assert_allclose(generic, fused, rtol=1e-14, atol=1e-16)
+    rep = KR.sparse_repeats(P1, 3).to_dense().cpu().numpy()
+    np.testing.assert_array_equal(rep, np.repeat(P1.to_dense().cpu().numpy(), 3, axis=0))
+    til = KR.sparse_tile(P1, 3).to_dense().cpu().numpy()
+    np.testing.assert_array_equal(til, np.tile(P1.to_dense().cpu().numpy(), (3, 1)))
+    model = A.GPR_kron((X, np.sin(5 * X[:, :1])), [k1, k2], [b1, b2])
+    m1, v1 = model.predict_f(X[:7])
+    m2, v2 = model.predict_f_sparse(X[:7])
+    np.testing.assert_array_equal(m1, m2)
+    assert v2.shape == (7, 1) and np.array_equal(v1[:, :1], v2)
