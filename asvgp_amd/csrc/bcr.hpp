@@ -82,15 +82,22 @@ __device__ __forceinline__ void blk_solve_LT(const T (&L)[B][B], const T (&invd)
 // LDS: struct-of-arrays with a COMPILE-TIME slot count NS, so (field * NS + slot) * 8 folds into the ds_read/ds_write
 // immediate offset; Dual keeps value and tangent planes apart (every access 8 B / lane, conflict-free).
 template <typename T, int NS> struct Soa;
+// D fields (diagonal blocks) always live in the LDS; the E fields (couplings) do too, except in the BIG layout (twice
+// the node count: M up to 4096 at k = 4) where they move to an L2-resident global plane and every barrier becomes a
+// full __syncthreads().  Field indices are relative to the D / E plane.
 template <int NS> struct Soa<double, NS> {
-  double* p;
-  __device__ __forceinline__ double get(int f, int s) const { return p[f * NS + s]; }
-  __device__ __forceinline__ void set(int f, int s, double v) const { p[f * NS + s] = v; }
+  double* p; double* pe;
+  __device__ __forceinline__ double getD(int f, int s) const { return p[f * NS + s]; }
+  __device__ __forceinline__ void setD(int f, int s, double v) const { p[f * NS + s] = v; }
+  __device__ __forceinline__ double getE(int f, int s) const { return pe[f * NS + s]; }
+  __device__ __forceinline__ void setE(int f, int s, double v) const { pe[f * NS + s] = v; }
 };
 template <int NS> struct Soa<Dual, NS> {
-  double* p; double* q;  // q = tangent plane
-  __device__ __forceinline__ Dual get(int f, int s) const { return {p[f * NS + s], q[f * NS + s]}; }
-  __device__ __forceinline__ void set(int f, int s, Dual v) const { p[f * NS + s] = v.v; q[f * NS + s] = v.d; }
+  double* p; double* q; double* pe; double* qe;  // q = tangent plane
+  __device__ __forceinline__ Dual getD(int f, int s) const { return {p[f * NS + s], q[f * NS + s]}; }
+  __device__ __forceinline__ void setD(int f, int s, Dual v) const { p[f * NS + s] = v.v; q[f * NS + s] = v.d; }
+  __device__ __forceinline__ Dual getE(int f, int s) const { return {pe[f * NS + s], qe[f * NS + s]}; }
+  __device__ __forceinline__ void setE(int f, int s, Dual v) const { pe[f * NS + s] = v.v; qe[f * NS + s] = v.d; }
 };
 // global workspace: struct-of-arrays over nodes with a compile-time node stride (coalesced across the lanes of a level,
 // field offsets are constants added on the scalar unit); `Rec` is the view of one node.
@@ -117,20 +124,26 @@ template <int B, int NRHS> struct BcrLayout {
 };
 template <typename T> __host__ __device__ constexpr int planes_of() { return sizeof(T) / sizeof(double); }
 
-// slots held in LDS: the largest power of two whose survivor image (+ the rhs vector) fits in ~150 KB
-template <typename T, int B> __host__ __device__ constexpr int bcr_ns() {
+// slots held in LDS: the largest power of two whose survivor image (+ the rhs vector) fits in ~150 KB; the BIG layout
+// doubles it by keeping only the D fields there.
+template <typename T, int B, bool BIG = false> __host__ __device__ constexpr int bcr_ns() {
   int ns = 1024;
   while ((long)planes_of<T>() * 2 * B * B * ns * 8 + (long)2 * ns * B * 8 + 1024 > 150 * 1024) ns >>= 1;
-  return ns;
+  return BIG ? 2 * ns : ns;
 }
-template <typename T, int B, int NRHS>
+template <typename T, int B, int NRHS, bool BIG = false>
 __host__ __device__ inline size_t bcr_lds_doubles(long nb) {
-  if ((nb + 1) / 2 > bcr_ns<T, B>()) return (size_t)1 << 40;  // does not fit: callers fall back to the sweeps
-  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::F_N * bcr_ns<T, B>() + (size_t)nb * B + 64;
+  if ((nb + 1) / 2 > bcr_ns<T, B, BIG>()) return (size_t)1 << 40;  // does not fit: callers fall back
+  const size_t fields = BIG ? (size_t)B * B : (size_t)BcrLayout<B, NRHS>::F_N;
+  return (size_t)planes_of<T>() * fields * bcr_ns<T, B, BIG>() + (NRHS || !BIG ? (size_t)nb * B : 0) + 64;
 }
-template <typename T, int B, int NRHS>
+template <typename T, int B, int NRHS, bool BIG = false>
 __host__ __device__ inline size_t bcr_ws_doubles(long) {
-  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::W_N * 2 * bcr_ns<T, B>();
+  return (size_t)planes_of<T>() * BcrLayout<B, NRHS>::W_N * 2 * bcr_ns<T, B, BIG>() +
+         (BIG ? (size_t)planes_of<T>() * B * B * bcr_ns<T, B, BIG>() : 0);   // + the global E plane
+}
+template <bool BIG> __device__ __forceinline__ void bcr_barrier() {
+  if constexpr (BIG) __syncthreads(); else bcr_lds_barrier();
 }
 
 // block extraction from the lower band (B+1, M): D_n (lower part) and E(n) = A[n+1, n] (upper-triangular block)
@@ -162,19 +175,29 @@ __device__ __forceinline__ T band_E(const Src& A, int M, int n, int r, int c) { 
 //   A: lower band (B+1, M);  rhs: (M) or null (NRHS = 0);  ws: bcr_ws_doubles;  lds: bcr_lds_doubles
 //   out: S lower band of A^-1 (B+1, M), x = A^-1 rhs (M), logdet (1), info (first bad column + 1)
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int B, int NRHS, typename Src = BandPtr<T>>
+template <typename T, int B, int NRHS, typename Src = BandPtr<T>, bool BIG = false>
 __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
                           double* logdet, int* info, double* stamps = nullptr) {
   using N = Num<T>;
   using Lay = BcrLayout<B, NRHS>;
   const int tid = threadIdx.x;
   const int nb = (M + B - 1) / B;
-  constexpr int NS = bcr_ns<T, B>();
+  constexpr int NS = bcr_ns<T, B, BIG>();
+  constexpr int NN0 = 2 * NS;
   Soa<T, NS> F;                                                               // survivors: D | E
   F.p = lds;
-  if constexpr (planes_of<T>() == 2) F.q = lds + (size_t)Lay::F_N * NS;
-  double* xs = lds + (size_t)planes_of<T>() * Lay::F_N * NS;                  // y / z / x per row in LDS
-  double* red = xs + (size_t)nb * B;                                          // 64 doubles scratch
+  double* xs;                                                                 // y / z / x per row in LDS
+  if constexpr (BIG) {
+    double* eg = ws + (size_t)planes_of<T>() * Lay::W_N * NN0;                // global E plane(s) behind the factor records
+    F.pe = eg;
+    if constexpr (planes_of<T>() == 2) { F.q = lds + (size_t)B * B * NS; F.qe = eg + (size_t)B * B * NS; }
+    xs = lds + (size_t)planes_of<T>() * B * B * NS;
+  } else {
+    F.pe = lds + (size_t)Lay::F_E * NS;
+    if constexpr (planes_of<T>() == 2) { F.q = lds + (size_t)Lay::F_N * NS; F.qe = F.q + (size_t)Lay::F_E * NS; }
+    xs = lds + (size_t)planes_of<T>() * Lay::F_N * NS;
+  }
+  double* red = xs + ((NRHS || !BIG) ? (size_t)nb * B : 0);                   // 64 doubles scratch
   constexpr int NN = 2 * NS;                                                  // node stride of the workspace arrays
   auto Wn = [&](int node) -> Rec<T, NN> {
     Rec<T, NN> rec;
@@ -218,8 +241,8 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
     for (int r = 0; r < B; ++r)
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
-        F.set(Lay::F_D + r * B + c, s, tmp[e]);
-        if (c != r) F.set(Lay::F_D + c * B + r, s, tmp[e]);
+        F.setD(r * B + c, s, tmp[e]);
+        if (c != r) F.setD(c * B + r, s, tmp[e]);
         ++e;
       }
   }
@@ -251,9 +274,9 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
             ua = band_E<T, B, Src>(A, M, a, r, c);
             ub = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();   // A[i,b] = E(i)^T
           } else {
-            d = F.get(Lay::F_D + e, i >> 1);
-            ua = F.get(Lay::F_E + e, a >> 1);
-            ub = hasb ? F.get(Lay::F_E + c * B + r, i >> 1) : N::zero();
+            d = F.getD(e, i >> 1);
+            ua = F.getE(e, a >> 1);
+            ub = hasb ? F.getE(c * B + r, i >> 1) : N::zero();
           }
           if (NRHS && c == 0) z = xs[i * B + r];
         }
@@ -315,18 +338,18 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           if (NRHS && c == 0) xs[i * B + r] = z;
           // phase A: left neighbour
           const int sa = a >> 1;
-          F.set(Lay::F_D + e, sa, F.get(Lay::F_D + e, sa) - upd_a);
-          F.set(Lay::F_E + e, sa, enew);
+          F.setD(e, sa, F.getD(e, sa) - upd_a);
+          F.setE(e, sa, enew);
           if (NRHS && c == 0) xs[a * B + r] -= ya_upd;
         }
       }
-      bcr_lds_barrier();
+      bcr_barrier<BIG>();
       if (hasb && lane_on) {  // phase B: right neighbour
         const int sb = b >> 1;
-        F.set(Lay::F_D + e, sb, F.get(Lay::F_D + e, sb) - upd_b);
+        F.setD(e, sb, F.getD(e, sb) - upd_b);
         if (NRHS && c == 0) xs[b * B + r] -= yb_upd;
       }
-      bcr_lds_barrier();
+      bcr_barrier<BIG>();
       }
       stamp();
       continue;
@@ -349,9 +372,9 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
               Ua[r][c] = band_E<T, B, Src>(A, M, a, r, c);
               Ub[r][c] = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
             } else {
-              D[r][c] = (c <= r) ? F.get(Lay::F_D + r * B + c, i >> 1) : N::zero();
-              Ua[r][c] = F.get(Lay::F_E + r * B + c, a >> 1);
-              Ub[r][c] = hasb ? F.get(Lay::F_E + c * B + r, i >> 1) : N::zero();
+              D[r][c] = (c <= r) ? F.getD(r * B + c, i >> 1) : N::zero();
+              Ua[r][c] = F.getE(r * B + c, a >> 1);
+              Ub[r][c] = hasb ? F.getE(c * B + r, i >> 1) : N::zero();
             }
           }
         blk_chol<T, B>(D, invd, bad, i * B);
@@ -387,11 +410,11 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
         for (int r = 0; r < B; ++r)
 #pragma unroll
           for (int c = 0; c <= r; ++c) {  // D_a -= Ua^T Ua (symmetric, keep both halves)
-            T t = F.get(Lay::F_D + r * B + c, sa);
+            T t = F.getD(r * B + c, sa);
 #pragma unroll
             for (int p = 0; p < B; ++p) t = N::nfma(Ua[p][r], Ua[p][c], t);
-            F.set(Lay::F_D + r * B + c, sa, t);
-            if (c != r) F.set(Lay::F_D + c * B + r, sa, t);
+            F.setD(r * B + c, sa, t);
+            if (c != r) F.setD(c * B + r, sa, t);
           }
 #pragma unroll
         for (int r = 0; r < B; ++r)
@@ -400,7 +423,7 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
             T t = N::zero();
 #pragma unroll
             for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ua[p][c], t);
-            F.set(Lay::F_E + r * B + c, sa, t);
+            F.setE(r * B + c, sa, t);
           }
         if (NRHS) {
 #pragma unroll
@@ -412,18 +435,18 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           }
         }
       }
-      bcr_lds_barrier();
+      bcr_barrier<BIG>();
       if (hasb) {  // phase B: right neighbour b
         const int sb = b >> 1;
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
           for (int c = 0; c <= r; ++c) {
-            T t = F.get(Lay::F_D + r * B + c, sb);
+            T t = F.getD(r * B + c, sb);
 #pragma unroll
             for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ub[p][c], t);
-            F.set(Lay::F_D + r * B + c, sb, t);
-            if (c != r) F.set(Lay::F_D + c * B + r, sb, t);
+            F.setD(r * B + c, sb, t);
+            if (c != r) F.setD(c * B + r, sb, t);
           }
         if (NRHS) {
 #pragma unroll
@@ -435,14 +458,14 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           }
         }
       }
-      bcr_lds_barrier();
+      bcr_barrier<BIG>();
     }
     stamp();
   }
 
   // ---------------- root (node 0): lane-distributed, group 0 ----------------
   if (grp == 0) {
-    T d = lane_on ? F.get(Lay::F_D + e, 0) : N::zero();
+    T d = lane_on ? F.getD(e, 0) : N::zero();
     T invd[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) {

@@ -17,15 +17,67 @@ namespace asvgp {
 
 // optional fine-grained ordering between the prior chain (stream A) and the data chain (stream B), owned by the library:
 // evK = Kuu assembled (the P chain may start), evP = prior chain complete (the finalize may start).
-static bool g_sync_on = false;
-static hipEvent_t g_evK = nullptr, g_evP = nullptr;
-
-static int g_band_algo = 0;  // 0 auto (= 2 when it fits the LDS), 1 sequential sweeps, 2 hybrid BCR (one thread per node on
+// (elbo.hip is compiled once per bandwidth with -DASVGP_ELBO_ONLY_K=k - those units hold the template instantiations -
+// and once without: the C entry points and the process-wide state.  asvgp_amd/build.py runs the units in parallel.)
+#ifdef ASVGP_ELBO_ONLY_K
+extern bool g_sync_on;
+extern hipEvent_t g_evK, g_evP;
+extern int g_band_algo;
+#else
+bool g_sync_on = false;
+hipEvent_t g_evK = nullptr, g_evP = nullptr;
+int g_band_algo = 0;
+#endif
+                             // 0 auto (= 2 when it fits the LDS), 1 sequential sweeps, 2 hybrid BCR (one thread per node on
                              // wide levels, lane-distributed on narrow levels), 3 fully lane-distributed BCR
 
+struct Ws {
+  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha, *logdets, *fin, *bcrK, *bcrP;
+};
+// factor workspaces of the two BCR chains (bcr_ws_doubles, normal or BIG layout - whichever is larger)
+static size_t bcr_ws_chain(int planes, int k, bool big) {
+  long ns = 1024;
+  while ((long)planes * 2 * k * k * ns * 8 + 2 * ns * k * 8 + 1024 > 150 * 1024) ns >>= 1;
+  if (big) ns *= 2;
+  return (size_t)planes * (7 * k * k + k) * 2 * ns + (big ? (size_t)planes * k * k * ns : 0);
+}
+static size_t bcr_ws_K(int k) { size_t a = bcr_ws_chain(2, k, false), b = bcr_ws_chain(2, k, true); return (a > b ? a : b) + 64; }
+static size_t bcr_ws_P(int k) { size_t a = bcr_ws_chain(1, k, false), b = bcr_ws_chain(1, k, true); return (a > b ? a : b) + 64; }
+static size_t bcr_ws_total(long M, int k) {
+  (void)M;
+  return bcr_ws_K(k) + bcr_ws_P(k);
+}
+static size_t ws_doubles(long M, int k, long D) {
+  return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64 + 32 + bcr_ws_total(M, k);
+}
+static Ws carve(void* ws, long M, int k, long D) {
+  double* p = static_cast<double*>(ws);
+  size_t E = (size_t)(k + 1) * M;
+  Ws w;
+  w.Kuu = p; p += E; w.dK = p; p += E; w.P = p; p += E; w.LK = p; p += E; w.dLK = p; p += E;
+  w.LP = p; p += E; w.SK = p; p += E; w.dSK = p; p += E; w.SP = p; p += E;
+  w.c = p; p += (size_t)M * D; w.alpha = p; p += (size_t)M * D;
+  w.logdets = p; p += 64;
+  w.fin = p; p += 32;   // 14 partial-sum slots + the arrival ticket of elbo_finalize_kernel (zero between calls)
+  w.bcrK = p; p += bcr_ws_K(k);
+  w.bcrP = p;
+  return w;
+}
+
+// launchers: declared for every unit, defined (and explicitly instantiated) only in the per-bandwidth units
+template <int K> struct ElboLauncher {
+  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
+                 double* out, int* info, void* ws, hipStream_t st, int part);
+};
+template <int K> struct PostLauncher {
+  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+                 double* alpha, double* W, int* info, void* ws, hipStream_t st);
+};
+
+#ifdef ASVGP_ELBO_ONLY_K
 struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]; int n; };
 
-__global__ void elbo_prepare_kernel(const double* __restrict__ S, KuuCoefs2 cf, long E, const double* __restrict__ A,
+static __global__ void elbo_prepare_kernel(const double* __restrict__ S, KuuCoefs2 cf, long E, const double* __restrict__ A,
                                     double s, double* __restrict__ Kuu, double* __restrict__ dK,
                                     double* __restrict__ P) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +128,7 @@ __global__ __launch_bounds__(64) void elbo_trsv_kernel(const double* L, int M, c
 }
 
 // Both chains by block cyclic reduction, one 256-thread workgroup each (bcr.hpp).
-template <int K, bool TANGENT>
+template <int K, bool TANGENT, bool BIG>
 __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu, const double* dK, const double* P,
                                                                const double* b, int M, double* wsK, double* wsP,
                                                                double* SK, double* dSK, double* SP, double* x,
@@ -87,12 +139,12 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu
   // do_stamps == 2 (diagnostic): run the solve twice and stamp the second, warm, pass (instruction cache / TLB effects)
   for (int rep = (do_stamps == 2) ? 0 : 1; rep < 2; ++rep) {
     if (blockIdx.x + first_chain == 0) {
-      if (TANGENT) bcr_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
-      else bcr_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
+      if (TANGENT) bcr_solve<Dual, K, 0, BandPtr<Dual>, BIG>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
+      else bcr_solve<double, K, 0, BandPtr<double>, BIG>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
     } else if (pfly_s > 0.0) {   // P = A/s + Kuu formed inside the gathers (P then points at A = the statistics band)
-      bcr_solve<double, K, 1, BandSumP>(BandSumP{P, Kuu, pfly_s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
+      bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{P, Kuu, pfly_s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
     } else {
-      bcr_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
+      bcr_solve<double, K, 1, BandPtr<double>, BIG>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
     }
     __syncthreads();
   }
@@ -243,38 +295,14 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
   }
 }
 
-__global__ void scale_sub_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
+static __global__ void scale_sub_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
                                  long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] - b[i];
 }
-__global__ void scale_kernel(double* __restrict__ x, double f, long n) {
+static __global__ void scale_kernel(double* __restrict__ x, double f, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = x[i] * f;
-}
-
-struct Ws {
-  double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha, *logdets, *fin, *bcrK, *bcrP;
-};
-static size_t bcr_ws_total(long M, int k) {  // factor workspaces of both chains (Dual + double), fixed node stride
-  (void)M;
-  return (size_t)3 * (7 * k * k + k) * 2048 + 64;
-}
-static size_t ws_doubles(long M, int k, long D) {
-  return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64 + 32 + bcr_ws_total(M, k);
-}
-static Ws carve(void* ws, long M, int k, long D) {
-  double* p = static_cast<double*>(ws);
-  size_t E = (size_t)(k + 1) * M;
-  Ws w;
-  w.Kuu = p; p += E; w.dK = p; p += E; w.P = p; p += E; w.LK = p; p += E; w.dLK = p; p += E;
-  w.LP = p; p += E; w.SK = p; p += E; w.dSK = p; p += E; w.SP = p; p += E;
-  w.c = p; p += (size_t)M * D; w.alpha = p; p += (size_t)M * D;
-  w.logdets = p; p += 64;
-  w.fin = p; p += 32;   // 14 partial-sum slots + the arrival ticket of elbo_finalize_kernel (zero between calls)
-  w.bcrK = p; p += (size_t)2 * (7 * k * k + k) * 2048;
-  w.bcrP = p;
-  return w;
 }
 
 template <int K, bool TANGENT>
@@ -291,7 +319,15 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   size_t ldsK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0>(nb) : bcr_lds_doubles<double, K, 0>(nb));
   size_t ldsP = sizeof(double) * bcr_lds_doubles<double, K, 1>(nb);
   size_t lds_bytes = ldsK > ldsP ? ldsK : ldsP;
-  const bool fits = lds_bytes <= 160 * 1024 - 256;
+  bool fits = lds_bytes <= 160 * 1024 - 256;
+  bool big = false;   // BIG layout (bcr.hpp): twice the nodes, couplings in an L2-resident plane - M up to 4096 at k = 4
+  constexpr bool HAS_BIG = (K <= 5);   // (the k = 6 BIG instantiation alone costs ~5 minutes of compile time)
+  if (HAS_BIG && !fits && g_band_algo != 3) {
+    size_t bK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0, true>(nb) : bcr_lds_doubles<double, K, 0, true>(nb));
+    size_t bP = sizeof(double) * bcr_lds_doubles<double, K, 1, true>(nb);
+    size_t bb = bK > bP ? bK : bP;
+    if (bb <= 160 * 1024 - 256) { big = true; fits = true; lds_bytes = bb; }
+  }
   use_bcr = (D == 1) && (g_band_algo == 2 || g_band_algo == 3 || (g_band_algo == 0 && fits));
   const bool lane16 = (g_band_algo == 3);   // auto = hybrid BCR (bcr.hpp: thread-per-node wide levels, lane-distributed narrow levels)
   if (part != 0 && !use_bcr) {   // split scheduling exists for the BCR path only: the sweeps run as one unit in the data call
@@ -308,16 +344,18 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   if (use_bcr) {
     if (!fits) { set_error("BCR forced but needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
     hipError_t e = lane16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_bcr16_kernel<K, TANGENT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                          : hipFuncSetAttribute(big ? reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT, HAS_BIG>) : reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     if (lane16)
       hipLaunchKernelGGL((elbo_bcr16_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR16_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
                          getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0);
-    else
-      hipLaunchKernelGGL((elbo_bcr_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
+    else {
+      auto kern = big ? elbo_bcr_kernel<K, TANGENT, HAS_BIG> : elbo_bcr_kernel<K, TANGENT, false>;
+      hipLaunchKernelGGL(kern, dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          pfly ? A : w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
                          getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, pfly ? s : 0.0);
+    }
     if (part == 1) {
       if (g_sync_on) (void)hipEventRecord(g_evP, st);
       return check_launch("elbo prior chain");
@@ -343,9 +381,10 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   return check_launch("elbo chains");
 }
 
-template <int K> struct ElboLauncher {
-  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
-                 double* out, int* info, void* ws, hipStream_t st, int part) {
+template <int K>
+int ElboLauncher<K>::run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
+                         double* out, int* info, void* ws, hipStream_t st, int part) {
+  {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
     int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false);
@@ -358,10 +397,11 @@ template <int K> struct ElboLauncher {
                        bcr ? 1.0 / s : 1.0, w.fin, reinterpret_cast<unsigned*>(w.fin + 16), out);
     return check_launch("elbo_grad_1d");
   }
-};
-template <int K> struct PostLauncher {
-  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
-                 double* alpha, double* W, int* info, void* ws, hipStream_t st) {
+}
+template <int K>
+int PostLauncher<K>::run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+                         double* alpha, double* W, int* info, void* ws, hipStream_t st) {
+  {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
     int rc = run_chains<K, false>(stats, S, kind, v, l, s, M, D, w, info, st, bcr);
@@ -372,10 +412,21 @@ template <int K> struct PostLauncher {
     if (e != hipSuccess) { set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
     return check_launch("posterior_prepare_1d");
   }
-};
+}
+
+
+// ASVGP_ELBO_PART: 1 = ELBO + gradient launcher (tangent chains), 2 = posterior launcher, unset = both
+#if !defined(ASVGP_ELBO_PART) || ASVGP_ELBO_PART == 1
+template struct ElboLauncher<ASVGP_ELBO_ONLY_K>;
+#endif
+#if !defined(ASVGP_ELBO_PART) || ASVGP_ELBO_PART == 2
+template struct PostLauncher<ASVGP_ELBO_ONLY_K>;
+#endif
+#endif  // ASVGP_ELBO_ONLY_K
 
 }  // namespace asvgp
 
+#ifndef ASVGP_ELBO_ONLY_K
 using namespace asvgp;
 
 extern "C" int asvgp_set_band_algorithm(int algo) {
@@ -468,3 +519,5 @@ extern "C" int asvgp_posterior_prepare_1d(const double* stats, const double* sta
 #undef POST_CASE
   return ASVGP_ERR_UNSUPPORTED;
 }
+
+#endif  // !ASVGP_ELBO_ONLY_K

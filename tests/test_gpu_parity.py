@@ -413,7 +413,9 @@ def kuu_cond(ob, kd, v, l):
 @pytest.mark.parametrize("order,M,kd,l", [(1, 37, 0, 0.08), (2, 64, 1, 0.08), (3, 100, 1, 0.08), (4, 256, 2, 0.08),
                                           (4, 255, 1, 0.08), (4, 13, 0, 0.3), (5, 129, 2, 0.05), (6, 90, 1, 0.08),
                                           (4, 2048, 1, 0.003), (3, 1000, 2, 0.006),     # well conditioned (l ~ 6 delta)
-                                          (4, 2048, 1, 0.05), (3, 1000, 2, 0.08)])      # BASELINE-like, cond(Kuu) >> 1e8
+                                          (4, 2048, 1, 0.05), (3, 1000, 2, 0.08),       # BASELINE-like, cond(Kuu) >> 1e8
+                                          (4, 4096, 2, 0.002), (4, 4096, 1, 0.004), (3, 3000, 0, 0.01),   # BIG BCR layout (config 3 shape)
+                                          (5, 2500, 2, 0.006)])
 def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd, l):
     """The O(log M) block-cyclic-reduction band solver and the sequential column sweeps are two evaluation orders of
     the same factorisation: ELBO, gradient and posterior must agree with each other and with the oracle, to the
@@ -432,11 +434,17 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
         for algo in (1, 2, 3):
             A.set_band_algorithm(algo)
             model._post = None
-            r = model.elbo_and_grad().cpu().numpy()
+            try:
+                r = model.elbo_and_grad().cpu().numpy()
+            except RuntimeError:
+                if algo == 3 and M > 2048:      # the fully lane-distributed variant has no BIG (M > 2048) layout
+                    continue
+                raise
             mean, var = model.predict_f(xs)
             res[algo] = (r, mean, var)
     finally:
         A.set_band_algorithm(0)
+    assert 1 in res and 2 in res
     ob = O.Basis(order, 0, 1, M)
     Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
     oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, N, v, l, s)
@@ -444,7 +452,7 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
     cond = kuu_cond(ob, kd, v, l)
     big = 0.5 * N * v / s + 0.5 * yy / s
     eps_c = 2.2e-16 * cond                       # what fp64 can resolve of the cancelling O(N v / s) terms
-    for algo in (1, 2, 3):
+    for algo in sorted(res):
         r, mean, var = res[algo]
         tol = elbo_tol(oe, N, v, s, yy, bcr=(algo != 1)) + eps_c * big
         assert abs(r[0] - oe) <= tol, (algo, r[0], oe, cond)
@@ -454,7 +462,8 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
         np.testing.assert_allclose(mean, om, rtol=0, atol=pt)
         np.testing.assert_allclose(var, ov, rtol=0, atol=pt)
     assert abs(res[1][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
-    assert abs(res[3][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
+    if 3 in res:
+        assert abs(res[3][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
 
 
 @pytest.mark.parametrize("order,M,N,sort", [(1, 16, 5000, False), (2, 33, 7001, False), (3, 100, 20000, True), (4, 64, 20000, False),
