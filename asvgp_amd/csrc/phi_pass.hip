@@ -70,12 +70,29 @@ __device__ __forceinline__ unsigned long long wave_sum_dpp_u64(unsigned long lon
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Phi y in fixed point too: the scale follows the data - y0 = 2^E bounds |y| over the workgroup's first tile (x4 margin);
+// a later point with |y| > y0 (or NaN) takes the fp64 atomic path into a second rhs plane, so the result never depends
+// on the guess.  chi_r: magic-constant high word for the scale 2^(s0 - E).
+struct FxParams { int s0; int chi_r; double y0; };
+
 template <int K, bool FX>
-__device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int ncols, bool do_band, double* band, double* rhs, int s0) {
+__device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int ncols, bool do_band, double* band, double* rhs, FxParams fx) {
+  const int s0 = fx.s0;
   double v[K + 1];
   bspline_pieces<K>(t, v);
+  if (FX) {
+    if (fabs(yv) <= fx.y0) {
 #pragma unroll
-  for (int i = 0; i <= K; ++i) lds_add(rhs + cb + K - i, v[i] * yv);
+      for (int i = 0; i <= K; ++i)
+        lds_add_u64(reinterpret_cast<unsigned long long*>(rhs) + cb + K - i, fx_convert(v[i] * yv, fx.chi_r));
+    } else {
+#pragma unroll
+      for (int i = 0; i <= K; ++i) lds_add(rhs + ncols + cb + K - i, v[i] * yv);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i <= K; ++i) lds_add(rhs + cb + K - i, v[i] * yv);
+  }
   if (do_band) {
 #pragma unroll
     for (int i = 0; i <= K; ++i)
@@ -95,7 +112,8 @@ __device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int nco
 template <int K, int NP, bool FX>
 __device__ __forceinline__ void phi_points(const double (&xv)[NP], const double (&yv)[NP], bool valid, const double* mesh,
                                            int n_mesh, double m0, double inv_delta, int cell0, int cell1, int ncols,
-                                           bool do_band, double* band, double* rhs, double& yy, int s0) {
+                                           bool do_band, double* band, double* rhs, double& yy, FxParams fx) {
+  const int s0 = fx.s0;
   int idx[NP];
   bool in[NP];
   bool all_in = true;
@@ -135,7 +153,7 @@ __device__ __forceinline__ void phi_points(const double (&xv)[NP], const double 
 #pragma unroll
     for (int i = 0; i <= K; ++i) {
       double r = wave_sum_dpp(accr[i]);
-      if (commit) lds_add(rhs + cb + K - i, r);
+      if (commit) lds_add(rhs + (FX ? ncols : 0) + cb + K - i, r);   // (fp64 plane: a wave sum is not bounded by y0)
 #pragma unroll
       for (int j = i; j <= K; ++j) {
         if (do_band) {
@@ -155,9 +173,30 @@ __device__ __forceinline__ void phi_points(const double (&xv)[NP], const double 
 #pragma unroll
   for (int q = 0; q < NP; ++q)
     if (in[q]) {
-      phi_scatter<K, FX>((xv[q] - mesh[idx[q]]) * inv_delta, yv[q], idx[q] - cell0, ncols, do_band, band, rhs, s0);
+      phi_scatter<K, FX>((xv[q] - mesh[idx[q]]) * inv_delta, yv[q], idx[q] - cell0, ncols, do_band, band, rhs, fx);
       yy = fma(yv[q], yv[q], yy);
     }
+}
+
+// workgroup-wide y scale from each thread's first value(s): y0 = 2^E >= 4 max|y| (E = 0 when the tile is all zero, NaN or inf)
+__device__ __forceinline__ FxParams fx_scale(double my_abs, int s0, double* scratch) {
+  double m = (my_abs == my_abs && my_abs < 1e300) ? my_abs : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, scratch[w]);
+  __syncthreads();
+  int E = (t > 0.0) ? ilogb(t) + 3 : 0;
+  if (E > 900) E = 900;
+  if (E < -900) E = -900;
+  FxParams fx;
+  fx.s0 = s0;
+  fx.chi_r = ((1075 - (s0 - E)) << 20) | 0x80000;
+  fx.y0 = ldexp(1.0, E);
+  return fx;
 }
 
 // One workgroup per CU; block b owns points [b*ppb, (b+1)*ppb).  VEC: 16-B loads of (x0,x1),(y0,y1).
@@ -170,12 +209,12 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
   // the packed stats buffer is zeroed here (it is only touched again by phi_reduce_kernel, after this kernel)
   if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
   double* band = lds;                      // (K+1) x ncols
-  double* rhs = band + (K + 1) * ncols;    // ncols
-  double* mesh = rhs + ncols;              // n_mesh
+  double* rhs = band + (K + 1) * ncols;    // ncols (FX: fixed-point plane, followed by an fp64 plane for out-of-scale y)
+  double* mesh = rhs + (FX ? 2 : 1) * ncols;   // n_mesh
   double* scratch = mesh + n_mesh;         // 16
   const int tid = threadIdx.x;
   const int E = (K + 2) * ncols;
-  for (int e = tid; e < E; e += PHI_THREADS) lds[e] = 0.0;
+  for (int e = tid; e < E + (FX ? ncols : 0); e += PHI_THREADS) lds[e] = 0.0;
   for (int e = tid; e < n_mesh; e += PHI_THREADS) mesh[e] = mesh_g[e];
   __syncthreads();
   const double m0 = mesh[0];
@@ -183,6 +222,7 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
   long end = beg + ppb;
   if (end > N) end = N;
   double yy = 0.0;
+  FxParams fx{s0, 0, 0.0};
   if (VEC) {
     const double2* x2 = reinterpret_cast<const double2*>(x);
     const double2* y2 = reinterpret_cast<const double2*>(y);
@@ -190,6 +230,7 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
     long p = (beg >> 1) + tid;
     double2 xa = make_double2(0.0, 0.0), ya = xa;
     if (p < pend) { xa = x2[p]; ya = y2[p]; }
+    if (FX) fx = fx_scale(fmax(fabs(ya.x), fabs(ya.y)), s0, scratch);
     // wave-convergent loop (phi_point uses wave-wide votes): iterate while ANY lane of the wave has a pair left
     while (__any(p < pend)) {
       const bool have = p < pend;
@@ -197,21 +238,22 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
       double2 xb = xa, yb = ya;
       if (pn < pend) { xa = x2[pn]; ya = y2[pn]; }   // prefetch next pair before the LDS-atomic burst
       const double xp[2] = {xb.x, xb.y}, yp[2] = {yb.x, yb.y};
-      phi_points<K, 2, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, s0);
+      phi_points<K, 2, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, fx);
       p = pn;
     }
     {  // odd tail point (only the last block can have one); whole wave 0 enters, one lane is valid
       const bool tail = (end & 1) && end > beg;
       if (tail && tid < 64) {
         const double xp[1] = {tid == 0 ? x[end - 1] : 0.0}, yp[1] = {tid == 0 ? y[end - 1] : 0.0};
-        phi_points<K, 1, FX>(xp, yp, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, s0);
+        phi_points<K, 1, FX>(xp, yp, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, fx);
       }
     }
   } else {
+    if (FX) fx = fx_scale((beg + tid < end) ? fabs(y[(beg + tid) * y_stride]) : 0.0, s0, scratch);
     for (long i = beg + tid; __any(i < end); i += PHI_THREADS) {
       const bool have = i < end;
       const double xp[1] = {have ? x[i] : 0.0}, yp[1] = {have ? y[i * y_stride] : 0.0};
-      phi_points<K, 1, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, s0);
+      phi_points<K, 1, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, fx);
     }
   }
   double tot = block_sum(yy, scratch);  // contains the barrier that orders the LDS atomics before the flush
@@ -227,6 +269,9 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
 #pragma unroll
         for (int q = 1; q <= K; ++q) gd = (d == q) ? FxCoef<K>::tab.g[q] : gd;
         v = ldexp((double)(long long)reinterpret_cast<const unsigned long long*>(lds)[e], -(s0 + gd));
+      } else {   // Phi y: fixed-point plane (scale 2^(s0 - E), E from chi_r) + fp64 plane
+        const int sr = 1075 - (fx.chi_r >> 20);
+        v = ldexp((double)(long long)reinterpret_cast<const unsigned long long*>(lds)[e], -sr) + lds[e + ncols];
       }
       out[e] = v;
     }
@@ -751,17 +796,18 @@ static hipEvent_t g_prof_ev[PROF_RING][2];
 static bool g_prof_made = false;
 static long g_prof_n = 0;
 
-static int phi_max_cols(int K, long n_mesh) {
+static int phi_max_cols(int K, long n_mesh, bool fx) {
   long avail = (long)PHI_LDS_BUDGET - (long)n_mesh * 8 - 16 * 8;
   if (avail <= 0) return 0;
-  return (int)(avail / (8 * (K + 2)));
+  return (int)(avail / (8 * (K + 2 + (fx ? 1 : 0))));
 }
 
 template <int K>
 static int launch_phi(const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
   const int ncells = (int)n_mesh - 1;
-  int maxc = phi_max_cols(K, n_mesh);
+  const bool fx = (g_phi_algo == 3 || g_phi_algo == 0);
+  int maxc = phi_max_cols(K, n_mesh, fx);
   if (maxc < 2 * K + 2) {
     set_error("phi_accumulate_1d: mesh table (%ld knots) leaves no LDS for the band", n_mesh);
     return ASVGP_ERR_LDS_CAPACITY;
@@ -786,9 +832,8 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
       int cell1 = cell0 + cells_per_chunk;
       if (cell1 > ncells) cell1 = ncells;
       int ncols = cell1 - cell0 + K;
-      size_t lds_bytes = sizeof(double) * ((size_t)(K + 2) * ncols + n_mesh + 16);
+      size_t lds_bytes = sizeof(double) * ((size_t)(K + 2 + (fx ? 1 : 0)) * ncols + n_mesh + 16);
       int do_band = (dcol == 0);
-      const bool fx = (g_phi_algo == 3 || g_phi_algo == 0);
       auto kern = fx ? (vec ? phi_accumulate_kernel<K, true, true> : phi_accumulate_kernel<K, false, true>)
                      : (vec ? phi_accumulate_kernel<K, true, false> : phi_accumulate_kernel<K, false, false>);
       int s0 = 50;   // 62 - ceil(log2(points per workgroup)), at most 50 (magic-constant conversion range)

@@ -814,3 +814,32 @@ def test_utils_and_kronecker_helper_mirrors(A):
     m2, v2 = model.predict_f_sparse(X[:7])
     np.testing.assert_array_equal(m1, m2)
     assert v2.shape == (7, 1) and np.array_equal(v1[:, :1], v2)
+
+
+def test_phi_fixed_point_scale_fallback(A):
+    """The fixed-point Phi y scale is guessed from each workgroup's first tile; values beyond it (here 1e6 times larger,
+    in the later part of every shard, and an all-zero first tile) must take the fp64 path and give the same sums."""
+    rng = np.random.default_rng(21)
+    N, M = 300000, 200
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    ob = O.Basis(4, 0, 1, M)
+    bs = A.B4Spline(0, 1, M)
+    for kind in ("late_large", "zero_head", "tiny"):
+        y = 1e-3 * rng.normal(size=N)
+        if kind == "late_large":
+            y[N // 2:] *= 1e6
+            y[5000::7] = -3e4
+        elif kind == "zero_head":
+            y[:4096] = 0.0
+            y[4096:] = rng.normal(size=N - 4096) * 50
+        else:
+            y *= 1e-200
+        m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern12(), bs)
+        band, rhs, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+        np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)), err_msg=kind)
+        assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= 1e-12 * np.max(np.abs(band))
+        assert abs(m.tr_yTy.item() - yy) <= 1e-12 * yy
+    y = rng.normal(size=N)
+    y[123456] = np.nan
+    m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern12(), bs)
+    assert torch.isnan(m.Kuf_y).any() and torch.isnan(m.tr_yTy)      # a NaN observation is not silently dropped

@@ -1,0 +1,41 @@
+"""Summarise gpurun_out/prof_final (tools/collect_profiles.sh) into profiles/ (tracked)."""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_final")
+dst = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+
+def counters(sub, kernel="phi_accumulate_kernel"):
+    out = {}
+    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Kernel_Name"]:
+                out.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, tag + "_bench.json"))
+fetch, nf = counters("fetch")
+write, nw = counters("write")
+name = None
+for row in csv.DictReader(open(ks)):
+    if "phi_accumulate_kernel" in row["Name"]:
+        name, avg_ns = row["Name"].split("(")[0].replace("void asvgp::", ""), float(row["AverageNs"])
+traffic = {
+    "kernel": name, "points_per_launch": 10_000_000,
+    "FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
+    "correction": "gfx950 tallies 128-B streaming reads at 64 B: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); units KiB",
+    "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024,
+    "algorithmic_bytes_per_launch": 160_000_000,
+    "kernel_trace_average_us": avg_ns / 1e3,
+    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 tools/phi_pmc.py "
+               "(tools/collect_profiles.sh; launches averaged: %d / %d)" % (nf["FETCH_SIZE"], nw["WRITE_SIZE"]),
+}
+json.dump(traffic, open(os.path.join(dst, "r01_phi_traffic.json"), "w"), indent=1)
+sq, _ = counters("sq")
+p = os.path.join(dst, "r01_phi_pmc_counters.json")
+old = json.load(open(p)) if os.path.exists(p) else {}
+old[name + " (fixed-point band, final)"] = sq
+json.dump(old, open(p, "w"), indent=1)
+print(json.dumps(traffic, indent=1)); print(sq)
