@@ -843,3 +843,55 @@ def test_phi_fixed_point_scale_fallback(A):
     y[123456] = np.nan
     m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern12(), bs)
     assert torch.isnan(m.Kuf_y).any() and torch.isnan(m.tr_yTy)      # a NaN observation is not silently dropped
+
+
+def test_kron_full_size_properties_config4_and_config5_shapes(A):
+    """BASELINE config 4 (N=1M, 128x128, k=3) and the eNATL60 stand-in shape (B4Spline(-80,-25,100) x B4Spline(15,55,100),
+    eNATL60.py:84) at full basis size: size-independent properties instead of an O(M_tot^3) oracle."""
+    from asvgp_amd import experiments as E
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N = 1_000_000
+    X = torch.rand((N, 2), dtype=torch.float64, device="cuda", generator=g) * (1 - 2e-6) + 1e-6
+    y = (torch.sin(12 * X[:, :1]) * torch.cos(9 * X[:, 1:]) + 0.1 * torch.randn((N, 1), dtype=torch.float64, device="cuda", generator=g))
+    bases = [A.B3Spline(0, 1, 128), A.B3Spline(0, 1, 128)]
+    model = A.GPR_kron((X, y), [A.Matern32(variance=1.0, lengthscales=0.2), A.Matern32(variance=1.0, lengthscales=0.2)], bases)
+    model.likelihood.variance.assign(0.01)
+    k, m1, m2 = 3, 128, 128
+    blk = model.KufKfu_blockband
+    # partition of unity in both dimensions: 1^T A 1 = N, 1^T Kuf y = sum y  (diagonal offset (0,0) once, all others twice)
+    tot = blk[0].sum() + 2 * blk[1:].sum()
+    assert abs(tot.item() - N) <= 1e-9 * N
+    assert abs(model.Kuf_y.sum().item() - y.sum().item()) <= 1e-9 * y.abs().sum().item()
+    assert abs(model.tr_yTy.item() - (y * y).sum().item()) <= 1e-12 * (y * y).sum().item()
+    assert (blk[0] >= 0).all()
+    # linearity over N-shards (what the multi-GPU all-reduce relies on)
+    h = N // 2
+    kerns = [A.Matern32(), A.Matern32()]
+    s1 = A.GPR_kron((X[:h], y[:h]), kerns, bases)._stats
+    s2 = A.GPR_kron((X[h:], y[h:]), kerns, bases)._stats
+    assert ((s1 + s2) - model._stats).abs().max().item() <= 1e-11 * model._stats.abs().max().item()
+    # the bound is finite, below the exact-GP upper limit trivially implied by its terms, and invariant to a point shuffle
+    e = model.elbo().item()
+    assert np.isfinite(e)
+    perm = torch.randperm(N, device="cuda", generator=g)
+    m2_ = A.GPR_kron((X[perm].contiguous(), y[perm].contiguous()), model.kernels, bases)
+    m2_.likelihood.variance.assign(0.01)
+    assert abs(m2_.elbo().item() - e) <= 1e-9 * abs(e) + 5e-10 * (0.5 * N / 0.01)
+    # posterior at 2000 test points: mean close to the noise-free function, variance within (0, prior]
+    Xs = torch.rand((2000, 2), dtype=torch.float64, device="cuda", generator=g) * 0.9 + 0.05
+    mean, var = model.predict_f(Xs)
+    f = (torch.sin(12 * Xs[:, :1]) * torch.cos(9 * Xs[:, 1:])).cpu().numpy()
+    assert np.sqrt(np.mean((mean - f) ** 2)) < 0.05
+    assert (var > 0).all() and (var < 1.0).all()
+    # eNATL60 stand-in shape at reduced N
+    Xk, yk = E.synthetic_ssh(200_000)
+    mk = A.GPR_kron((Xk, yk), [A.Matern32(variance=0.1, lengthscales=8.0), A.Matern32(variance=1.0, lengthscales=8.0)],
+                    [A.B4Spline(-80, -25, 100), A.B4Spline(15, 55, 100)])
+    mk.likelihood.variance.assign(1e-3)
+    assert mk.order == 4 and mk.Mtot == 10_000 and mk.true_bandwidth == 4 * 101
+    blk = mk.KufKfu_blockband
+    assert abs((blk[0].sum() + 2 * blk[1:].sum()).item() - 200_000) <= 1e-9 * 200_000
+    ek = mk.elbo().item()
+    assert np.isfinite(ek)
+    mean, var = mk.predict_f(Xk[:3000])
+    assert E.MSE(yk[:3000], mean) < 5e-3 and (var > 0).all()
