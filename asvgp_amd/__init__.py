@@ -16,7 +16,7 @@ def set_band_algorithm(algo):
 
 
 def set_phi_algorithm(algo):
-    """0 = auto, 1 = fp64 LDS atomic scatter, 2 = counting sort + per-cell moments, 3 = fixed-point band scatter
-    (asvgp_set_phi_algorithm)."""
+    """0 = auto, 1 = fp64 LDS atomic scatter, 2 = counting sort + per-cell moments, 3 = fixed-point band scatter,
+    4 = per-cell buckets + moments (asvgp_set_phi_algorithm)."""
     from ._lib import check, get_lib
     check(get_lib().asvgp_set_phi_algorithm(int(algo)), "set_phi_algorithm")

@@ -665,6 +665,260 @@ __global__ __launch_bounds__(MOM_THREADS) void phi_moments_kernel(
   }
 }
 
+// =================================================================================================
+// Phi pass v4 ("buckets"): per-cell point lists instead of a sort, one barrier per tile.
+//
+// Tile = 2048 points (one 16-B pair per thread), double-buffered in the LDS as raw (x, y).  Rank phase: every thread
+// finds its two cells and takes a slot in the cell's list with ONE returning u32 LDS atomic (count), then stores its
+// 11-bit point index in the slot (6 slots per cell; mean occupancy is 1 at M = 2048).  Points beyond 6 go to a
+// tile-wide overflow list that can hold the whole tile.  Owner phase (next barrier interval, overlapping the rank
+// phase of the following tile): thread tau owns cells 2tau and 2tau+1, reads count + slot words (4 conflict-free
+// ds_read_b64), fetches its points from the raw tile and accumulates the 3k+2 centred moments in registers exactly like
+// v2 - no fp64 atomics, no scan, no scatter of 16-B records.  A wavefront whose 128 points fall into ONE cell (sorted /
+// time-series input) reduces its moments on the VALU (DPP) and posts a single aggregate record instead.
+// =================================================================================================
+constexpr int BK_THREADS = 1024;
+constexpr int BK_T = 2 * BK_THREADS;   // points per tile
+constexpr int BK_CELLS = 2048;         // cells per pass (2 per thread)
+constexpr int BK_SLOTS = 6;
+constexpr int BK_AGG = 16;             // at most one aggregate per wave and tile
+
+template <int K> constexpr int bk_agg_doubles() { return 3 * K + 2 + 2; }   // cell, S[2K+1], T[K+1], pad
+
+template <int K>
+__host__ __device__ constexpr size_t bk_lds_bytes() {
+  return (size_t)2 * BK_T * 16            // raw tiles
+       + (size_t)2 * BK_CELLS * 4         // counts
+       + (size_t)2 * 3 * BK_CELLS * 4     // slot words (3 dwords = 6 u16 per cell), dword-major
+       + (size_t)3 * BK_T * 4             // overflow lists (triple-buffered with their counters)
+       + (size_t)3 * BK_AGG * bk_agg_doubles<K>() * 8
+       + 64 * 8;                          // counters, reduction scratch, flags
+}
+
+template <int K, bool VEC>
+__global__ __launch_bounds__(BK_THREADS) void phi_bucket_kernel(
+    const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
+    const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
+    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n) {
+  extern __shared__ double lds[];
+  if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
+  constexpr int NA = bk_agg_doubles<K>();
+  double2* raw = reinterpret_cast<double2*>(lds);                                    // [2][BK_T]
+  unsigned* cnt = reinterpret_cast<unsigned*>(raw + 2 * BK_T);                      // [2][BK_CELLS]
+  unsigned* slotw = cnt + 2 * BK_CELLS;                                             // [2][3][BK_CELLS]
+  unsigned* ovf = slotw + 2 * 3 * BK_CELLS;                                         // [3][BK_T]   cell << 16 | point
+  double* agg = reinterpret_cast<double*>(ovf + 3 * BK_T);                          // [3][BK_AGG][NA]
+  double* red = agg + 3 * BK_AGG * NA;                                              // 16 doubles
+  unsigned* ctr = reinterpret_cast<unsigned*>(red + 16);                            // [3] overflow counts, [3] aggregate counts
+  int* flag = reinterpret_cast<int*>(ctr + 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int NC = cell1 - cell0;
+
+  const double m0 = mesh_g[0];
+  const double step = (mesh_g[n_mesh - 1] - m0) / (double)(n_mesh - 1);
+  if (tid == 0) *flag = 1;
+  for (int e = tid; e < 2 * BK_CELLS; e += BK_THREADS) cnt[e] = 0;
+  if (tid < 8) ctr[tid] = 0;
+  __syncthreads();
+  {
+    bool ok = true;
+    for (int e = tid; e < n_mesh - 1; e += BK_THREADS) ok = ok && (__dadd_rn(__dmul_rn((double)e, step), m0) == mesh_g[e]);
+    if (!ok) *flag = 0;
+  }
+  __syncthreads();
+  const bool arith = (*flag != 0);
+  auto knot = [&](int i) -> double { return arith ? __dadd_rn(__dmul_rn((double)i, step), m0) : mesh_g[i]; };
+
+  double SA[2 * K + 1], TA[K + 1], SB[2 * K + 1], TB[K + 1];
+#pragma unroll
+  for (int p = 0; p <= 2 * K; ++p) { SA[p] = 0.0; SB[p] = 0.0; }
+#pragma unroll
+  for (int p = 0; p <= K; ++p) { TA[p] = 0.0; TB[p] = 0.0; }
+  double yy = 0.0;
+  const int cA = 2 * tid, cB = 2 * tid + 1;                 // owned cells (chunk-local)
+  const double uA = knot(min(cell0 + cA, n_mesh - 2)), uB = knot(min(cell0 + cB, n_mesh - 2));
+
+  const long beg = (long)blockIdx.x * ppb;
+  long end = beg + ppb;
+  if (end > N) end = N;
+  const long ntiles = (end > beg) ? (end - beg + BK_T - 1) / BK_T : 0;
+
+  double2 px, py;   // the pair in flight (x0, x1), (y0, y1); NaN x = no point
+  auto load_pair = [&](long t) {
+    const long i = beg + t * BK_T + 2 * tid;
+    if (VEC) {
+      if (i + 1 < end) { px = *reinterpret_cast<const double2*>(x + i); py = *reinterpret_cast<const double2*>(y + i); return; }
+    }
+    px.x = (i < end) ? x[i] : __builtin_nan("");
+    py.x = (i < end) ? y[i * y_stride] : 0.0;
+    px.y = (i + 1 < end) ? x[i + 1] : __builtin_nan("");
+    py.y = (i + 1 < end) ? y[(i + 1) * y_stride] : 0.0;
+  };
+
+  auto find_cell = [&](double xv) -> int {
+    double g = floor((xv - m0) * inv_delta);
+    int i = (g < 0.0) ? 0 : ((g > (double)(n_mesh - 2)) ? (n_mesh - 2) : (int)g);   // NaN -> 0
+    i -= (i > 0 && !(knot(i) < xv)) ? 1 : 0;
+    i += (i < n_mesh - 2 && knot(i + 1) < xv) ? 1 : 0;
+    const double lo = knot(i), hi = knot(i + 1);
+    const bool good = (lo < xv || i == 0) && (!(hi < xv) || i == n_mesh - 2);
+    if (!good && xv == xv) {   // rare: exact searchsorted semantics by linear walk
+      while (i > 0 && !(knot(i) < xv)) --i;
+      while (i < n_mesh - 2 && knot(i + 1) < xv) ++i;
+    }
+    return i;
+  };
+
+  // ---- rank phase of tile t into buffer t & 1
+  auto rank_tile = [&](long t) {
+    const int b = (int)(t & 1), o3 = (int)(t % 3);
+    double2* rw = raw + b * BK_T;
+    unsigned* cn = cnt + b * BK_CELLS;
+    unsigned* sw = slotw + b * 3 * BK_CELLS;
+    const double xv[2] = {px.x, px.y}, yv[2] = {py.x, py.y};
+    rw[2 * tid] = make_double2(xv[0], yv[0]);
+    rw[2 * tid + 1] = make_double2(xv[1], yv[1]);
+    int c[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ci = find_cell(xv[u]) - cell0;
+      ok[u] = (xv[u] == xv[u]) && ci >= 0 && ci < NC;
+      c[u] = ok[u] ? ci : -1;
+      yy = ok[u] ? fma(yv[u], yv[u], yy) : yy;
+    }
+    if (t + 1 < ntiles) load_pair(t + 1);   // next pair in flight under the LDS work (raw barrier keeps it there)
+    const int c0 = __builtin_amdgcn_readfirstlane(c[0]);
+    if (__all(ok[0] && ok[1] && c[0] == c0 && c[1] == c0)) {   // wave-uniform: one aggregate record
+      const double u = knot(cell0 + c0);
+      double S2[2 * K + 1], T2[K + 1];
+#pragma unroll
+      for (int p = 0; p <= 2 * K; ++p) S2[p] = 0.0;
+#pragma unroll
+      for (int p = 0; p <= K; ++p) T2[p] = 0.0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) mom_accumulate<K>(fma(xv[q] - u, inv_delta, -0.5), yv[q], S2, T2);
+      unsigned pos = 0;
+      if (lane == 0) pos = atomicAdd(&ctr[3 + o3], 1u);
+      pos = __builtin_amdgcn_readfirstlane(pos);
+      double* rec = agg + ((size_t)o3 * BK_AGG + pos) * NA;
+#pragma unroll
+      for (int p = 0; p <= 2 * K; ++p) { double r = wave_sum_dpp(S2[p]); if (lane == 0) rec[1 + p] = r; }
+#pragma unroll
+      for (int p = 0; p <= K; ++p) { double r = wave_sum_dpp(T2[p]); if (lane == 0) rec[2 + 2 * K + p] = r; }
+      if (lane == 0) rec[0] = (double)c0;
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (ok[u]) {
+        const unsigned r = atomicAdd(&cn[c[u]], 1u);
+        const unsigned pidx = 2 * tid + u;
+        if (r < BK_SLOTS) {
+          reinterpret_cast<unsigned short*>(sw + (r >> 1) * BK_CELLS + c[u])[r & 1] = (unsigned short)pidx;
+        } else {
+          const unsigned pos = atomicAdd(&ctr[o3], 1u);
+          ovf[o3 * BK_T + pos] = ((unsigned)c[u] << 16) | pidx;
+        }
+      }
+    }
+  };
+
+  // ---- owner phase of tile t
+  auto own_tile = [&](long t) {
+    const int b = (int)(t & 1), o3 = (int)(t % 3);
+    const double2* rw = raw + b * BK_T;
+    unsigned* cn = cnt + b * BK_CELLS;
+    const unsigned* sw = slotw + b * 3 * BK_CELLS;
+    const uint2 n2 = *reinterpret_cast<const uint2*>(cn + cA);
+    const unsigned nA = min(n2.x, (unsigned)BK_SLOTS), nB = min(n2.y, (unsigned)BK_SLOTS);
+    const unsigned nmax = max(nA, nB);
+    if (nmax) {
+      uint2 w[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const uint2*>(sw + q * BK_CELLS + cA);
+      if (n2.x | n2.y) *reinterpret_cast<uint2*>(cn + cA) = make_uint2(0u, 0u);
+#pragma unroll
+      for (int j = 0; j < BK_SLOTS; ++j) {
+        if (j < (int)nmax) {
+          const bool a = j < (int)nA, bb = j < (int)nB;
+          const unsigned ia = (w[j >> 1].x >> (16 * (j & 1))) & 0xffffu, ib = (w[j >> 1].y >> (16 * (j & 1))) & 0xffffu;
+          const double2 pa = a ? rw[ia] : make_double2(0.0, 0.0);
+          const double2 pb = bb ? rw[ib] : make_double2(0.0, 0.0);
+          const double sa = a ? fma(pa.x - uA, inv_delta, -0.5) : 0.0, sb = bb ? fma(pb.x - uB, inv_delta, -0.5) : 0.0;
+          double wa = sa, wb = sb;
+          SA[0] += a ? 1.0 : 0.0;
+          SB[0] += bb ? 1.0 : 0.0;
+          TA[0] += pa.y;
+          TB[0] += pb.y;
+          SA[1] += wa; SB[1] += wb;
+          TA[1] = fma(pa.y, wa, TA[1]); TB[1] = fma(pb.y, wb, TB[1]);
+#pragma unroll
+          for (int p = 2; p <= 2 * K; ++p) {
+            wa *= sa; wb *= sb;
+            SA[p] += wa; SB[p] += wb;
+            if (p <= K) { TA[p] = fma(pa.y, wa, TA[p]); TB[p] = fma(pb.y, wb, TB[p]); }
+          }
+        }
+      }
+    }
+    // overflow list of this tile (cells with more than BK_SLOTS points) and wave aggregates: usually both empty
+    const unsigned nov = ctr[o3], nag = ctr[3 + o3];
+    for (unsigned e = 0; e < nov; ++e) {
+      const unsigned ent = ovf[o3 * BK_T + e];
+      const int cc = (int)(ent >> 16);
+      if (cc == cA || cc == cB) {
+        const double2 pt = rw[ent & 0xffffu];
+        if (cc == cA) mom_accumulate<K>(fma(pt.x - uA, inv_delta, -0.5), pt.y, SA, TA);
+        else mom_accumulate<K>(fma(pt.x - uB, inv_delta, -0.5), pt.y, SB, TB);
+      }
+    }
+    for (unsigned e = 0; e < nag; ++e) {
+      const double* rec = agg + ((size_t)o3 * BK_AGG + e) * NA;
+      const int cc = (int)rec[0];
+      if (cc == cA) {
+#pragma unroll
+        for (int p = 0; p <= 2 * K; ++p) SA[p] += rec[1 + p];
+#pragma unroll
+        for (int p = 0; p <= K; ++p) TA[p] += rec[2 + 2 * K + p];
+      } else if (cc == cB) {
+#pragma unroll
+        for (int p = 0; p <= 2 * K; ++p) SB[p] += rec[1 + p];
+#pragma unroll
+        for (int p = 0; p <= K; ++p) TB[p] += rec[2 + 2 * K + p];
+      }
+    }
+  };
+
+  if (ntiles > 0) {
+    load_pair(0);
+    rank_tile(0);
+  }
+  lds_barrier();
+  for (long t = 0; t < ntiles; ++t) {
+    // counters of tile t + 2 were last read by the owner phase of tile t - 1, which the barrier above has retired
+    if (tid == 0) { ctr[(t + 2) % 3] = 0; ctr[3 + (t + 2) % 3] = 0; }
+    if (t + 1 < ntiles) rank_tile(t + 1);
+    own_tile(t);
+    lds_barrier();
+  }
+
+  // ---- moments -> band / rhs (LDS image aliases the tile buffers), then flush like v1
+  double tot = block_sum(yy, red);
+  __syncthreads();
+  const int E = (K + 2) * ncols;
+  for (int e = tid; e < E; e += BK_THREADS) lds[e] = 0.0;
+  __syncthreads();
+  double* band = lds;
+  double* rhs = band + (K + 1) * ncols;
+  if (cA < NC) mom_to_band<K>(SA, TA, cA, ncols, do_band, band, rhs);
+  if (cB < NC) mom_to_band<K>(SB, TB, cB, ncols, do_band, band, rhs);
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * (E + 1);
+  for (int e = tid; e < E; e += BK_THREADS) out[e] = lds[e];
+  if (tid == 0) out[E] = tot;
+}
+
 // Sum the per-workgroup partials into the packed stats buffer (zeroed beforehand).
 // grid = (ceil((E+1)/256), gsplit); each thread sums its slice of workgroups, then one fp64 global atomic.
 __global__ __launch_bounds__(256) void phi_reduce_kernel(const double* __restrict__ partials, int G, int ncols,
@@ -806,7 +1060,7 @@ template <int K>
 static int launch_phi(const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
   const int ncells = (int)n_mesh - 1;
-  const bool fx = (g_phi_algo == 3 || g_phi_algo == 0);
+  const bool fx = (g_phi_algo == 3 || g_phi_algo == 0 || (g_phi_algo == 4 && bk_lds_bytes<K>() > PHI_LDS_BUDGET));
   int maxc = phi_max_cols(K, n_mesh, fx);
   if (maxc < 2 * K + 2) {
     set_error("phi_accumulate_1d: mesh table (%ld knots) leaves no LDS for the band", n_mesh);
@@ -814,8 +1068,9 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
   }
   int cells_per_chunk = (M <= maxc) ? ncells : (maxc - K);
   const bool v2 = (g_phi_algo == 2);
+  const bool v4 = (g_phi_algo == 4) && bk_lds_bytes<K>() <= PHI_LDS_BUDGET;   // (k = 6: the bucket buffers exceed the LDS -> algorithm 3)
   constexpr int TP = 6;
-  if (v2 && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
+  if ((v2 || v4) && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
   long nblk = (N + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS);
   const long gmax = (g_phi_blocks > 0 && g_phi_blocks < PHI_MAX_BLOCKS) ? g_phi_blocks : PHI_MAX_BLOCKS;
   int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
@@ -851,7 +1106,15 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
       const bool prof = g_prof_on && g_prof_n < PROF_RING && (g_prof_calls++ % g_prof_every == 0);
       if (prof) hipEventRecord(g_prof_ev[g_prof_n][0], st);
-      if (v2) {
+      if (v4) {
+        auto k4 = vec ? phi_bucket_kernel<K, true> : phi_bucket_kernel<K, false>;
+        size_t band_bytes = sizeof(double) * (size_t)(K + 2) * ncols;
+        size_t l4 = bk_lds_bytes<K>() > band_bytes ? bk_lds_bytes<K>() : band_bytes;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", l4, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+        hipLaunchKernelGGL(k4, dim3(G), dim3(BK_THREADS), l4, st, x, yd, (long)D, N, mesh, (int)n_mesh, inv_delta,
+                           cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
+      } else if (v2) {
         auto k2 = vec ? phi_moments_kernel<K, TP, true> : phi_moments_kernel<K, TP, false>;
         if (K == 4 && vec && g_phi_ablate >= 1 && g_phi_ablate <= 9) {  // diagnostic builds (tools/phi_ablate.py)
           if (g_phi_ablate == 1) k2 = phi_moments_kernel<4, TP, true, 1>;
@@ -884,7 +1147,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
 using namespace asvgp;
 
 extern "C" int asvgp_set_phi_algorithm(int algo) {
-  if (algo < 0 || algo > 3) { set_error("set_phi_algorithm: 0 auto, 1 fp64 LDS-atomic scatter, 2 counting-sort + moments, 3 fixed-point band scatter"); return ASVGP_ERR_BAD_ARG; }
+  if (algo < 0 || algo > 4) { set_error("set_phi_algorithm: 0 auto, 1 fp64 LDS-atomic scatter, 2 counting-sort + moments, 3 fixed-point band scatter, 4 per-cell buckets + moments"); return ASVGP_ERR_BAD_ARG; }
   g_phi_algo = algo;
   const char* ab = getenv("ASVGP_PHI_ABLATE");
   g_phi_ablate = ab ? atoi(ab) : 0;

@@ -64,7 +64,9 @@ int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t
  * + per-cell moment accumulation in registers (3k+2 sums per point, converted to band entries once per workgroup),
  * 3 = as 1 with the Phi Phi^T products accumulated as 64-bit fixed-point integers (ds_add_u64 runs at twice the
  * ds_add_f64 rate; per-diagonal power-of-two scales, error per addend <= 2^-43 of the diagonal's largest product,
- * order-independent sums).  Same statistics to <= 1e-12 of the band's largest entry.  Process-wide, host-side. */
+ * order-independent sums), 4 = per-cell point lists (one returning u32 LDS atomic per point, 6 slots per cell, overflow
+ * list) + per-cell moments in registers, one barrier per 2048-point tile (VALU-bound where 3 is LDS-bound; same speed
+ * at M = 2048).  Same statistics to <= 1e-12 of the band's largest entry.  Process-wide, host-side. */
 int asvgp_set_phi_algorithm(int algo);
 /* workgroups of the Phi-pass kernel: 0 = default (256, one per CU); a smaller number leaves CUs free so that a
  * concurrently enqueued asvgp_elbo_prior_chain_1d (second stream) is resident at the same time. */
