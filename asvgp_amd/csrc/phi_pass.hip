@@ -14,6 +14,7 @@
 namespace asvgp {
 
 constexpr int PHI_THREADS = 1024;
+constexpr int PHI_CH = 8;                     // iterations a wavefront stays on one contiguous slice (see phi_accumulate_kernel)
 constexpr int PHI_MAX_BLOCKS = 256;           // one 1024-thread workgroup per CU (LDS-limited)
 constexpr size_t PHI_LDS_BUDGET = 160 * 1024 - 512;
 
@@ -109,73 +110,107 @@ __device__ __forceinline__ void phi_scatter(double t, double yv, int cb, int nco
 // Time-series / sorted inputs put a whole wavefront into ONE cell: 64 same-address LDS atomics would serialise
 // (1.0 ms for the sorted N = 10M case).  When every point of the wave sits in the same cell, the 20 products are
 // summed in-lane over the pair, reduced across the wave on the VALU (DPP) and committed by one lane.
-template <int K, int NP, bool FX>
-__device__ __forceinline__ void phi_points(const double (&xv)[NP], const double (&yv)[NP], bool valid, const double* mesh,
-                                           int n_mesh, double m0, double inv_delta, int cell0, int cell1, int ncols,
-                                           bool do_band, double* band, double* rhs, double& yy, FxParams fx) {
-  const int s0 = fx.s0;
+// Run-length accumulator of a wavefront that stays inside ONE cell (sorted / time-series input): products are summed
+// in-lane across iterations and reduced across the wave only when the cell changes (run_flush).
+template <int K> struct RunAcc {
+  int cell;   // wave-uniform; -1 = empty
+  double r[K + 1];
+  double b[(K + 1) * (K + 2) / 2];
+};
+template <int K> __device__ __forceinline__ void run_clear(RunAcc<K>& A) {
+  A.cell = -1;
+#pragma unroll
+  for (int i = 0; i <= K; ++i) A.r[i] = 0.0;
+#pragma unroll
+  for (int e = 0; e < (K + 1) * (K + 2) / 2; ++e) A.b[e] = 0.0;
+}
+// wave-uniform call.  The band sums leave as fixed point through a full double -> int64 conversion (a run's sum exceeds
+// the magic-constant range of fx_convert; the conversion runs once per run, on one lane's worth of values).
+template <int K, bool FX>
+__device__ __forceinline__ void run_flush(RunAcc<K>& A, int cell0, int ncols, bool do_band, double* band, double* rhs, FxParams fx) {
+  const int c = __builtin_amdgcn_readfirstlane(A.cell);
+  if (c < 0) return;
+  const int cb = c - cell0;
+  const bool commit = (threadIdx.x & 63) == 0;
+  int e = 0;
+#pragma unroll
+  for (int i = 0; i <= K; ++i) {
+    const double r = wave_sum_dpp(A.r[i]);
+    if (commit) lds_add(rhs + (FX ? ncols : 0) + cb + K - i, r);   // (fp64 plane: a run's sum is not bounded by y0)
+    A.r[i] = 0.0;
+#pragma unroll
+    for (int j = i; j <= K; ++j) {
+      if (do_band) {
+        const double t = wave_sum_dpp(A.b[e]);
+        if (commit) {
+          if (FX) lds_add_u64(reinterpret_cast<unsigned long long*>(band) + (j - i) * ncols + cb + K - j,
+                              (unsigned long long)__double2ll_rn(ldexp(t, fx.s0 + FxCoef<K>::tab.g[j - i])));
+          else lds_add(band + (j - i) * ncols + cb + K - j, t);
+        }
+      }
+      A.b[e] = 0.0;
+      ++e;
+    }
+  }
+  A.cell = -1;
+}
+
+// One batch = NP points per lane (a 16-B pair or a single point).  Whole wavefronts only (wave-wide votes).
+template <int NP> struct Batch {
+  double x[NP], y[NP];
   int idx[NP];
   bool in[NP];
+  int idx0;       // wave-uniform: cell of lane 0's first point
+  bool uniform;   // wave-uniform: every point of the wave lies in cell idx0 (and inside this column chunk)
+};
+template <int NP>
+__device__ __forceinline__ void classify(Batch<NP>& B, bool valid, const double* mesh, int n_mesh, double m0, double inv_delta,
+                                         int cell0, int cell1) {
   bool all_in = true;
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    idx[q] = valid ? neighbour_index(xv[q], mesh, n_mesh, m0, inv_delta) : -1;
-    in[q] = valid && idx[q] >= cell0 && idx[q] < cell1;
-    all_in = all_in && in[q];
+    B.idx[q] = valid ? neighbour_index(B.x[q], mesh, n_mesh, m0, inv_delta) : -1;
+    B.in[q] = valid && B.idx[q] >= cell0 && B.idx[q] < cell1;
+    all_in = all_in && B.in[q];
   }
-  const int idx0 = __builtin_amdgcn_readfirstlane(idx[0]);
+  B.idx0 = __builtin_amdgcn_readfirstlane(B.idx[0]);
   bool same = all_in;
 #pragma unroll
-  for (int q = 0; q < NP; ++q) same = same && (idx[q] == idx0);
-  if (__all(same)) {  // wave-uniform branch
-    const int cb = idx0 - cell0;
-    const double u = mesh[idx0];
-    double accr[K + 1], accb[(K + 1) * (K + 2) / 2];
+  for (int q = 0; q < NP; ++q) same = same && (B.idx[q] == B.idx0);
+  B.uniform = __all(same);
+}
+template <int K, int NP, bool FX>
+__device__ __forceinline__ void scatter_batch(const Batch<NP>& B, const double* mesh, double inv_delta, int cell0, int ncols,
+                                              bool do_band, double* band, double* rhs, double& yy, FxParams fx) {
 #pragma unroll
-    for (int i = 0; i <= K; ++i) accr[i] = 0.0;
-#pragma unroll
-    for (int e = 0; e < (K + 1) * (K + 2) / 2; ++e) accb[e] = 0.0;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      double v[K + 1];
-      bspline_pieces<K>((xv[q] - u) * inv_delta, v);
-      int e = 0;
-#pragma unroll
-      for (int i = 0; i <= K; ++i) {
-        accr[i] = fma(v[i], yv[q], accr[i]);
-#pragma unroll
-        for (int j = i; j <= K; ++j) accb[e++] += v[i] * v[j];
-      }
-      yy = fma(yv[q], yv[q], yy);
+  for (int q = 0; q < NP; ++q)
+    if (B.in[q]) {
+      phi_scatter<K, FX>((B.x[q] - mesh[B.idx[q]]) * inv_delta, B.y[q], B.idx[q] - cell0, ncols, do_band, band, rhs, fx);
+      yy = fma(B.y[q], B.y[q], yy);
     }
-    const bool commit = (threadIdx.x & 63) == 0;
+}
+// uniform batch -> run accumulator (flushing first when the cell changes)
+template <int K, int NP, bool FX>
+__device__ __forceinline__ void run_batch(const Batch<NP>& B, RunAcc<K>& run, const double* mesh, double inv_delta, int cell0,
+                                          int ncols, bool do_band, double* band, double* rhs, double& yy, FxParams fx) {
+  if (B.idx0 != __builtin_amdgcn_readfirstlane(run.cell)) {
+    run_flush<K, FX>(run, cell0, ncols, do_band, band, rhs, fx);
+    run.cell = B.idx0;
+  }
+  const double u = mesh[B.idx0];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    double v[K + 1];
+    bspline_pieces<K>((B.x[q] - u) * inv_delta, v);
     int e = 0;
 #pragma unroll
     for (int i = 0; i <= K; ++i) {
-      double r = wave_sum_dpp(accr[i]);
-      if (commit) lds_add(rhs + (FX ? ncols : 0) + cb + K - i, r);   // (fp64 plane: a wave sum is not bounded by y0)
+      run.r[i] = fma(v[i], B.y[q], run.r[i]);
 #pragma unroll
-      for (int j = i; j <= K; ++j) {
-        if (do_band) {
-          if (FX) {   // in-lane pair sum < 2^(s0+1) <= 2^51 after scaling: still inside the magic-constant range
-            unsigned long long b = wave_sum_dpp_u64(fx_convert(accb[e], fx_chi<K>(s0, j - i)));
-            if (commit) lds_add_u64(reinterpret_cast<unsigned long long*>(band) + (j - i) * ncols + cb + K - j, b);
-          } else {
-            double b = wave_sum_dpp(accb[e]);
-            if (commit) lds_add(band + (j - i) * ncols + cb + K - j, b);
-          }
-        }
-        ++e;
-      }
+      for (int j = i; j <= K; ++j) { run.b[e] = fma(v[i], v[j], run.b[e]); ++e; }
     }
-    return;
+    yy = fma(B.y[q], B.y[q], yy);
   }
-#pragma unroll
-  for (int q = 0; q < NP; ++q)
-    if (in[q]) {
-      phi_scatter<K, FX>((xv[q] - mesh[idx[q]]) * inv_delta, yv[q], idx[q] - cell0, ncols, do_band, band, rhs, fx);
-      yy = fma(yv[q], yv[q], yy);
-    }
 }
 
 // workgroup-wide y scale from each thread's first value(s): y0 = 2^E >= 4 max|y| (E = 0 when the tile is all zero, NaN or inf)
@@ -223,37 +258,75 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
   if (end > N) end = N;
   double yy = 0.0;
   FxParams fx{s0, 0, 0.0};
-  if (VEC) {
-    const double2* x2 = reinterpret_cast<const double2*>(x);
-    const double2* y2 = reinterpret_cast<const double2*>(y);
-    const long pend = end >> 1;  // pairs [beg/2, pend)
-    long p = (beg >> 1) + tid;
-    double2 xa = make_double2(0.0, 0.0), ya = xa;
-    if (p < pend) { xa = x2[p]; ya = y2[p]; }
-    if (FX) fx = fx_scale(fmax(fabs(ya.x), fabs(ya.y)), s0, scratch);
-    // wave-convergent loop (phi_point uses wave-wide votes): iterate while ANY lane of the wave has a pair left
-    while (__any(p < pend)) {
-      const bool have = p < pend;
-      long pn = p + PHI_THREADS;
-      double2 xb = xa, yb = ya;
-      if (pn < pend) { xa = x2[pn]; ya = y2[pn]; }   // prefetch next pair before the LDS-atomic burst
-      const double xp[2] = {xb.x, xb.y}, yp[2] = {yb.x, yb.y};
-      phi_points<K, 2, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, fx);
-      p = pn;
+  // Point -> wave mapping: the workgroup walks its range in super-tiles of 16 waves x PHI_CH iterations x 128 points; inside
+  // a super-tile every wavefront streams a contiguous slice (PHI_CH * 128 points), so a sorted input keeps a wave inside
+  // one cell for PHI_CH iterations while the workgroup as a whole still reads one contiguous window of memory at a time.
+  const int lane = tid & 63, wv = tid >> 6;
+  constexpr int NP = VEC ? 2 : 1;
+  const long n_it = (ppb / (2 * PHI_THREADS)) * (VEC ? 1 : 2);   // rows of 64 lanes per wave (ppb is a multiple of 2 * PHI_THREADS)
+  auto unit_of = [&](long it) -> long {   // row visited by this wave at iteration `it`
+    const long nfull = n_it / PHI_CH, rem = n_it - nfull * PHI_CH;
+    const long sup = it / PHI_CH, r = it - sup * PHI_CH;
+    return (sup < nfull) ? (sup * (PHI_THREADS / 64) + wv) * PHI_CH + r     // full super-tile: slices of PHI_CH rows
+                         : nfull * (PHI_THREADS / 64) * PHI_CH + wv * rem + r;   // last, shorter super-tile: slices of `rem` rows
+  };
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  const double2* y2 = reinterpret_cast<const double2*>(y);
+  const long ubeg = VEC ? (beg >> 1) : beg, uend = (end > beg) ? (VEC ? (end >> 1) : end) : 0;   // units: pairs or points
+  double2 xa = make_double2(0.0, 0.0), ya = xa;   // the prefetched unit (VEC: pair; scalar: .x only)
+  auto fetch = [&](long it) {
+    const long u = ubeg + unit_of(it) * 64 + lane;
+    if (it < n_it && u < uend) {
+      if (VEC) { xa = x2[u]; ya = y2[u]; }
+      else { xa.x = x[u]; ya.x = y[u * y_stride]; }
     }
-    {  // odd tail point (only the last block can have one); whole wave 0 enters, one lane is valid
-      const bool tail = (end & 1) && end > beg;
-      if (tail && tid < 64) {
-        const double xp[1] = {tid == 0 ? x[end - 1] : 0.0}, yp[1] = {tid == 0 ? y[end - 1] : 0.0};
-        phi_points<K, 1, FX>(xp, yp, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, fx);
-      }
+  };
+  fetch(0);
+  if (FX) fx = fx_scale((n_it > 0 && ubeg + unit_of(0) * 64 + lane < uend) ? fmax(fabs(ya.x), VEC ? fabs(ya.y) : 0.0) : 0.0, s0, scratch);
+  Batch<NP> B;
+  long it = 0;
+  // take the prefetched unit as the current batch, start the next prefetch (before the LDS burst), classify
+  auto advance = [&]() {
+    const bool have = (ubeg + unit_of(it) * 64 + lane) < uend;
+    B.x[0] = xa.x; B.y[0] = ya.x;
+    if (VEC) { B.x[NP - 1] = xa.y; B.y[NP - 1] = ya.y; }
+    fetch(it + 1);
+    classify<NP>(B, have, mesh, n_mesh, m0, inv_delta, cell0, cell1);
+  };
+  // Two loops so that the run accumulator (40 VGPRs) is live only while a wave actually is inside a run: scatter mode is the
+  // steady state of unsorted input, run mode of sorted / time-series input; every batch is classified, so a wrong mode
+  // costs time, never correctness.
+  while (it < n_it) {   // wave-convergent throughout (votes, DPP)
+    bool pending = false;
+    for (; it < n_it; ++it) {   // ---- scatter mode
+      advance();
+      if (B.uniform) { pending = true; break; }
+      scatter_batch<K, NP, FX>(B, mesh, inv_delta, cell0, ncols, do_band, band, rhs, yy, fx);
     }
-  } else {
-    if (FX) fx = fx_scale((beg + tid < end) ? fabs(y[(beg + tid) * y_stride]) : 0.0, s0, scratch);
-    for (long i = beg + tid; __any(i < end); i += PHI_THREADS) {
-      const bool have = i < end;
-      const double xp[1] = {have ? x[i] : 0.0}, yp[1] = {have ? y[i * y_stride] : 0.0};
-      phi_points<K, 1, FX>(xp, yp, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, ncols, do_band, band, rhs, yy, fx);
+    if (!pending) break;
+    RunAcc<K> run;              // ---- run mode: the pending uniform batch starts a run
+    run_clear<K>(run);
+    for (;;) {
+      run_batch<K, NP, FX>(B, run, mesh, inv_delta, cell0, ncols, do_band, band, rhs, yy, fx);
+      ++it;
+      if (it >= n_it) { pending = false; break; }
+      advance();
+      if (!B.uniform) break;    // (pending stays true: B holds a classified non-uniform batch)
+    }
+    run_flush<K, FX>(run, cell0, ncols, do_band, band, rhs, fx);
+    if (pending) {
+      scatter_batch<K, NP, FX>(B, mesh, inv_delta, cell0, ncols, do_band, band, rhs, yy, fx);
+      ++it;
+    }
+  }
+  if (VEC) {  // odd tail point (only the last block can have one); whole wave 0 enters, one lane is valid
+    const bool tail = (end & 1) && end > beg;
+    if (tail && tid < 64) {
+      Batch<1> T1;
+      T1.x[0] = (tid == 0) ? x[end - 1] : 0.0;
+      T1.y[0] = (tid == 0) ? y[end - 1] : 0.0;
+      classify<1>(T1, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1);
+      scatter_batch<K, 1, FX>(T1, mesh, inv_delta, cell0, ncols, do_band, band, rhs, yy, fx);
     }
   }
   double tot = block_sum(yy, scratch);  // contains the barrier that orders the LDS atomics before the flush
