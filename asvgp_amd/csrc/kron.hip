@@ -304,6 +304,126 @@ __global__ void predict_kron2d_kernel(const double* __restrict__ X, long n, cons
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Selected inverse of P on the band, through dense super-blocks.
+// With block size Bb >= bw (a multiple of 32) the band factor is block BIDIAGONAL: diagonal blocks L_ii (lower
+// triangular) and sub-diagonal blocks L_{i+1,i}.  bb_blocks_kernel unpacks the column-major band factor into those two
+// dense batches; the caller runs the block recursion
+//     G_i = L_{i+1,i} L_ii^-1,   Sigma_{i+1,i} = -Sigma_{i+1,i+1} G_i,   Sigma_ii = (L_ii L_ii^T)^-1 - G_i^T Sigma_{i+1,i}
+// with one batched triangular solve and 2(n-1) dense fp64 GEMMs (plain library calls), and the kernels below read
+// Sigma[row, col] (|row - col| <= bw <= Bb) out of the two block batches.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void bb_blocks_kernel(const double* __restrict__ Lb, long M, int bw, long LD, int Bb, long nblk,
+                                 double* __restrict__ diag, double* __restrict__ sub) {
+  const long per = (long)Bb * Bb;
+  const long total = (2 * nblk - 1) * per;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const bool is_sub = t >= nblk * per;
+    const long u = is_sub ? t - nblk * per : t;
+    const long blk = u / per;
+    const int r = (int)((u - blk * per) / Bb), c = (int)(u % Bb);
+    const long row = (blk + (is_sub ? 1 : 0)) * Bb + r, col = blk * Bb + c;
+    double v = 0.0;
+    if (row < M && col < M && row >= col && row - col <= bw) v = Lb[col * LD + (row - col)];
+    else if (!is_sub && r == c && row >= M) v = 1.0;   // identity padding of the last block
+    (is_sub ? sub : diag)[u] = v;
+  }
+}
+
+// Sigma[row, col] for row >= col, row - col <= Bb
+__device__ __forceinline__ double sig_read(const double* __restrict__ SigD, const double* __restrict__ SigS, int Bb, long row, long col) {
+  const long bi = row / Bb, bj = col / Bb;
+  const long per = (long)Bb * Bb;
+  const int r = (int)(row - bi * Bb), c = (int)(col - bj * Bb);
+  return (bi == bj) ? SigD[bi * per + (long)r * Bb + c] : SigS[bj * per + (long)r * Bb + c];
+}
+
+// 11 contractions over the block band (full symmetric sums: off-diagonal entries count twice):
+//  0 tr(Sig A)  1 a^T A a  2 tr(Sig X1) 3 a^T X1 a  4 tr(Sig X2) 5 a^T X2 a  6 tr(Sig Kuu) 7 a^T Kuu a
+//  8 tr((Z1 (x) S2) A)  9 tr((S1 (x) Z2) A)  10 tr((S1 (x) S2) A)      X1 = dK1 (x) K2,  X2 = K1 (x) dK2
+__global__ void kron_grad_terms_kernel(const double* __restrict__ SigD, const double* __restrict__ SigS, int Bb,
+                                       const double* __restrict__ alpha, const double* __restrict__ Ablk,
+                                       const double* __restrict__ K1, const double* __restrict__ K2,
+                                       const double* __restrict__ dK1, const double* __restrict__ dK2,
+                                       const double* __restrict__ S1, const double* __restrict__ S2,
+                                       const double* __restrict__ Z1, const double* __restrict__ Z2, int k, int m1, int m2,
+                                       double* __restrict__ out) {
+  __shared__ double scratch[16];
+  const long Mtot = (long)m1 * m2;
+  const int noff = kron_noff(k);
+  double acc[11];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) acc[q] = 0.0;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < Mtot * noff; t += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(t / Mtot);
+    const long c = t - (long)o * Mtot;
+    int d1, d2;
+    if (o <= k) { d1 = 0; d2 = o; } else { int q = o - (k + 1); d1 = 1 + q / (2 * k + 1); d2 = q % (2 * k + 1) - k; }
+    const int i1 = (int)(c / m2), i2 = (int)(c - (long)i1 * m2);
+    if (i1 + d1 >= m1 || i2 + d2 < 0 || i2 + d2 >= m2) continue;
+    const long row = c + (long)d1 * m2 + d2;
+    const double w = (o == 0) ? 1.0 : 2.0;
+    const double a = Ablk[t];
+    const double sg = sig_read(SigD, SigS, Bb, row, c);
+    const double aa = alpha[row] * alpha[c];
+    const double k1 = K1[(long)d1 * m1 + i1], k2 = band_sym(K2, m2, i2, d2);
+    const double x1 = dK1[(long)d1 * m1 + i1] * k2, x2 = k1 * band_sym(dK2, m2, i2, d2), ku = k1 * k2;
+    const double s1 = S1[(long)d1 * m1 + i1], s2 = band_sym(S2, m2, i2, d2);
+    acc[0] = fma(w * sg, a, acc[0]);
+    acc[1] = fma(w * aa, a, acc[1]);
+    acc[2] = fma(w * sg, x1, acc[2]);
+    acc[3] = fma(w * aa, x1, acc[3]);
+    acc[4] = fma(w * sg, x2, acc[4]);
+    acc[5] = fma(w * aa, x2, acc[5]);
+    acc[6] = fma(w * sg, ku, acc[6]);
+    acc[7] = fma(w * aa, ku, acc[7]);
+    acc[8] = fma(w * a, Z1[(long)d1 * m1 + i1] * s2, acc[8]);
+    acc[9] = fma(w * a, s1 * band_sym(Z2, m2, i2, d2), acc[9]);
+    acc[10] = fma(w * a, s1 * s2, acc[10]);
+  }
+#pragma unroll
+  for (int q = 0; q < 11; ++q) {
+    double tot = block_sum(acc[q], scratch);
+    __syncthreads();
+    if (threadIdx.x == 0 && tot != 0.0) __hip_atomic_fetch_add(out + q, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// q_P = phi*^T P^-1 phi* per test point from the block batches: (k+1)^2 basis pairs, every index pair inside the band
+template <int K>
+__global__ void predict_kron2d_var_kernel(const double* __restrict__ X, long n, const double* __restrict__ mesh1, int n1,
+                                          double id1, const double* __restrict__ mesh2, int n2, double id2, int m2,
+                                          const double* __restrict__ SigD, const double* __restrict__ SigS, int Bb,
+                                          double* __restrict__ qp) {
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double2 xv = *reinterpret_cast<const double2*>(X + 2 * p);
+  const int i1 = neighbour_index(xv.x, mesh1, n1, mesh1[0], id1);
+  const int i2 = neighbour_index(xv.y, mesh2, n2, mesh2[0], id2);
+  double v1[K + 1], v2[K + 1];
+  bspline_pieces<K>((xv.x - mesh1[i1]) * id1, v1);
+  bspline_pieces<K>((xv.y - mesh2[i2]) * id2, v2);
+  double q = 0.0;
+#pragma unroll
+  for (int a = 0; a <= K; ++a)
+#pragma unroll
+    for (int b = 0; b <= K; ++b) {
+      const long ra = (long)(i1 + K - a) * m2 + (i2 + K - b);
+      const double wa = v1[a] * v2[b];
+#pragma unroll
+      for (int a2 = 0; a2 <= K; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 <= K; ++b2) {
+          const long rb = (long)(i1 + K - a2) * m2 + (i2 + K - b2);
+          if (rb > ra) continue;   // lower triangle, doubled below
+          const double sg = sig_read(SigD, SigS, Bb, ra, rb);
+          q = fma((rb == ra ? 1.0 : 2.0) * wa * v1[a2] * v2[b2], sg, q);
+        }
+    }
+  qp[p] = q;
+}
+
 }  // namespace asvgp
 
 using namespace asvgp;
@@ -435,4 +555,50 @@ extern "C" int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double*
                                           as_stream(stream), Xnew, (long)n, mesh1, (int)n_mesh1, 1.0 / delta1, (int)m1, mesh2,
                                           (int)n_mesh2, 1.0 / delta2, (int)m2, alpha, S1, S2, mean, qk));
   return check_launch("predict_kron2d");
+}
+
+extern "C" int asvgp_blockband_to_blocks(const double* Lb, int64_t M, int64_t bw, int64_t Bb, double* diag, double* sub,
+                                         asvgp_stream_t stream) {
+  if (!Lb || !diag || M < 1 || bw < 0 || Bb < bw || Bb < 1 || (Bb % 32) != 0) { set_error("blockband_to_blocks: bad argument (Bb must be a multiple of 32 and >= bw)"); return ASVGP_ERR_BAD_ARG; }
+  const long nblk = (M + Bb - 1) / Bb;
+  if (nblk > 1 && !sub) { set_error("blockband_to_blocks: sub is null"); return ASVGP_ERR_BAD_ARG; }
+  const long total = (2 * nblk - 1) * Bb * Bb;
+  long blocks = (total + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(bb_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), Lb, (long)M, (int)bw, (long)(bw + 1),
+                     (int)Bb, nblk, diag, sub);
+  return check_launch("blockband_to_blocks");
+}
+
+extern "C" int asvgp_kron_grad_terms(const double* SigD, const double* SigS, int64_t Bb, const double* alpha,
+                                     const double* Ablk, const double* K1, const double* K2, const double* dK1,
+                                     const double* dK2, const double* S1, const double* S2, const double* Z1,
+                                     const double* Z2, int k, int64_t m1, int64_t m2, double* out11, asvgp_stream_t stream) {
+  if (!SigD || !alpha || !Ablk || !K1 || !K2 || !dK1 || !dK2 || !S1 || !S2 || !Z1 || !Z2 || !out11 || k < 1 || k > ASVGP_MAX_ORDER ||
+      m1 < 1 || m2 < 1 || Bb < (int64_t)k * m2 + k) { set_error("kron_grad_terms: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  if (((m1 * m2 + Bb - 1) / Bb) > 1 && !SigS) { set_error("kron_grad_terms: SigS is null"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out11, 0, 11 * sizeof(double), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  const long total = (long)m1 * m2 * kron_noff(k);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(kron_grad_terms_kernel, dim3((unsigned)blocks), dim3(256), 0, st, SigD, SigS, (int)Bb, alpha, Ablk, K1, K2,
+                     dK1, dK2, S1, S2, Z1, Z2, k, (int)m1, (int)m2, out11);
+  return check_launch("kron_grad_terms");
+}
+
+extern "C" int asvgp_predict_kron2d_var(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
+                                        const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                        const double* SigD, const double* SigS, int64_t Bb, double* qp,
+                                        asvgp_stream_t stream) {
+  if ((n > 0 && !Xnew) || !mesh1 || !mesh2 || !SigD || !qp || n < 0 || order < 1 || order > ASVGP_MAX_ORDER ||
+      Bb < (int64_t)order * m2 + order) { set_error("predict_kron2d_var: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  if (n == 0) return ASVGP_OK;
+  if ((reinterpret_cast<uintptr_t>(Xnew) & 15) != 0) { set_error("predict_kron2d_var: Xnew must be 16-byte aligned (n,2) row-major"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  KRON_DISPATCH(order, hipLaunchKernelGGL(predict_kron2d_var_kernel<K>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, Xnew,
+                                          (long)n, mesh1, (int)n_mesh1, 1.0 / delta1, mesh2, (int)n_mesh2, 1.0 / delta2, (int)m2,
+                                          SigD, SigS, (int)Bb, qp));
+  return check_launch("predict_kron2d_var");
 }

@@ -355,10 +355,75 @@ class GPR_kron:
             ps += [kern.variance, kern.lengthscales]
         return ps + [self.likelihood.variance]
 
+    def _selinv(self, f):
+        """Sigma = P^-1 on the band, as dense super-blocks (asvgp_blockband_to_blocks + the block recursion with library
+        TRSM / GEMM): SigD[i] = Sigma_ii, SigS[i] = Sigma_{i+1,i}, block size Bb = bw rounded up to a multiple of 32."""
+        lib = get_lib()
+        dev = self._stats.device
+        bw, M = f["bw"], self.Mtot
+        Bb = ((max(bw, 1) + 31) // 32) * 32
+        nblk = (M + Bb - 1) // Bb
+        diag = torch.empty((nblk, Bb, Bb), dtype=torch.float64, device=dev)
+        sub = torch.empty((max(nblk - 1, 1), Bb, Bb), dtype=torch.float64, device=dev)
+        check(lib.asvgp_blockband_to_blocks(f["Lb"].data_ptr(), M, bw, Bb, diag.data_ptr(), sub.data_ptr(), stream_ptr()),
+              "blockband_to_blocks")
+        eye = torch.eye(Bb, dtype=torch.float64, device=dev).expand(nblk, Bb, Bb)
+        Linv = torch.linalg.solve_triangular(diag, eye, upper=False)
+        Dinv = Linv.transpose(1, 2) @ Linv                       # (L_ii L_ii^T)^-1
+        SigD, SigS = torch.empty_like(diag), torch.zeros_like(sub)
+        SigD[nblk - 1] = Dinv[nblk - 1]
+        if nblk > 1:
+            G = sub @ Linv[:-1]                                   # G_i = L_{i+1,i} L_ii^-1
+            for i in range(nblk - 2, -1, -1):
+                SigS[i] = -(SigD[i + 1] @ G[i])
+                SigD[i] = Dinv[i] - G[i].t() @ SigS[i]
+        return SigD, SigS, Bb
+
+    def elbo_and_grad(self):
+        """(elbo, d elbo / d [v1, l1, v2, l2, sigma2]) - the gradient TF autodiff gives the reference (eNATL60.py:89), here
+        analytic: tr(P^-1 dKuu), alpha^T dKuu alpha and tr(Kuu^-1 dKuu Kuu^-1 A) contracted over the block band
+        (asvgp_kron_grad_terms) from the band-restricted inverse of P and the two 1-D inverse bands."""
+        from . import banded
+        lib = get_lib()
+        f = self._factor(want_alpha=True)
+        SigD, SigS, Bb = self._selinv(f)
+        s, N = f["s"], float(self.num_data)
+        vs = [float(k.variance) for k in self.kernels]
+        ls = [float(k.lengthscales) for k in self.kernels]
+        dKs, Zs = [], []
+        for feat, kern, v, l in zip(self.inducing_features, self.kernels, vs, ls):
+            _, dK = feat.make_Kuu(kern, with_dl=True)
+            dKs.append(dK)
+            h = 1e-5 * l                                         # band of K^-1 dK K^-1 = -d band(K^-1) / dl, central difference on the 1-D factor
+            Sp = banded.inverse_from_cholesky_band(banded.cholesky_band(feat.make_Kuu(type(kern)(variance=v, lengthscales=l + h))))
+            Sm = banded.inverse_from_cholesky_band(banded.cholesky_band(feat.make_Kuu(type(kern)(variance=v, lengthscales=l - h))))
+            Zs.append((Sm - Sp) / (2 * h))
+        out = torch.empty(11, dtype=torch.float64, device=self._stats.device)
+        b1, b2 = self.bases
+        check(lib.asvgp_kron_grad_terms(SigD.data_ptr(), SigS.data_ptr(), Bb, f["alpha"].data_ptr(),
+                                        self.KufKfu_blockband.data_ptr(), f["Ks"][0].data_ptr(), f["Ks"][1].data_ptr(),
+                                        dKs[0].data_ptr(), dKs[1].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(),
+                                        Zs[0].data_ptr(), Zs[1].data_ptr(), self.order, b1.m, b2.m, out.data_ptr(),
+                                        stream_ptr()), "kron_grad_terms")
+        tPA, aAa, tPX1, aX1a, tPX2, aX2a, tPK, aKa, tZ1A, tZ2A, tSA = out.tolist()
+        trK = [float(banded.band_trace_sym(S, dK)) for S, dK in zip(f["Ss"], dKs)]      # tr(K_i^-1 dK_i)
+        cc = float((f["c"] ** 2).sum())
+        yy = float(self.tr_yTy)
+        vprod = vs[0] * vs[1]
+        elbo = (-0.5 * N * math.log(2 * math.pi * s) - 0.5 * float(f["logdet_P"]) + 0.5 * float(f["logdet_K"]) - 0.5 * yy / s
+                + 0.5 * cc - 0.5 * N * vprod / s + 0.5 * tSA / s)
+        mo = [b2.m, b1.m]                                        # size of the OTHER factor: tr((K1^-1 dK1) (x) I_m2) = m2 tr(K1^-1 dK1)
+        g = np.zeros(5)
+        for i, (tPX, aXa, tZA) in enumerate(((tPX1, aX1a, tZ1A), (tPX2, aX2a, tZ2A))):
+            g[2 * i + 1] = -0.5 * tPX + 0.5 * mo[i] * trK[i] - 0.5 * aXa - 0.5 * tZA / s            # d / d l_i
+            g[2 * i] = (0.5 * tPK - 0.5 * self.Mtot + 0.5 * aKa + 0.5 * tSA / s) / vs[i] - 0.5 * N * vprod / (vs[i] * s)   # d / d v_i  (dKuu = -Kuu / v_i)
+        g[4] = (-0.5 * N / s + 0.5 * tPA / s ** 2 - cc / s + 0.5 * aAa / s ** 2 + 0.5 * yy / s ** 2 + 0.5 * N * vprod / s ** 2
+                - 0.5 * tSA / s ** 2)
+        return elbo, g
+
     def fit(self, maxiter=200):
-        """eNATL60.py:88-89 opt.minimize(model_kron.training_loss, ...): L-BFGS-B on the unconstrained parameters.  Interim:
-        the gradient is a 2-point finite difference of elbo() (the analytic one needs the band-restricted inverse of P,
-        DESIGN.md 4.4), i.e. 2 d + 2 bound evaluations per iteration."""
+        """eNATL60.py:88-89 opt.minimize(model_kron.training_loss, ...): L-BFGS-B on the unconstrained parameters with the
+        analytic gradient (one band factorisation + one selected inverse per evaluation)."""
         from scipy.optimize import minimize
         params = self.trainable_parameters
 
@@ -366,14 +431,16 @@ class GPR_kron:
             for p, ui in zip(params, u):
                 p.unconstrained = float(ui)
             try:
-                return -float(self.elbo().item())
+                e, g = self.elbo_and_grad()
             except NotPositiveDefiniteError:
-                return np.inf
+                return np.inf, np.zeros(len(u))
+            return -e, -g * np.array([p.dtheta_du() for p in params])
 
         u0 = np.array([p.unconstrained for p in params])
-        res = minimize(fun, u0, jac="2-point", method="L-BFGS-B", options=dict(maxiter=maxiter, eps=1e-6))
+        res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
         for p, ui in zip(params, res.x):
             p.unconstrained = float(ui)
+        self._post = None
         return res
 
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
@@ -383,8 +450,6 @@ class GPR_kron:
             raise NotImplementedError
         mean, var = self.predict_f_device(Xnew)
         return mean.cpu().numpy(), var.cpu().numpy()
-
-    predict_f_sparse = predict_f                              # gpr.py:336-359 computes the same moments with CHOLMOD
 
     def predict_f_sparse(self, Xnew, full_cov=False, full_output_cov=False):
         """gpr.py:336-359: the CHOLMOD route of the same posterior; here both entry points share the band solver.
@@ -396,53 +461,29 @@ class GPR_kron:
         lib = get_lib()
         key = self.theta()
         if self._post is None or self._post[0] != key:
-            self._post = (key, self._factor(want_alpha=True))
-        f = self._post[1]
+            f = self._factor(want_alpha=True)
+            self._post = (key, f, self._selinv(f))
+        f, (SigD, SigS, Bb) = self._post[1], self._post[2]
         b1, b2 = self.bases
         X = _to_device(Xnew, self._stats.device)
         n = X.shape[0]
         mean = torch.empty(n, dtype=torch.float64, device=X.device)
         qk = torch.empty(n, dtype=torch.float64, device=X.device)
+        qp = torch.empty(n, dtype=torch.float64, device=X.device)
         check(lib.asvgp_predict_kron2d(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np, b1.m,
                                        b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
                                        f["alpha"].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(), mean.data_ptr(),
                                        qk.data_ptr(), stream_ptr()), "predict_kron2d")
+        # phi*^T P^-1 phi* (= |L_P^-1 phi*|^2, gpr.py:320-330) straight from the band-restricted inverse
+        check(lib.asvgp_predict_kron2d_var(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np,
+                                           b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                                           SigD.data_ptr(), SigS.data_ptr(), Bb, qp.data_ptr(), stream_ptr()),
+              "predict_kron2d_var")
         vprod = 1.0
         for kern in self.kernels:
             vprod *= float(kern.variance)
-        qp = self._quad_P(X, f, chunk)
         var = vprod + qp - qk
         return mean.reshape(-1, 1), var.reshape(-1, 1)
-
-    def _quad_P(self, X, f, chunk):
-        """phi*^T P^-1 phi* = |L_P^-1 phi*|^2 (gpr.py:320-330), by multi-right-hand-side forward substitution on the
-        wide-band factor, a chunk of test points at a time (first version: blocked solves through torch on unpacked
-        diagonal blocks; the planned replacement is the band-restricted selected inverse)."""
-        from . import kronecker
-        Lb, bw, M = f["Lb"].view(self.Mtot, f["bw"] + 1), f["bw"], self.Mtot
-        out = torch.empty(X.shape[0], dtype=torch.float64, device=X.device)
-        NB = 256
-        for c0 in range(0, X.shape[0], chunk):
-            Xc = X[c0:c0 + chunk]
-            rows, cols, data = kronecker.make_kvs_coo(self.bases, Xc)
-            Z = torch.zeros((M, Xc.shape[0]), dtype=torch.float64, device=X.device)
-            Z.index_put_((rows, cols), data, accumulate=True)
-            r_first = int(rows.min().item())
-            for j0 in range((r_first // NB) * NB, M, NB):
-                j1 = min(j0 + NB, M)
-                nb = j1 - j0
-                # unpack the nb x nb diagonal block and the (<= bw + nb) x nb panel below it from band storage
-                hi = min(j1 + bw, M)
-                r = torch.arange(j0, hi, device=X.device).reshape(-1, 1)
-                cc = torch.arange(j0, j1, device=X.device).reshape(1, -1)
-                d = r - cc
-                ok = (d >= 0) & (d <= bw)
-                blk = torch.where(ok, Lb[cc.expand_as(d), d.clamp(0, bw)], torch.zeros((), dtype=torch.float64, device=X.device))
-                Z[j0:j1] = torch.linalg.solve_triangular(blk[:nb], Z[j0:j1], upper=False)
-                if hi > j1:
-                    Z[j1:hi] -= blk[nb:] @ Z[j0:j1]
-            out[c0:c0 + chunk] = (Z * Z).sum(0)
-        return out
 
 
 class GPR_additive:

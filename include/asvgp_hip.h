@@ -202,6 +202,26 @@ int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int
                          const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order, const double* alpha,
                          const double* S1, const double* S2, double* mean, double* qk, asvgp_stream_t stream);
 
+/* Selected inverse of P = Kuu + KufKfu/sigma2 on the band (what the gradient of gpr.py:282-308 and the predictive variance
+ * of gpr.py:319-330 need of P^-1), through dense super-blocks of size Bb (a multiple of 32, >= bw): the band factor is
+ * block bidiagonal.  asvgp_blockband_to_blocks unpacks it into diag[nblk][Bb][Bb] (lower triangular, identity-padded) and
+ * sub[nblk-1][Bb][Bb] (L[(i+1)Bb + r, i Bb + c]); the caller runs the block recursion
+ *   G_i = sub_i diag_i^-1,  SigS_i = -SigD_{i+1} G_i,  SigD_i = (diag_i diag_i^T)^-1 - G_i^T SigS_i
+ * with library GEMM / TRSM calls and hands SigD / SigS (same shapes) to the two kernels below. */
+int asvgp_blockband_to_blocks(const double* Lb, int64_t M, int64_t bw, int64_t Bb, double* diag, double* sub,
+                              asvgp_stream_t stream);
+/* out11 (overwritten) = [tr(Sig A), a^T A a, tr(Sig X1), a^T X1 a, tr(Sig X2), a^T X2 a, tr(Sig Kuu), a^T Kuu a,
+ * tr((Z1 (x) S2) A), tr((S1 (x) Z2) A), tr((S1 (x) S2) A)] with X1 = dK1 (x) K2, X2 = K1 (x) dK2, a = alpha; every band
+ * argument is a 1-D lower band (k+1, m_i); Ablk as written by asvgp_phi_accumulate_kron2d. */
+int asvgp_kron_grad_terms(const double* SigD, const double* SigS, int64_t Bb, const double* alpha, const double* Ablk,
+                          const double* K1, const double* K2, const double* dK1, const double* dK2, const double* S1,
+                          const double* S2, const double* Z1, const double* Z2, int k, int64_t m1, int64_t m2,
+                          double* out11, asvgp_stream_t stream);
+/* qp[i] = phi*(x_i)^T P^-1 phi*(x_i): (k+1)^4 reads of the block batches per test point instead of a triangular solve */
+int asvgp_predict_kron2d_var(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
+                             const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                             const double* SigD, const double* SigS, int64_t Bb, double* qp, asvgp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Additive model (GPR_additive, gpr.py:139-236): Kuf = vstack(Kuf_1 .. Kuf_d), so Kuf Kuf^T (gpr.py:170-171) has the
  * 1-D banded blocks of asvgp_phi_accumulate_1d on its diagonal and dense cross blocks

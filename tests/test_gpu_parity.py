@@ -896,3 +896,53 @@ def test_kron_full_size_properties_config4_and_config5_shapes(A):
     assert np.isfinite(ek)
     mean, var = mk.predict_f(Xk[:3000])
     assert E.MSE(yk[:3000], mean) < 5e-3 and (var > 0).all()
+
+
+@pytest.mark.parametrize("order,m1,m2,N", [(3, 10, 11, 1500), (2, 30, 8, 2500), (4, 14, 13, 3000)])
+def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
+    """Band-restricted inverse of P through dense super-blocks vs the dense inverse; analytic gradient of the bound
+    (TF autodiff in the reference, eNATL60.py:89) vs central differences of the dense oracle."""
+    rng = np.random.default_rng(m1 * 31 + m2)
+    X = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(-0.999, 1.999, N)], axis=1)
+    y = (np.sin(6 * X[:, :1]) * np.cos(2 * X[:, 1:]) + 0.1 * rng.normal(size=(N, 1)))
+    B = getattr(A, "B%dSpline" % order)
+    bases = [B(0, 1, m1), B(-1, 2, m2)]
+    th = [(1.1, 0.3), (0.7, 0.6)]
+    s = 0.05
+    kerns = [A.Matern32(variance=th[0][0], lengthscales=th[0][1]), A.Matern32(variance=th[1][0], lengthscales=th[1][1])]
+    model = A.GPR_kron((X, y), kerns, bases)
+    model.likelihood.variance.assign(s)
+    obases = [O.Basis(order, 0, 1, m1), O.Basis(order, -1, 2, m2)]
+    oe, parts = O.elbo_kron(obases, [1, 1], th, s, X, y)
+    # selected inverse
+    f = model._factor(want_alpha=True)
+    SigD, SigS, Bb = model._selinv(f)
+    Pinv = np.linalg.inv(parts["P"])
+    M = m1 * m2
+    nblk = (M + Bb - 1) // Bb
+    assert nblk >= 2
+    pad = nblk * Bb
+    Pi = np.eye(pad)
+    Pi[:M, :M] = Pinv
+    sc = np.max(np.abs(Pinv))
+    for i in range(nblk):
+        np.testing.assert_allclose(SigD[i].cpu().numpy(), Pi[i * Bb:(i + 1) * Bb, i * Bb:(i + 1) * Bb], rtol=0, atol=1e-9 * sc)
+        if i + 1 < nblk:
+            np.testing.assert_allclose(SigS[i].cpu().numpy(), Pi[(i + 1) * Bb:(i + 2) * Bb, i * Bb:(i + 1) * Bb], rtol=0, atol=1e-9 * sc)
+    # bound and gradient
+    e, g = model.elbo_and_grad()
+    yy = float(np.sum(y * y))
+    assert abs(e - oe) <= elbo_tol(oe, N, th[0][0] * th[1][0], s, yy, bcr=True)
+    assert abs(e - model.elbo().item()) <= 1e-9 * abs(e)
+
+    def val(p):
+        return O.elbo_kron(obases, [1, 1], [(p[0], p[1]), (p[2], p[3])], p[4], X, y)[0]
+    p0 = np.array([th[0][0], th[0][1], th[1][0], th[1][1], s])
+    fd = np.zeros(5)
+    for i in range(5):
+        h = 1e-5 * p0[i]
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += h
+        pm[i] -= h
+        fd[i] = (val(pp) - val(pm)) / (2 * h)
+    np.testing.assert_allclose(g, fd, rtol=2e-5, atol=2e-5 * np.max(np.abs(fd)))

@@ -21,3 +21,13 @@ Xs = torch.from_numpy(rng.uniform(0.01, 0.99, size=(10000, 2))).cuda()
 mean, var = model.predict_f_device(Xs); torch.cuda.synchronize(); t6 = time.perf_counter()
 print("N=%d M_tot=%d bw=%d | construct %.1f ms | phi pass %.2f ms (%.0f Mpoints/s) | elbo %.1f ms | predict 10k (incl. factor) %.1f ms | elbo=%.6f" % (
     N, m * m, model.true_bandwidth, (t1 - t0) * 1e3, (t3 - t2) * 1e3, N / (t3 - t2) / 1e6, (t5 - t4) * 1e3, (t6 - t5) * 1e3, e))
+mean, var = model.predict_f_device(Xs); torch.cuda.synchronize(); t7 = time.perf_counter()
+Xl = torch.from_numpy(rng.uniform(0.01, 0.99, size=(1_000_000, 2))).cuda()
+torch.cuda.synchronize(); t8 = time.perf_counter()
+mean, var = model.predict_f_device(Xl); torch.cuda.synchronize(); t9 = time.perf_counter()
+eg = model.elbo_and_grad(); torch.cuda.synchronize(); t10 = time.perf_counter()
+eg = model.elbo_and_grad(); torch.cuda.synchronize(); t11 = time.perf_counter()
+f = model._factor(want_alpha=True); torch.cuda.synchronize(); t12 = time.perf_counter()
+model._selinv(f); torch.cuda.synchronize(); t13 = time.perf_counter()
+print("predict 10k (cached factor) %.2f ms | predict 1M %.1f ms | elbo+grad %.1f ms | factor %.1f ms | selected inverse %.1f ms | grad %s" % (
+    (t7 - t6) * 1e3, (t9 - t8) * 1e3, (t11 - t10) * 1e3, (t12 - t11) * 1e3, (t13 - t12) * 1e3, np.round(eg[1], 3)))
