@@ -61,6 +61,132 @@ __global__ __launch_bounds__(256) void phi_kron2d_kernel(const double* __restric
   if (threadIdx.x == 0 && tot != 0.0) __hip_atomic_fetch_add(yy_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cell-sorted Khatri-Rao Phi pass.  The caller sorts the points by 2-D cell id c = i1 * (n2 - 1) + i2 (asvgp_kron_cell_index
+// + a device radix sort) and passes the cell offsets.  All points of a cell touch the SAME (k+1)^2 (k+1)^2 / ~2 block-band
+// entries, so one workgroup per cell stages, per point, the products v1[a] v1[a2] (a <= a2), v2[b] v2[b2] and v1[a], v2[b] y
+// in the LDS, and thread t owns output entry t: it walks the staged points with two LDS reads and one FMA each and issues
+// ONE global atomic per entry and cell - 136 atomics per cell instead of per point (k = 3).
+// ---------------------------------------------------------------------------------------------------------
+template <int K> struct KronOut {
+  static constexpr int NP1 = (K + 1) * (K + 2) / 2;      // (a, a2), a <= a2
+  static constexpr int NP2 = (K + 1) * (K + 1);          // (b, b2)
+  static constexpr int NREC = NP1 + NP2 + 2 * (K + 1);   // doubles staged per point
+  static constexpr int NBAND = NP1 * NP2 - (K + 1) * (K * (K + 1) / 2);   // minus (d1 = 0, d2 < 0)
+  static constexpr int NOUT = NBAND + NP2;               // + the (k+1)^2 rhs entries
+};
+template <int K> constexpr int kron_chunk() { return K <= 4 ? 128 : 64; }   // points staged per pass (static LDS <= 64 KB)
+
+template <int K>
+__global__ __launch_bounds__(256) void phi_kron2d_cells_kernel(
+    const double* __restrict__ X, const double* __restrict__ y, const long long* __restrict__ cell_start, int ncell,
+    const double* __restrict__ mesh1, double id1, int m1, const double* __restrict__ mesh2, int n2, double id2, int m2,
+    double* __restrict__ Ablk, double* __restrict__ rhs, double* __restrict__ yy_out) {
+  using KO = KronOut<K>;
+  constexpr int CH = kron_chunk<K>();
+  constexpr int NPT = (KO::NOUT + 255) / 256;   // output entries per thread
+  __shared__ double stage[CH * KO::NREC];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  const long Mtot = (long)m1 * m2;
+  // decode this thread's output entries once: entry o = tid + 256 j; band entries first, then the (k+1)^2 rhs entries
+  int f1[NPT], f2[NPT];      // staged fields to multiply
+  long tgt[NPT];             // offset into Ablk (band) or rhs, without the cell's i1 * m2 + i2
+  int kind[NPT];             // 0 none, 1 band, 2 rhs
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int o = tid + 256 * j;
+    kind[j] = 0; f1[j] = 0; f2[j] = 0; tgt[j] = 0;
+    if (o < KO::NBAND) {
+      int e = 0, p1 = 0;
+      for (int a = 0; a <= K; ++a)
+        for (int a2 = a; a2 <= K; ++a2, ++p1)
+          for (int b = 0; b <= K; ++b)
+            for (int b2 = 0; b2 <= K; ++b2) {
+              if (a2 == a && b2 < b) continue;
+              if (e == o) {
+                kind[j] = 1; f1[j] = p1; f2[j] = KO::NP1 + b * (K + 1) + b2;
+                tgt[j] = (long)kron_off(K, a2 - a, b2 - b) * Mtot + (long)(K - a2) * m2 + (K - b2);
+              }
+              ++e;
+            }
+    } else if (o < KO::NOUT) {
+      const int a = (o - KO::NBAND) / (K + 1), b = (o - KO::NBAND) % (K + 1);
+      kind[j] = 2; f1[j] = KO::NP1 + KO::NP2 + a; f2[j] = KO::NP1 + KO::NP2 + K + 1 + b;
+      tgt[j] = (long)(K - a) * m2 + (K - b);
+    }
+  }
+  double yy = 0.0;
+  for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
+    const long long p0 = cell_start[c], p1e = cell_start[c + 1];
+    if (p1e <= p0) continue;   // workgroup-uniform
+    const int i1 = c / (n2 - 1), i2 = c - i1 * (n2 - 1);
+    const double u1 = mesh1[i1], u2 = mesh2[i2];
+    double acc[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) acc[j] = 0.0;
+    for (long long base = p0; base < p1e; base += CH) {
+      const int np = (int)((p1e - base < CH) ? (p1e - base) : CH);
+      __syncthreads();
+      if (tid < np) {
+        const double2 xv = *reinterpret_cast<const double2*>(X + 2 * (base + tid));
+        const double yv = y[base + tid];
+        double v1[K + 1], v2[K + 1];
+        bspline_pieces<K>((xv.x - u1) * id1, v1);
+        bspline_pieces<K>((xv.y - u2) * id2, v2);
+        double* rec = stage + tid;   // field-major: field f of point t at stage[f * CH + t] (conflict-free writes)
+        int f = 0;
+#pragma unroll
+        for (int a = 0; a <= K; ++a)
+#pragma unroll
+          for (int a2 = a; a2 <= K; ++a2) rec[(f++) * CH] = v1[a] * v1[a2];
+#pragma unroll
+        for (int b = 0; b <= K; ++b)
+#pragma unroll
+          for (int b2 = 0; b2 <= K; ++b2) rec[(f++) * CH] = v2[b] * v2[b2];
+#pragma unroll
+        for (int a = 0; a <= K; ++a) rec[(f++) * CH] = v1[a];
+#pragma unroll
+        for (int b = 0; b <= K; ++b) rec[(f++) * CH] = v2[b] * yv;
+        yy = fma(yv, yv, yy);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NPT; ++j)
+        if (kind[j]) {
+          const double* g1 = stage + f1[j] * CH;
+          const double* g2 = stage + f2[j] * CH;
+          double t0 = 0.0, t1 = 0.0;
+          int t = 0;
+          for (; t + 1 < np; t += 2) { t0 = fma(g1[t], g2[t], t0); t1 = fma(g1[t + 1], g2[t + 1], t1); }
+          if (t < np) t0 = fma(g1[t], g2[t], t0);
+          acc[j] += t0 + t1;
+        }
+    }
+    const long cell_off = (long)i1 * m2 + i2;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      if (kind[j] == 1 && acc[j] != 0.0) __hip_atomic_fetch_add(Ablk + tgt[j] + cell_off, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (kind[j] == 2 && acc[j] != 0.0) __hip_atomic_fetch_add(rhs + tgt[j] + cell_off, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  double tot = block_sum(yy, scratch);
+  if (tid == 0 && tot != 0.0) __hip_atomic_fetch_add(yy_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 2-D cell id per point: i1 * (n2 - 1) + i2  (basis.py:58-59 index rule per dimension)
+__global__ void kron_cell_index_kernel(const double* __restrict__ X, long N, const double* __restrict__ mesh1, int n1,
+                                       double id1, const double* __restrict__ mesh2, int n2, double id2,
+                                       int* __restrict__ cell) {
+  long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double2 xv = *reinterpret_cast<const double2*>(X + 2 * n);
+  const int i1 = neighbour_index(xv.x, mesh1, n1, mesh1[0], id1);
+  const int i2 = neighbour_index(xv.y, mesh2, n2, mesh2[0], id2);
+  cell[n] = i1 * (n2 - 1) + i2;
+}
+
 // Khatri-Rao COO triplets (kronecker.make_kvs_sparse): for point n, entry e = a*(K+1)+b: row, value
 template <int K>
 __global__ void kron_evaluate_kernel(const double* __restrict__ X, long N, const double* __restrict__ mesh1, int n1,
@@ -601,4 +727,45 @@ extern "C" int asvgp_predict_kron2d_var(const double* Xnew, int64_t n, const dou
                                           (long)n, mesh1, (int)n_mesh1, 1.0 / delta1, mesh2, (int)n_mesh2, 1.0 / delta2, (int)m2,
                                           SigD, SigS, (int)Bb, qp));
   return check_launch("predict_kron2d_var");
+}
+
+extern "C" int asvgp_kron_cell_index(const double* X, int64_t N, const double* mesh1, int64_t n_mesh1, double delta1,
+                                     const double* mesh2, int64_t n_mesh2, double delta2, int* cell, asvgp_stream_t stream) {
+  if ((N > 0 && (!X || !cell)) || !mesh1 || !mesh2 || N < 0 || n_mesh1 < 2 || n_mesh2 < 2 || !(delta1 > 0) || !(delta2 > 0) ||
+      (n_mesh1 - 1) * (n_mesh2 - 1) > 0x7fffffff) { set_error("kron_cell_index: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  if (N == 0) return ASVGP_OK;
+  if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) { set_error("kron_cell_index: X must be 16-byte aligned (N,2) row-major"); return ASVGP_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(kron_cell_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), X, (long)N, mesh1,
+                     (int)n_mesh1, 1.0 / delta1, mesh2, (int)n_mesh2, 1.0 / delta2, cell);
+  return check_launch("kron_cell_index");
+}
+
+extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double* ys, int64_t N, const int64_t* cell_start,
+                                                  const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
+                                                  const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                                  double* stats, asvgp_stream_t stream) {
+  if ((N > 0 && (!Xs || !ys)) || !cell_start || !mesh1 || !mesh2 || !stats || N < 0 || !(delta1 > 0) || !(delta2 > 0) ||
+      n_mesh1 != m1 - order + 1 || n_mesh2 != m2 - order + 1 || n_mesh1 < 2 || n_mesh2 < 2) {
+    set_error("phi_accumulate_kron2d_sorted: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  if (order < 1 || order > ASVGP_MAX_ORDER) { set_error("phi_accumulate_kron2d_sorted: order %d unsupported", order); return ASVGP_ERR_UNSUPPORTED; }
+  if ((reinterpret_cast<uintptr_t>(Xs) & 15) != 0) { set_error("phi_accumulate_kron2d_sorted: Xs must be 16-byte aligned (N,2) row-major"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  const size_t nd = asvgp_kron_stats_doubles(m1, m2, order);
+  hipError_t e = hipMemsetAsync(stats, 0, nd * sizeof(double), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  if (N == 0) return ASVGP_OK;
+  const long Mtot = (long)m1 * m2;
+  double* Ablk = stats;
+  double* rhs = stats + (size_t)kron_noff(order) * Mtot;
+  double* yy = rhs + Mtot;
+  const long ncell = (long)(n_mesh1 - 1) * (n_mesh2 - 1);
+  long blocks = ncell < 4096 ? ncell : 4096;
+  KRON_DISPATCH(order, {
+    hipLaunchKernelGGL(phi_kron2d_cells_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, st, Xs, ys,
+                       reinterpret_cast<const long long*>(cell_start), (int)ncell, mesh1, 1.0 / delta1, (int)m1, mesh2,
+                       (int)n_mesh2, 1.0 / delta2, (int)m2, Ablk, rhs, yy);
+  });
+  return check_launch("phi_accumulate_kron2d_sorted");
 }

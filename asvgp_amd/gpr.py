@@ -278,12 +278,40 @@ class GPR_kron:
         self._info = torch.zeros(1, dtype=torch.int32, device=dev)
         self._post = None
 
-    def phi_pass(self):
+    def _sort_by_cell(self):
+        """Rows of (X, y) permuted into 2-D cell order + the cell offsets (the data are immutable: sorted once)."""
+        lib = get_lib()
         b1, b2 = self.bases
-        check(get_lib().asvgp_phi_accumulate_kron2d(self.X.data_ptr(), self.y.data_ptr(), self.n, b1.mesh.data_ptr(),
-                                                    b1.mesh.shape[0], b1.delta_np, b1.m, b2.mesh.data_ptr(),
-                                                    b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
-                                                    self._stats.data_ptr(), stream_ptr()), "phi_accumulate_kron2d")
+        dev = self._stats.device
+        cell = torch.empty(self.n, dtype=torch.int32, device=dev)
+        check(lib.asvgp_kron_cell_index(self.X.data_ptr(), self.n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np,
+                                        b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, cell.data_ptr(), stream_ptr()),
+              "kron_cell_index")
+        ncell = (b1.mesh.shape[0] - 1) * (b2.mesh.shape[0] - 1)
+        order = torch.argsort(cell)
+        counts = torch.bincount(cell, minlength=ncell)
+        start = torch.zeros(ncell + 1, dtype=torch.int64, device=dev)
+        start[1:] = torch.cumsum(counts, 0)
+        return self.X[order].contiguous(), self.y[order].contiguous(), start
+
+    def phi_pass(self, sorted_cells=True):
+        """The N-dependent pass -> [block band | Kuf y | y^T y].  Default: cell-sorted accumulation (one atomic per band entry and
+        cell); sorted_cells=False: the per-point atomic kernel (asvgp_phi_accumulate_kron2d), same statistics."""
+        b1, b2 = self.bases
+        lib = get_lib()
+        if sorted_cells and self.n > 0:
+            if getattr(self, "_sorted", None) is None:
+                self._sorted = self._sort_by_cell()
+            Xs, ys, start = self._sorted
+            check(lib.asvgp_phi_accumulate_kron2d_sorted(Xs.data_ptr(), ys.data_ptr(), self.n, start.data_ptr(),
+                                                         b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np, b1.m,
+                                                         b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                                                         self._stats.data_ptr(), stream_ptr()), "phi_accumulate_kron2d_sorted")
+        else:
+            check(lib.asvgp_phi_accumulate_kron2d(self.X.data_ptr(), self.y.data_ptr(), self.n, b1.mesh.data_ptr(),
+                                                  b1.mesh.shape[0], b1.delta_np, b1.m, b2.mesh.data_ptr(),
+                                                  b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                                                  self._stats.data_ptr(), stream_ptr()), "phi_accumulate_kron2d")
         return self._stats
 
     @property

@@ -202,6 +202,16 @@ int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int
                          const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order, const double* alpha,
                          const double* S1, const double* S2, double* mean, double* qk, asvgp_stream_t stream);
 
+/* The same statistics from CELL-SORTED points: Xs, ys are the rows of X, y permuted so that the 2-D cell id
+ * c = i1 * (n_mesh2 - 1) + i2 (asvgp_kron_cell_index; basis.py:58-59 per dimension) is non-decreasing, cell_start[c] (int64,
+ * n_cells + 1 entries) the first row of cell c.  One global atomic per block-band entry and CELL instead of per point. */
+int asvgp_kron_cell_index(const double* X, int64_t N, const double* mesh1, int64_t n_mesh1, double delta1,
+                          const double* mesh2, int64_t n_mesh2, double delta2, int* cell, asvgp_stream_t stream);
+int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double* ys, int64_t N, const int64_t* cell_start,
+                                       const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
+                                       const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                       double* stats, asvgp_stream_t stream);
+
 /* Selected inverse of P = Kuu + KufKfu/sigma2 on the band (what the gradient of gpr.py:282-308 and the predictive variance
  * of gpr.py:319-330 need of P^-1), through dense super-blocks of size Bb (a multiple of 32, >= bw): the band factor is
  * block bidiagonal.  asvgp_blockband_to_blocks unpacks it into diag[nblk][Bb][Bb] (lower triangular, identity-padded) and

@@ -946,3 +946,32 @@ def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
         pm[i] -= h
         fd[i] = (val(pp) - val(pm)) / (2 * h)
     np.testing.assert_allclose(g, fd, rtol=2e-5, atol=2e-5 * np.max(np.abs(fd)))
+
+
+@pytest.mark.parametrize("order,m1,m2,N", [(1, 7, 9, 3000), (2, 9, 8, 4001), (3, 12, 10, 20000), (4, 14, 15, 30000), (5, 16, 15, 8000),
+                                           (6, 17, 18, 6000)])
+def test_kron_cell_sorted_phi_pass_equals_per_point_pass(A, order, m1, m2, N):
+    """The cell-sorted Khatri-Rao accumulation (default) and the per-point atomic kernel give the same block band, Kuf y
+    and y^T y; the cell ids follow the per-dimension index rule (basis.py:58-59) bit for bit."""
+    rng = np.random.default_rng(order + m1)
+    X = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(-0.999, 1.999, N)], axis=1)
+    X[:50, 0] = 0.5                                   # a heavy cell column
+    y = rng.normal(size=(N, 1))
+    B = getattr(A, "B%dSpline" % order)
+    bases = [B(0, 1, m1), B(-1, 2, m2)]
+    model = A.GPR_kron((X, y), [A.Matern12(), A.Matern12()], bases)
+    s_sorted = model._stats.clone()
+    model.phi_pass(sorted_cells=False)
+    s_point = model._stats.clone()
+    sc = s_point.abs().max().item()
+    assert (s_sorted - s_point).abs().max().item() <= 1e-12 * sc
+    assert torch.equal(s_sorted == 0, s_point == 0)
+    # cell ids vs the oracle's index rule
+    Xs, ys, start = model._sorted
+    o1, o2 = O.Basis(order, 0, 1, m1), O.Basis(order, -1, 2, m2)
+    i1 = O.neighbour_index(o1.mesh, Xs[:, 0].cpu().numpy())
+    i2 = O.neighbour_index(o2.mesh, Xs[:, 1].cpu().numpy())
+    cid = i1 * (len(o2.mesh) - 1) + i2
+    assert np.all(np.diff(cid) >= 0)
+    st = start.cpu().numpy()
+    assert st[-1] == N and np.array_equal(np.bincount(cid, minlength=len(st) - 1), np.diff(st))
