@@ -252,10 +252,10 @@ __global__ void kron_assemble_kernel(const double* __restrict__ K1, const double
 // ---------------------------------------------------------------------------------------------------------
 constexpr int BB_NB = 32;
 
-__global__ __launch_bounds__(1024) void bb_panel_kernel(double* __restrict__ Pb, long M, int bw, long LD, long j0,
+__global__ __launch_bounds__(512) void bb_panel_kernel(double* __restrict__ Pb, long M, int bw, long LD, long j0,
                                                         double* __restrict__ rhs, int* __restrict__ info) {
   __shared__ double Ls[BB_NB][BB_NB + 1];
-  __shared__ double cs[BB_NB];
+  __shared__ double cs[BB_NB], invd[BB_NB];
   const int tid = threadIdx.x;
   const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
   for (int idx = tid; idx < BB_NB * BB_NB; idx += blockDim.x) {
@@ -264,36 +264,48 @@ __global__ __launch_bounds__(1024) void bb_panel_kernel(double* __restrict__ Pb,
     if (r >= c && r < nbk && c < nbk) v = (r - c <= bw) ? Pb[(j0 + c) * LD + (r - c)] : 0.0;
     Ls[r][c] = v;
   }
+  if (tid < BB_NB) cs[tid] = (rhs && tid < nbk) ? rhs[j0 + tid] : 0.0;
   __syncthreads();
-  for (int j = 0; j < nbk; ++j) {
-    if (tid == 0) {
-      double piv = Ls[j][j];
-      if (!(piv > 0.0)) atomicCAS(info, 0, (int)(j0 + j + 1));
-      Ls[j][j] = sqrt(piv);
+  // Diagonal block: one wavefront, rows in registers (lane r holds row r; fully unrolled, so every register index and every
+  // v_readlane lane is static) - no workgroup barriers inside the 32 column steps; the rhs block rides along (y = L^-1 b).
+  if (tid < 64) {
+    const int r = tid & 31;
+    double a[BB_NB];
+#pragma unroll
+    for (int c = 0; c < BB_NB; ++c) a[c] = Ls[r][c];
+    double t = cs[r];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) {
+      const double piv = readlane_f64(a[j], j);
+      if (!(piv > 0.0) && !bad) bad = j + 1;
+      const double ljj = sqrt(piv), inv = 1.0 / ljj;
+      a[j] = (r == j) ? ljj : a[j] * inv;              // (rows above j hold zeros in column j)
+      const double yj = readlane_f64(t, j) * inv;       // forward substitution rides along
+      t = (r == j) ? yj : fma(-a[j], yj, t);
+#pragma unroll
+      for (int c = j + 1; c < BB_NB; ++c) {
+        const double lcj = readlane_f64(a[j], c);
+        a[c] = (r >= c) ? fma(-a[j], lcj, a[c]) : a[c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    if (tid > j && tid < BB_NB) Ls[tid][j] = Ls[tid][j] / Ls[j][j];
-    __syncthreads();
-    {
-      int r = tid / BB_NB, c = tid % BB_NB;  // 1024 threads = 32 x 32 entries
-      if (c > j && r >= c) Ls[r][c] = fma(-Ls[r][j], Ls[c][j], Ls[r][c]);
+    if (tid < BB_NB) {
+#pragma unroll
+      for (int c = 0; c < BB_NB; ++c) Ls[r][c] = (c < r) ? a[c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < BB_NB; ++c)
+        if (c == r) { Ls[r][r] = a[c]; invd[r] = 1.0 / a[c]; }
+      cs[r] = (r < nbk) ? t : 0.0;
     }
-    __syncthreads();
+    if (tid == 0 && bad) atomicCAS(info, 0, (int)(j0 + bad));
   }
+  __syncthreads();
   for (int idx = tid; idx < BB_NB * BB_NB; idx += blockDim.x) {
     int r = idx / BB_NB, c = idx % BB_NB;
     if (r >= c && r < nbk && c < nbk && r - c <= bw) Pb[(j0 + c) * LD + (r - c)] = Ls[r][c];
   }
-  if (rhs && tid == 0) {
-    for (int r = 0; r < nbk; ++r) {
-      double t = rhs[j0 + r];
-      for (int p = 0; p < r; ++p) t = fma(-Ls[r][p], cs[p], t);
-      cs[r] = t / Ls[r][r];
-      rhs[j0 + r] = cs[r];
-    }
-    for (int r = nbk; r < BB_NB; ++r) cs[r] = 0.0;
-  }
-  __syncthreads();
+  if (rhs && tid < nbk) rhs[j0 + tid] = cs[tid];
   const long r_lo = j0 + nbk;
   long r_hi = j0 + nbk - 1 + bw;  // last row touching this block column
   if (r_hi > M - 1) r_hi = M - 1;
@@ -306,9 +318,10 @@ __global__ __launch_bounds__(1024) void bb_panel_kernel(double* __restrict__ Pb,
       double v = (c < nbk && d <= bw) ? Pb[(j0 + c) * LD + d] : 0.0;
 #pragma unroll
       for (int p = 0; p < c; ++p) v = fma(-xr[p], Ls[c][p], v);
-      xr[c] = v / Ls[c][c];
+      xr[c] = v * invd[c];
       if (c < nbk && d <= bw) Pb[(j0 + c) * LD + d] = xr[c];
       t = fma(-xr[c], cs[c], t);
+      __builtin_amdgcn_sched_barrier(0);   // keep the 528 broadcast reads of L from being hoisted into ~500 live registers
     }
     if (rhs) rhs[r] = t;
   }
@@ -366,11 +379,21 @@ __global__ __launch_bounds__(1024) void bb_backsolve_kernel(const double* __rest
   if (r_hi > M - 1) r_hi = M - 1;
   const int c = tid / 32, part = tid % 32;  // 32 columns x 32 row-lanes (a half wave per column)
   double acc = 0.0;
-  if (c < nbk)
-    for (long r = r_lo + part; r <= r_hi; r += 32) {
-      long d = r - (j0 + c);
-      if (d <= bw) acc = fma(Pb[(j0 + c) * LD + d], x[r], acc);
+  if (c < nbk) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four independent load / FMA streams
+    long r = r_lo + part;
+    for (; r + 96 <= r_hi; r += 128) {
+      const long d = r - (j0 + c);
+      const double p0 = (d <= bw) ? Pb[(j0 + c) * LD + d] : 0.0, p1 = (d + 32 <= bw) ? Pb[(j0 + c) * LD + d + 32] : 0.0;
+      const double p2 = (d + 64 <= bw) ? Pb[(j0 + c) * LD + d + 64] : 0.0, p3 = (d + 96 <= bw) ? Pb[(j0 + c) * LD + d + 96] : 0.0;
+      a0 = fma(p0, x[r], a0); a1 = fma(p1, x[r + 32], a1); a2 = fma(p2, x[r + 64], a2); a3 = fma(p3, x[r + 96], a3);
     }
+    for (; r <= r_hi; r += 32) {
+      const long d = r - (j0 + c);
+      if (d <= bw) a0 = fma(Pb[(j0 + c) * LD + d], x[r], a0);
+    }
+    acc = (a0 + a1) + (a2 + a3);
+  }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (part == 0) ts[c] = (c < nbk) ? x[j0 + c] - acc : 0.0;
@@ -641,7 +664,7 @@ extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, doubl
   hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
   if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
   for (long j0 = 0; j0 < M; j0 += BB_NB) {
-    hipLaunchKernelGGL(bb_panel_kernel, dim3(1), dim3(1024), 0, st, Pb, (long)M, (int)bw, LD, j0, rhs, info);
+    hipLaunchKernelGGL(bb_panel_kernel, dim3(1), dim3(512), 0, st, Pb, (long)M, (int)bw, LD, j0, rhs, info);
     long nbk = (M - j0 < BB_NB) ? (M - j0) : BB_NB;
     long r_lo = j0 + nbk, r_hi = j0 + nbk - 1 + bw;
     if (r_hi > M - 1) r_hi = M - 1;

@@ -405,6 +405,15 @@ class GPR_kron:
             for i in range(nblk - 2, -1, -1):
                 SigS[i] = -(SigD[i + 1] @ G[i])
                 SigD[i] = Dinv[i] - G[i].t() @ SigS[i]
+        if f.get("alpha") is None:   # alpha = L^-T c on the same blocks (40 small matrix-vector steps instead of 512 band launches)
+            cb = torch.zeros(nblk * Bb, dtype=torch.float64, device=dev)
+            cb[:M] = f["c"].reshape(-1)
+            cb = cb.view(nblk, Bb)
+            ab = torch.empty_like(cb)
+            ab[nblk - 1] = Linv[nblk - 1].t() @ cb[nblk - 1]
+            for i in range(nblk - 2, -1, -1):
+                ab[i] = Linv[i].t() @ (cb[i] - sub[i].t() @ ab[i + 1])
+            f["alpha"] = ab.reshape(-1)[:M].contiguous()
         return SigD, SigS, Bb
 
     def elbo_and_grad(self):
@@ -413,8 +422,8 @@ class GPR_kron:
         (asvgp_kron_grad_terms) from the band-restricted inverse of P and the two 1-D inverse bands."""
         from . import banded
         lib = get_lib()
-        f = self._factor(want_alpha=True)
-        SigD, SigS, Bb = self._selinv(f)
+        f = self._factor(want_alpha=False)
+        SigD, SigS, Bb = self._selinv(f)                         # (also fills f["alpha"])
         s, N = f["s"], float(self.num_data)
         vs = [float(k.variance) for k in self.kernels]
         ls = [float(k.lengthscales) for k in self.kernels]
@@ -489,8 +498,8 @@ class GPR_kron:
         lib = get_lib()
         key = self.theta()
         if self._post is None or self._post[0] != key:
-            f = self._factor(want_alpha=True)
-            self._post = (key, f, self._selinv(f))
+            f = self._factor(want_alpha=False)
+            self._post = (key, f, self._selinv(f))               # (also fills f["alpha"])
         f, (SigD, SigS, Bb) = self._post[1], self._post[2]
         b1, b2 = self.bases
         X = _to_device(Xnew, self._stats.device)
