@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu
                                                                const double* b, int M, double* wsK, double* wsP,
                                                                double* SK, double* dSK, double* SP, double* x,
                                                                double* logdets, int* info, int do_stamps,
-                                                               int first_chain, double pfly_s) {
+                                                               int first_chain, double /*unused*/) {
   extern __shared__ double lds[];
   double* st = do_stamps ? logdets + 8 : nullptr;  // diagnostic: 24 stamps per chain after the 4 log-det slots
   // do_stamps == 2 (diagnostic): run the solve twice and stamp the second, warm, pass (instruction cache / TLB effects)
@@ -141,13 +141,24 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu
     if (blockIdx.x + first_chain == 0) {
       if (TANGENT) bcr_solve<Dual, K, 0, BandPtr<Dual>, BIG>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
       else bcr_solve<double, K, 0, BandPtr<double>, BIG>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
-    } else if (pfly_s > 0.0) {   // P = A/s + Kuu formed inside the gathers (P then points at A = the statistics band)
-      bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{P, Kuu, pfly_s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
-    } else {
+    } else {   // (the split data chain, P formed in the gathers, has its own kernel: elbo_bcr_data_kernel)
       bcr_solve<double, K, 1, BandPtr<double>, BIG>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
     }
     __syncthreads();
   }
+}
+
+// Data chain alone (asvgp_elbo_data_chain_1d): the P chain with P = A/s + Kuu formed in its gathers.  A kernel of its own
+// so that its register allocation is not shared with the Dual (tangent) chain: 256 VGPRs, no spills (the combined kernel
+// above spills 135 VGPRs), and it is the one on the critical path of a step.
+template <int K, bool BIG>
+__global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_data_kernel(const double* Kuu, const double* A, const double* b, int M,
+                                                                    double* wsP, double* SP, double* x, double* logdets,
+                                                                    int* info, int do_stamps, double s) {
+  extern __shared__ double lds[];
+  double* st = do_stamps ? logdets + 8 : nullptr;
+  bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1,
+                                         st ? st + 24 : nullptr);
 }
 
 // the same with the lane-distributed solver (bcr16.hpp), 1024 threads per chain
@@ -350,11 +361,17 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
       hipLaunchKernelGGL((elbo_bcr16_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR16_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
                          getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0);
-    else {
+    else if (pfly) {
+      auto kern = big ? elbo_bcr_data_kernel<K, HAS_BIG> : elbo_bcr_data_kernel<K, false>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+      hipLaunchKernelGGL(kern, dim3(1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info,
+                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, s);
+    } else {
       auto kern = big ? elbo_bcr_kernel<K, TANGENT, HAS_BIG> : elbo_bcr_kernel<K, TANGENT, false>;
       hipLaunchKernelGGL(kern, dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
-                         pfly ? A : w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
-                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, pfly ? s : 0.0);
+                         w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
+                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, 0.0);
     }
     if (part == 1) {
       if (g_sync_on) (void)hipEventRecord(g_evP, st);
