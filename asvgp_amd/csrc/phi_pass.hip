@@ -459,6 +459,63 @@ __device__ __forceinline__ void mom_own_cell(const double2* buf, unsigned n, uns
   }
 }
 
+// Heavy cells of a wave's 128 owned cells (sorted / clustered input): the whole wavefront walks the cell's points, in TWO
+// passes (S moments, then T moments) so that at most 2k+1 temporaries are live next to the 2 (3k+2) owner accumulators - the
+// one-pass version cost 64 spilled VGPRs in the streaming loop - and reduces on the VALU (DPP).  Wave-uniform control flow.
+template <int K>
+__device__ __forceinline__ void mom_heavy_cells(const double2* buf, unsigned nA, unsigned oA, bool hvA, unsigned nB, unsigned oB,
+                                                bool hvB, int lane, double (&SA)[2 * K + 1], double (&TA)[K + 1],
+                                                double (&SB)[2 * K + 1], double (&TB)[K + 1]) {
+  unsigned long long ma = __ballot(hvA), mb = __ballot(hvB);
+  while (ma | mb) {
+    const bool isA = ma != 0ull;
+    const unsigned long long m = isA ? ma : mb;
+    const int h = __ffsll((long long)m) - 1;
+    if (isA) ma &= ma - 1; else mb &= mb - 1;
+    const unsigned nh = (unsigned)__builtin_amdgcn_readlane((int)(isA ? nA : nB), h);
+    const unsigned oh = (unsigned)__builtin_amdgcn_readlane((int)(isA ? oA : oB), h);
+    const bool meA = isA && lane == h, meB = !isA && lane == h;
+    {
+      double S2[2 * K + 1];
+#pragma unroll
+      for (int p = 0; p <= 2 * K; ++p) S2[p] = 0.0;
+      for (unsigned j = lane; j < nh; j += 64) {
+        const double sv = buf[oh + j].x;
+        double pw = 1.0;
+        S2[0] += 1.0;
+#pragma unroll
+        for (int p = 1; p <= 2 * K; ++p) { pw *= sv; S2[p] += pw; }
+      }
+#pragma unroll
+      for (int p = 0; p <= 2 * K; ++p) {
+        const double t = wave_sum_dpp(S2[p]);
+        SA[p] += meA ? t : 0.0;
+        SB[p] += meB ? t : 0.0;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      double T2[K + 1];
+#pragma unroll
+      for (int p = 0; p <= K; ++p) T2[p] = 0.0;
+      for (unsigned j = lane; j < nh; j += 64) {
+        const double2 pt = buf[oh + j];
+        double pw = 1.0;
+        T2[0] += pt.y;
+#pragma unroll
+        for (int p = 1; p <= K; ++p) { pw *= pt.x; T2[p] = fma(pt.y, pw, T2[p]); }
+      }
+#pragma unroll
+      for (int p = 0; p <= K; ++p) {
+        const double t = wave_sum_dpp(T2[p]);
+        TA[p] += meA ? t : 0.0;
+        TB[p] += meB ? t : 0.0;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // both cells of one owner lane in ONE loop (trip = max(nA, nB) instead of nA + nB, two independent FMA streams);
 // a missing point is fed as (s, y) = (0, 0), which only touches S_0 - masked explicitly.
 template <int K>
@@ -486,8 +543,7 @@ __device__ __forceinline__ void mom_own_two_cells(const double2* buf, unsigned n
       if (p <= K) { TA[p] = fma(pa.y, wa, TA[p]); TB[p] = fma(pb.y, wb, TB[p]); }
     }
   }
-  if (__any(hvA)) mom_own_cell<K>(buf, hvA ? nA : 0u, oA, lane, SA, TA);
-  if (__any(hvB)) mom_own_cell<K>(buf, hvB ? nB : 0u, oB, lane, SB, TB);
+  if (__any(hvA || hvB)) mom_heavy_cells<K>(buf, nA, oA, hvA, nB, oB, hvB, lane, SA, TA, SB, TB);
 }
 
 // moments of cell c -> band / rhs contributions (exact integer-ratio coefficients, centred monomials)
@@ -1142,7 +1198,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
   int cells_per_chunk = (M <= maxc) ? ncells : (maxc - K);
   const bool v2 = (g_phi_algo == 2);
   const bool v4 = (g_phi_algo == 4) && bk_lds_bytes<K>() <= PHI_LDS_BUDGET;   // (k = 6: the bucket buffers exceed the LDS -> algorithm 3)
-  constexpr int TP = 6;
+  constexpr int TP = 4;
   if ((v2 || v4) && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
   long nblk = (N + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS);
   const long gmax = (g_phi_blocks > 0 && g_phi_blocks < PHI_MAX_BLOCKS) ? g_phi_blocks : PHI_MAX_BLOCKS;

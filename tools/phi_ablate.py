@@ -27,7 +27,7 @@ st = np.array([w[b * E1: b * E1 + 6] for b in range(256)])
 print("per-phase cycles (thread 0; mean over 256 blocks; 7 tiles): P1 cell+rank | P2 scan (incl. prefetch issue) | P3 scatter | P4 owner | end barrier")
 print(np.round(st.mean(0)[:5]), " total", st.mean(0)[:5].sum())
 print("max over blocks", np.round(st.max(0)[:5]))
-for algo, modes in ((1, (0,)), (3, (0,)), (4, (0,))):
+for algo, modes in ((2, (1, 2, 3, 4, 5, 0)), (3, (0,))):
     for ab in modes:
         os.environ["ASVGP_PHI_ABLATE"] = str(ab)
         A.set_phi_algorithm(algo)
