@@ -5,15 +5,21 @@ src = os.path.join(ROOT, "gpurun_out", "prof_final")
 dst = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
+def newest(pattern):
+    """gpurun merges new files into gpurun_out/ without deleting older runs: keep only the most recent match."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 def counters(sub, kernel="phi_accumulate_kernel"):
     out = {}
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if kernel in row["Kernel_Name"]:
                 out.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
-ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, tag + "_bench.json"))
 fetch, nf = counters("fetch")
