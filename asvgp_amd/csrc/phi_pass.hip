@@ -435,30 +435,6 @@ __device__ __forceinline__ void mom_accumulate(double s, double y, double (&S)[2
 }
 
 
-// one owner lane, one cell: light cells in a private loop, heavy cells (sorted / clustered input) by the whole wave
-template <int K>
-__device__ __forceinline__ void mom_own_cell(const double2* buf, unsigned n, unsigned o, int lane,
-                                             double (&S)[2 * K + 1], double (&T)[K + 1]) {
-  if (n <= MOM_HEAVY)
-    for (unsigned j = 0; j < n; ++j) { double2 p = buf[o + j]; mom_accumulate<K>(p.x, p.y, S, T); }
-  unsigned long long hv = __ballot(n > MOM_HEAVY);   // (callers pass n = 0 for lanes whose cell was handled already)
-  while (hv) {  // wave-uniform loop
-    const int h = __ffsll((long long)hv) - 1;
-    hv &= hv - 1;
-    const unsigned nh = __shfl(n, h, 64), oh = __shfl(o, h, 64);
-    double S2[2 * K + 1], T2[K + 1];
-#pragma unroll
-    for (int p = 0; p <= 2 * K; ++p) S2[p] = 0.0;
-#pragma unroll
-    for (int p = 0; p <= K; ++p) T2[p] = 0.0;
-    for (unsigned j = lane; j < nh; j += 64) { double2 p = buf[oh + j]; mom_accumulate<K>(p.x, p.y, S2, T2); }
-#pragma unroll
-    for (int p = 0; p <= 2 * K; ++p) { double t = wave_sum(S2[p]); S[p] += (lane == h) ? t : 0.0; }
-#pragma unroll
-    for (int p = 0; p <= K; ++p) { double t = wave_sum(T2[p]); T[p] += (lane == h) ? t : 0.0; }
-  }
-}
-
 // Heavy cells of a wave's 128 owned cells (sorted / clustered input): the whole wavefront walks the cell's points, in TWO
 // passes (S moments, then T moments) so that at most 2k+1 temporaries are live next to the 2 (3k+2) owner accumulators - the
 // one-pass version cost 64 spilled VGPRs in the streaming loop - and reduces on the VALU (DPP).  Wave-uniform control flow.
