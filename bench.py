@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--features", type=int, default=2048)
     ap.add_argument("--sorted", action="store_true", help="secondary case: time-series (sorted) inputs")
+    ap.add_argument("--matern", type=int, default=32, choices=(12, 32, 52), help="kernel of the workload (BASELINE config 3 uses 52)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
@@ -109,7 +110,8 @@ def main():
     xd = torch.from_numpy(x[lo:hi].copy()).cuda().reshape(-1, 1)
     yd = torch.from_numpy(y[lo:hi].copy()).cuda().reshape(-1, 1)
     basis = A.B4Spline(0, 1, M)
-    model = A.GPR_1d((xd, yd), A.Matern32(variance=theta[0], lengthscales=theta[1]), basis)
+    Kern = {12: A.Matern12, 32: A.Matern32, 52: A.Matern52}[args.matern]
+    model = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
     model.likelihood.variance.assign(theta[2])
     model.num_data = N
     stats = model._stats
@@ -190,8 +192,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "1D synthetic N=%d (U(0,1) i.i.d. %s), Matern-3/2, B4Spline(0,1,M=%d) band k=4, theta=(1,0.05,0.01)"
-                                   % (N, "sorted" if args.sorted else "unsorted", M),
+            "config": {"workload": "1D synthetic N=%d (U(0,1) i.i.d. %s), Matern-%d/2, B4Spline(0,1,M=%d) band k=4, theta=(1,0.05,0.01)"
+                                   % (N, "sorted" if args.sorted else "unsorted", args.matern // 10, M),
                        "parallelism": "dp%d (contiguous N-shards, one all-reduce of the %d-double band buffer)" % (world, stats.numel()),
                        "points_per_rank": n_local},
             "phases_us": {"phi_pass": t_phi, "band_allreduce": t_comm, "data_chain_after_stats": t_band,
