@@ -148,6 +148,17 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu
   }
 }
 
+// Prior chain alone (asvgp_elbo_prior_chain_1d): the Dual (value + tangent) Kuu chain in a kernel of its own - 35 spilled
+// VGPRs instead of the 135 of the combined kernel.
+template <int K, bool BIG>
+__global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_prior_kernel(const double* Kuu, const double* dK, int M, double* wsK,
+                                                                     double* SK, double* dSK, double* logdets, int* info,
+                                                                     int do_stamps) {
+  extern __shared__ double lds[];
+  double* st = do_stamps ? logdets + 8 : nullptr;
+  bcr_solve<Dual, K, 0, BandPtr<Dual>, BIG>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
+}
+
 // Data chain alone (asvgp_elbo_data_chain_1d): the P chain with P = A/s + Kuu formed in its gathers.  A kernel of its own
 // so that its register allocation is not shared with the Dual (tangent) chain: 256 VGPRs, no spills (the combined kernel
 // above spills 135 VGPRs), and it is the one on the critical path of a step.
@@ -361,7 +372,15 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
       hipLaunchKernelGGL((elbo_bcr16_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR16_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
                          getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0);
-    else if (pfly) {
+    else if (part == 1 && TANGENT) {
+      if constexpr (TANGENT) {
+        auto kern = big ? elbo_bcr_prior_kernel<K, HAS_BIG> : elbo_bcr_prior_kernel<K, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK, (int)M, w.bcrK, w.SK, w.dSK, w.logdets, info,
+                           getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0);
+      }
+    } else if (pfly) {
       auto kern = big ? elbo_bcr_data_kernel<K, HAS_BIG> : elbo_bcr_data_kernel<K, false>;
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
