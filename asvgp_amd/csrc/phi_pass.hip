@@ -14,7 +14,7 @@
 namespace asvgp {
 
 constexpr int PHI_THREADS = 1024;
-constexpr int PHI_CH = 8;                     // iterations a wavefront stays on one contiguous slice (see phi_accumulate_kernel)
+constexpr int PHI_CH = 32;                    // iterations a wavefront stays on one contiguous slice (see phi_accumulate_kernel)
 constexpr int PHI_MAX_BLOCKS = 256;           // one 1024-thread workgroup per CU (LDS-limited)
 constexpr size_t PHI_LDS_BUDGET = 160 * 1024 - 512;
 
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
   FxParams fx{s0, 0, 0.0};
   // Point -> wave mapping: the workgroup walks its range in super-tiles of 16 waves x PHI_CH iterations x 128 points; inside
   // a super-tile every wavefront streams a contiguous slice (PHI_CH * 128 points), so a sorted input keeps a wave inside
-  // one cell for PHI_CH iterations while the workgroup as a whole still reads one contiguous window of memory at a time.
+  // one cell for up to PHI_CH iterations.  (8 -> 32 iterations: sorted input 87 -> 79 us, unsorted unchanged; a two-deep
+  // register prefetch was tried and gave nothing: the hand-over copy forces the older load to complete anyway.)
   const int lane = tid & 63, wv = tid >> 6;
   constexpr int NP = VEC ? 2 : 1;
   const long n_it = (ppb / (2 * PHI_THREADS)) * (VEC ? 1 : 2);   // rows of 64 lanes per wave (ppb is a multiple of 2 * PHI_THREADS)
