@@ -378,8 +378,11 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
             }
           }
         blk_chol<T, B>(D, invd, bad, i * B);
+        __builtin_amdgcn_sched_barrier(0);   // (phase fences: keep the scheduler from overlapping the phases' live ranges - Dual blocks spill otherwise)
         blk_solve_L<T, B, B>(D, invd, Ua);
+        __builtin_amdgcn_sched_barrier(0);
         blk_solve_L<T, B, B>(D, invd, Ub);
+        __builtin_amdgcn_sched_barrier(0);
         if (NRHS) {
 #pragma unroll
           for (int r = 0; r < B; ++r) {
@@ -649,8 +652,11 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
 #pragma unroll
           for (int r = 0; r < B; ++r) xs[i * B + r] = t[r];
         }
+        __builtin_amdgcn_sched_barrier(0);
         blk_solve_LT<T, B, B>(L, invd, Ga);  // G_a = L^-T U_a = D^-1 A[i,a]
+        __builtin_amdgcn_sched_barrier(0);
         blk_solve_LT<T, B, B>(L, invd, Gb);
+        __builtin_amdgcn_sched_barrier(0);
         // neighbour blocks of the inverse
         T Saa[B][B], Sbb[B][B], Sba[B][B];
         const bool e_is_a = ((a / (2 * h)) & 1) != 0;  // which of a,b was eliminated at level l+1
@@ -684,6 +690,7 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
             Ca[r][c] = ta;
             Cb[r][c] = tb;
           }
+        __builtin_amdgcn_sched_barrier(0);
         // D_i^-1 = L^-T L^-1
 #pragma unroll
         for (int r = 0; r < B; ++r)
@@ -691,6 +698,7 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           for (int c = 0; c < B; ++c) Sii[r][c] = (r == c) ? N::make(1.0, 0.0) : N::zero();
         blk_solve_L<T, B, B>(L, invd, Sii);
         blk_solve_LT<T, B, B>(L, invd, Sii);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
