@@ -213,7 +213,7 @@ __device__ __forceinline__ void run_batch(const Batch<NP>& B, RunAcc<K>& run, co
   }
 }
 
-// workgroup-wide y scale from each thread's first value(s): y0 = 2^E >= 4 max|y| (E = 0 when the tile is all zero, NaN or inf)
+// workgroup-wide y scale from each thread's first value(s): y0 = 2^E >= 4 max|y| (2^-900 when the tile is all zero, NaN or inf)
 __device__ __forceinline__ FxParams fx_scale(double my_abs, int s0, double* scratch) {
   double m = (my_abs == my_abs && my_abs < 1e300) ? my_abs : 0.0;
 #pragma unroll
@@ -224,7 +224,7 @@ __device__ __forceinline__ FxParams fx_scale(double my_abs, int s0, double* scra
   double t = 0.0;
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, scratch[w]);
   __syncthreads();
-  int E = (t > 0.0) ? ilogb(t) + 3 : 0;
+  int E = (t > 0.0) ? ilogb(t) + 3 : -900;   // nothing to go by: every later non-zero y takes the exact fp64 plane
   if (E > 900) E = 900;
   if (E < -900) E = -900;
   FxParams fx;
@@ -283,7 +283,11 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
     }
   };
   fetch(0);
-  if (FX) fx = fx_scale((n_it > 0 && ubeg + unit_of(0) * 64 + lane < uend) ? fmax(fabs(ya.x), VEC ? fabs(ya.y) : 0.0) : 0.0, s0, scratch);
+  if (FX) {
+    double mine = (n_it > 0 && ubeg + unit_of(0) * 64 + lane < uend) ? fmax(fabs(ya.x), VEC ? fabs(ya.y) : 0.0) : 0.0;
+    if (VEC && tid == 0 && (end & 1) && end > beg) mine = fmax(mine, fabs(y[end - 1]));   // the odd tail point counts too (N = 1!)
+    fx = fx_scale(mine, s0, scratch);
+  }
   Batch<NP> B;
   long it = 0;
   // take the prefetched unit as the current batch, start the next prefetch (before the LDS burst), classify

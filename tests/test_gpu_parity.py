@@ -825,9 +825,12 @@ def test_phi_fixed_point_scale_fallback(A):
     x = rng.uniform(1e-9, 1 - 1e-9, N)
     ob = O.Basis(4, 0, 1, M)
     bs = A.B4Spline(0, 1, M)
-    for kind in ("late_large", "zero_head", "tiny"):
+    for kind in ("late_large", "zero_head", "zero_head_tiny", "tiny"):
         y = 1e-3 * rng.normal(size=N)
-        if kind == "late_large":
+        if kind == "zero_head_tiny":          # nothing to scale by in the first tile, small values afterwards (found by tools/fuzz_phi.py)
+            y[:4096] = 0.0
+            y[4096:] = 1e-7 * rng.normal(size=N - 4096)
+        elif kind == "late_large":
             y[N // 2:] *= 1e6
             y[5000::7] = -3e4
         elif kind == "zero_head":
@@ -840,6 +843,10 @@ def test_phi_fixed_point_scale_fallback(A):
         np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)), err_msg=kind)
         assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= 1e-12 * np.max(np.abs(band))
         assert abs(m.tr_yTy.item() - yy) <= 1e-12 * yy
+    for n1, yv in ((1, 1e-7), (3, -3e-5)):   # the odd tail point alone must set the scale
+        m = A.GPR_1d((x[:n1].reshape(-1, 1), np.full((n1, 1), yv)), A.Matern12(), bs)
+        band, rhs, yy = O.sufficient_stats_direct(ob, x[:n1], np.full((n1, 1), yv))
+        np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)))
     y = rng.normal(size=N)
     y[123456] = np.nan
     m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern12(), bs)

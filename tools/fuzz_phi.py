@@ -1,0 +1,48 @@
+"""Randomised parity sweep of the Phi pass against the oracle (not a unit test: run on the GPU box, prints failures).
+usage: python tools/fuzz_phi.py [n_cases] [seed]"""
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+import asvgp_amd as A
+from oracle import asvgp_oracle as O
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+min_m = {1: 4, 2: 7, 3: 9, 4: 12, 5: 13, 6: 15}
+fails = 0
+for case in range(n_cases):
+    order = int(rng.integers(1, 7))
+    M = int(rng.integers(min_m[order], 40)) if rng.random() < 0.5 else int(rng.integers(40, 5000))
+    N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 2047, 2048, 2049, 4097])) if rng.random() < 0.3 else int(rng.integers(1, 300000))
+    a, b = (0, 1) if rng.random() < 0.7 else (-3.5, 10.5)
+    dist = rng.choice(["uniform", "sorted", "clustered", "repeats", "two_cells"])
+    lo, hi = a + 1e-9 * (b - a), b - 1e-9 * (b - a)
+    if dist == "uniform": x = rng.uniform(lo, hi, N)
+    elif dist == "sorted": x = np.sort(rng.uniform(lo, hi, N))
+    elif dist == "clustered": x = np.clip(a + (b - a) * (0.5 + 0.03 * rng.standard_normal(N)), lo, hi)
+    elif dist == "repeats": x = rng.choice(rng.uniform(lo, hi, 7), N)
+    else: x = rng.choice([lo, a + 0.3 * (b - a), hi], N)
+    yscale = 10.0 ** rng.integers(-8, 9)
+    y = yscale * rng.standard_normal((N, 1))
+    if rng.random() < 0.3 and N > 10: y[rng.integers(0, N, 3)] *= 1e6
+    algo = int(rng.choice([0, 1, 2, 3, 4]))
+    A.set_phi_algorithm(algo)
+    try:
+        bs = getattr(A, "B%dSpline" % order)(a, b, M)
+        xs = torch.from_numpy(np.concatenate([[0.0], x]))[1:].cuda() if rng.random() < 0.3 else torch.from_numpy(x).cuda()   # sometimes unaligned
+        m = A.GPR_1d((xs.reshape(-1, 1), torch.from_numpy(y).cuda()), A.Matern12(), bs)
+        ob = O.Basis(order, a, b, M)
+        band, rhs, yy = O.sufficient_stats_direct(ob, x, y)
+        eb = np.max(np.abs(m.KufKfu.cpu().numpy() - band)) / max(np.max(np.abs(band)), 1e-300)
+        er = np.max(np.abs(m.Kuf_y.cpu().numpy() - rhs)) / max(np.max(np.abs(rhs)), 1e-300)
+        ey = abs(m.tr_yTy.item() - yy) / max(yy, 1e-300)
+        g = m.KufKfu.cpu().numpy()
+        zero_ok = all((g[d, M - d:] == 0).all() for d in range(1, order + 1))      # structural right padding of the band
+        tol = 1e-12 + 4e-16 * N      # (the oracle's own sequential fp64 sums lose ~N eps on heavily repeated x)
+        ok = eb <= tol and er <= tol and ey <= tol and zero_ok
+    except Exception as e:  # noqa
+        ok, eb, er, ey = False, -1, -1, -1
+        print("EXC", repr(e)[:200])
+    if not ok:
+        fails += 1
+        print("FAIL case %d: order %d M %d N %d [%s,%s] %s yscale %g algo %d  band %.2e rhs %.2e yy %.2e" % (case, order, M, N, a, b, dist, yscale, algo, eb, er, ey), flush=True)
+A.set_phi_algorithm(0)
+print("cases %d, failures %d" % (n_cases, fails))
