@@ -1,0 +1,62 @@
+"""Randomised parity sweep of GPR_kron and GPR_additive against the dense oracle (run on the GPU box).
+usage: python tools/fuzz_kron_additive.py [n_cases] [seed]"""
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+import asvgp_amd as A
+from oracle import asvgp_oracle as O
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+KIND = ["Matern12", "Matern32", "Matern52"]
+orders_for = {0: [1, 2, 3, 4], 1: [2, 3, 4], 2: [3, 4]}
+min_m = {1: 4, 2: 7, 3: 9, 4: 12}
+fails = 0
+for case in range(n_cases):
+    kron = rng.random() < 0.6
+    d = 2 if kron else int(rng.integers(1, 5))
+    kds = [int(rng.integers(0, 3)) for _ in range(d)]
+    order = int(rng.choice(sorted(set.intersection(*[set(orders_for[k]) for k in kds]))))
+    ms = [int(rng.integers(min_m[order], 26)) for _ in range(d)]
+    N = int(rng.integers(200, 20000))
+    X = rng.uniform(0.001, 0.999, (N, d))
+    if rng.random() < 0.3: X[:, 0] = np.sort(X[:, 0])
+    y = (np.sin(5 * X[:, :1]) + (X[:, 1:2] ** 2 if d > 1 else 0) + 0.1 * rng.standard_normal((N, 1)))
+    th = [(float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.15, 0.8))) for _ in range(d)]
+    s = float(10 ** rng.uniform(-2.5, -0.5))
+    try:
+        bases = [getattr(A, "B%dSpline" % order)(0, 1, m) for m in ms]
+        obases = [O.Basis(order, 0, 1, m) for m in ms]
+        kerns = [getattr(A, KIND[k])(variance=v, lengthscales=l) for k, (v, l) in zip(kds, th)]
+        Xs = rng.uniform(0.01, 0.99, (100, d))
+        yy = float(np.sum(y * y))
+        if kron:
+            model = A.GPR_kron((X, y), kerns, bases); model.likelihood.variance.assign(s)
+            oe, parts = O.elbo_kron(obases, kds, th, s, X, y)
+            e, g = model.elbo_and_grad()
+            om, ov = O.predict_f_kron(obases, kds, th, s, X, y, Xs)
+            def val(p): return O.elbo_kron(obases, kds, [(p[0], p[1]), (p[2], p[3])], p[4], X, y)[0]
+            p0 = np.array([th[0][0], th[0][1], th[1][0], th[1][1], s]); fd = np.zeros(5)
+            for i in range(5):
+                h = 1e-5 * p0[i]; pp, pm = p0.copy(), p0.copy(); pp[i] += h; pm[i] -= h
+                fd[i] = (val(pp) - val(pm)) / (2 * h)
+            eg = np.max(np.abs(g - fd) / (np.abs(fd) + np.max(np.abs(fd))))
+            vs = th[0][0] * th[1][0]
+        else:
+            model = A.GPR_additive((X, y), kerns, bases); model.likelihood.variance.assign(s)
+            oe, _ = O.elbo_additive(obases, kds, th, s, X, y)
+            e = model.elbo().item()
+            om, ov = O.predict_f_additive(obases, kds, th, s, X, y, Xs)
+            eg = 0.0
+            vs = sum(v for v, _ in th)
+        mean, var = model.predict_f(Xs)
+        tol_e = 1e-9 * abs(oe) + 5e-9 * (0.5 * N * vs / s + 0.5 * yy / s)
+        ee = abs(e - oe)
+        ep = max(np.max(np.abs(mean - om)), np.max(np.abs(var - ov)))
+        ok = ee <= tol_e and eg <= 5e-5 and ep <= 1e-7
+    except Exception as ex:  # noqa
+        ok, ee, eg, ep, tol_e = False, -1, -1, -1, 0
+        print("EXC", repr(ex)[:300])
+    if not ok:
+        fails += 1
+        print("FAIL case %d: %s d %d order %d m %s N %d kinds %s s %.3g | elbo err %.2e (tol %.2e) grad %.2e post %.2e" % (
+            case, "kron" if kron else "additive", d, order, ms, N, kds, s, ee, tol_e, eg, ep), flush=True)
+print("cases %d, failures %d" % (n_cases, fails))
