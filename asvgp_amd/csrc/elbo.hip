@@ -168,7 +168,7 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_data_kernel(const double
                                                                     int* info, int do_stamps, double s) {
   extern __shared__ double lds[];
   double* st = do_stamps ? logdets + 8 : nullptr;
-  bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1,
+  bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1,
                                          st ? st + 24 : nullptr);
 }
 
