@@ -248,8 +248,14 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
       }
   }
   // NRHS <= 1: y lives in xs[] indexed by row and is updated in place (y -> z -> x)
-  if (NRHS)
-    for (int r = tid; r < nb * B; r += BCR_THREADS) xs[r] = (r < M) ? rhs[r] : 0.0;
+  if (NRHS) {   // all loads of the copy in flight together (the serial form paid one L2/HBM round trip per 256 rows: ~16K cycles)
+    constexpr int RMAX = (2 * NS * B + BCR_THREADS - 1) / BCR_THREADS;
+    double rv[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) { const int r = tid + q * BCR_THREADS; rv[q] = (r < M) ? rhs[r] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) { const int r = tid + q * BCR_THREADS; if (r < nb * B) xs[r] = rv[q]; }
+  }
   __syncthreads();
 
   // ---------------- forward elimination ----------------
@@ -509,6 +515,7 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
     }
     if (lane_on) {
       Wn(0).set(Lay::W_SD + e, xi);
+      if (r >= c && r < M) S.store((long)(r - c) * M + c, xi);
       Wn(0).set(Lay::W_L + e, (r >= c) ? d : N::zero());
       if (NRHS && c == 0) xs[r] = z;
     }
@@ -605,9 +612,18 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           sii = N::nfma(cbrp, gbcp, sii);
         }
         if (lane_on) {
-          Wn(i).set(Lay::W_SD + e, sii);
-          Wn(i).set(Lay::W_CA + e, ca);
-          Wn(i).set(Lay::W_CB + e, cb);
+          if (l > 0) {   // blocks a deeper level will read (nothing reads a level-0 node again)
+            Wn(i).set(Lay::W_SD + e, sii);
+            Wn(i).set(Lay::W_CA + e, ca);
+            Wn(i).set(Lay::W_CB + e, cb);
+          }
+          // the band of the inverse leaves from here: Sigma_ii (lower part) and, at level 0, the couplings to both neighbours
+          if (r >= c && i * B + r < M) S.store((long)(r - c) * M + i * B + c, sii);
+          if (l == 0) {
+            // Sigma[iB + r, aB + c] = C_a[r][c] (r <= c);  Sigma[bB + r, iB + c] = C_b[c][r] (r <= c): lane (r, c) holds C_b[r][c]
+            if (r <= c && i * B + r < M) S.store((long)(B + r - c) * M + a * B + c, ca);
+            if (hasb && c <= r && b * B + c < M) S.store((long)(B + c - r) * M + i * B + r, cb);
+          }
         }
       }
       __syncthreads();
@@ -710,9 +726,17 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
               t = N::nfma(Ca[r][p], Ga[c][p], t);
               t = N::nfma(Cb[r][p], Gb[c][p], t);
             }
-            Wn(i).set(Lay::W_SD + r * B + c, t);
-            Wn(i).set(Lay::W_CA + r * B + c, Ca[r][c]);
-            Wn(i).set(Lay::W_CB + r * B + c, Cb[r][c]);
+            if (l > 0) {   // blocks a deeper level will read (nothing reads a level-0 node again)
+              Wn(i).set(Lay::W_SD + r * B + c, t);
+              Wn(i).set(Lay::W_CA + r * B + c, Ca[r][c]);
+              Wn(i).set(Lay::W_CB + r * B + c, Cb[r][c]);
+            }
+            // the band of the inverse leaves from here (see the lane-distributed branch)
+            if (c <= r && i * B + r < M) S.store((long)(r - c) * M + i * B + c, t);
+            if (l == 0) {
+              if (r <= c && i * B + r < M) S.store((long)(B + r - c) * M + a * B + c, Ca[r][c]);
+              if (hasb && c <= r && b * B + c < M) S.store((long)(B + c - r) * M + i * B + r, Cb[r][c]);
+            }
           }
       }
       __syncthreads();
@@ -720,41 +744,29 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
     stamp();
   }
 
-  // ---------------- outputs: band of the inverse, x, logdet, info ----------------
-  for (int n = tid; n < nb; n += BCR_THREADS) {
+  // ---------------- outputs: x, logdet, info (the band of the inverse was written level by level) ----------------
+  // right padding of the band rows (structural zeros): the last B columns
+  for (int col = M - B + tid; col < M; col += BCR_THREADS)
+    if (col >= 0)
 #pragma unroll
-    for (int r = 0; r < B; ++r)
-#pragma unroll
-      for (int c = 0; c <= r; ++c) {
-        int row = n * B + r, col = n * B + c;
-        if (row < M) S.store((long)(r - c) * M + col, Wn(n).get(Lay::W_SD + r * B + c));
-      }
-    if (n + 1 < nb) {  // Sigma[(n+1)B + r, nB + c], r <= c : from the odd member of the pair
-#pragma unroll
-      for (int r = 0; r < B; ++r)
-#pragma unroll
-        for (int c = r; c < B; ++c) {
-          int row = (n + 1) * B + r, col = n * B + c;
-          T v = (n & 1) ? Wn(n).get(Lay::W_CB + c * B + r) : Wn(n + 1).get(Lay::W_CA + r * B + c);
-          if (row < M) S.store((long)(B + r - c) * M + col, v);
-        }
-    }
-    // right padding of the band rows (structural zeros)
-#pragma unroll
-    for (int r = 0; r < B; ++r)
-#pragma unroll
-      for (int d = 1; d <= B; ++d) {
-        int col = n * B + r;
-        if (col < M && col + d >= M) S.store((long)d * M + col, N::zero());
-      }
-  }
+      for (int d = 1; d <= B; ++d)
+        if (col + d >= M) S.store((long)d * M + col, N::zero());
   if (NRHS)
     for (int r = tid; r < M; r += BCR_THREADS) x[r] = xs[r];
   // log|A| = 2 sum log diag(L_i) over all nodes, off the dependent chain (padding rows have L = 1)
-  for (int e = tid; e < nb * B; e += BCR_THREADS) {
-    T d = Wn(e / B).get(Lay::W_L + (e % B) * B + (e % B));
-    ld_acc += 2.0 * log(N::val(d));
-    dld_acc += 2.0 * N::tan(d) / N::val(d);
+  {
+    constexpr int RMAX = (2 * NS * B + BCR_THREADS - 1) / BCR_THREADS;
+    T dv[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {   // loads first ...
+      const int e = tid + q * BCR_THREADS;
+      dv[q] = (e < nb * B) ? Wn(e / B).get(Lay::W_L + (e % B) * B + (e % B)) : N::make(1.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {   // ... then the logs
+      ld_acc += 2.0 * log(N::val(dv[q]));
+      dld_acc += 2.0 * N::tan(dv[q]) / N::val(dv[q]);
+    }
   }
   // reductions
   double tot = block_sum(ld_acc, red);
