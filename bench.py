@@ -76,8 +76,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
-    ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
-    ap.add_argument("--phase-events", type=int, default=10, help="record per-phase events on every n-th step (0 = never)")
+    ap.add_argument("--kernel-events", type=int, default=10, help="HIP events around every n-th Phi kernel launch")
+    ap.add_argument("--phase-events", type=int, default=25, help="record per-phase events on every n-th step (0 = never)")
     args = ap.parse_args()
 
     import torch

@@ -251,7 +251,7 @@ def test_kron_elbo_matches_direct_dense():
     Qff = Phi.T @ np.linalg.solve(Kuu, Phi)
     C = Qff + s * np.eye(300)
     sign, ld = np.linalg.slogdet(C)
-    direct = -0.5 * (300 * np.log(2 * np.pi) + ld + float(y.T @ np.linalg.solve(C, y))) - 0.5 / s * (300 * 0.7 - np.trace(Qff))
+    direct = -0.5 * (300 * np.log(2 * np.pi) + ld + (y.T @ np.linalg.solve(C, y)).item()) - 0.5 / s * (300 * 0.7 - np.trace(Qff))
     assert abs(e - direct) < 1e-8 * abs(direct)
 
 

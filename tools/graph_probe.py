@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import asvgp_amd as A
 from asvgp_amd import _lib
-lib = _lib.get_lib(); lib.asvgp_set_phi_workgroups(248)
+lib = _lib.get_lib(); lib.asvgp_set_phi_workgroups(248); lib.asvgp_elbo_chain_sync(1)
 N, M = 10_000_000, 2048
 rng = np.random.default_rng(1234)
 x = rng.uniform(1e-9, 1 - 1e-9, N); y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
@@ -17,8 +17,7 @@ def step():
     with torch.cuda.stream(side):
         model.launch_prior_chain()
     model.phi_pass()
-    cur.wait_stream(side)
-    model.launch_data_chain()
+    model.launch_data_chain()      # ordered against the prior chain by the library's own events (asvgp_elbo_chain_sync)
 for _ in range(3): step()
 torch.cuda.synchronize()
 ref = model._out.clone()
