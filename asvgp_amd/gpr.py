@@ -25,7 +25,26 @@ def _to_device(a, device):
     return f64c(t.to(device))
 
 
-class GPR_1d:
+class _GPModelSurface:
+    """The bits of gpflow.models.GPModel the reference's scripts call on every model class: trainable_variables
+    (example.py:32, eNATL60.py:89), predict_y and predict_log_density (electricity.py:132,138) for the Gaussian likelihood."""
+
+    @property
+    def trainable_variables(self):
+        return self.trainable_parameters
+
+    def predict_y(self, Xnew):
+        mean, var = self.predict_f(Xnew)
+        return mean, var + float(self.likelihood.variance)
+
+    def predict_log_density(self, data):
+        Xnew, Ynew = data
+        mean, var = self.predict_y(Xnew)
+        Ynew = np.asarray(Ynew.cpu() if isinstance(Ynew, torch.Tensor) else Ynew, dtype=np.float64).reshape(mean.shape)
+        return -0.5 * (np.log(2 * np.pi * var) + (Ynew - mean) ** 2 / var)
+
+
+class GPR_1d(_GPModelSurface):
     def __init__(self, data, kernel, basis, process_group=None, distributed=None):
         # Check inputs (gpr.py:22-26)
         assert isinstance(kernel, (kernels.Matern12, kernels.Matern32, kernels.Matern52))
@@ -222,19 +241,8 @@ class GPR_1d:
             var[:nfull] = v_.cpu().numpy()
         return mean, var
 
-    def predict_y(self, Xnew):
-        mean, var = self.predict_f(Xnew)
-        return mean, var + float(self.likelihood.variance)
 
-    def predict_log_density(self, data):
-        """gpflow GPModel.predict_log_density for the Gaussian likelihood (used by large_regression/electricity.py:138)."""
-        Xnew, Ynew = data
-        mean, var = self.predict_y(Xnew)
-        Ynew = np.asarray(Ynew, dtype=np.float64).reshape(mean.shape)
-        return -0.5 * (np.log(2 * np.pi * var) + (Ynew - mean) ** 2 / var)
-
-
-class GPR_kron:
+class GPR_kron(_GPModelSurface):
     """Drop-in for asvgp/gpr.py:239-359 (d = 2): GPR_kron((X[N,2], y[N,1]), kernels, bases) with elbo(),
     maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew).  Never densifies: KufKfu is a block band
     (asvgp_phi_accumulate_kron2d), Kuu = K1 (x) K2 is handled factor-wise (log|Kuu| = m2 log|K1| + m1 log|K2|, the trace
@@ -523,7 +531,7 @@ class GPR_kron:
         return mean.reshape(-1, 1), var.reshape(-1, 1)
 
 
-class GPR_additive:
+class GPR_additive(_GPModelSurface):
     """Drop-in for asvgp/gpr.py:139-236: GPR_additive((X[N,d], y[N,1]), kernels, bases) with elbo(),
     maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew), fit().
 

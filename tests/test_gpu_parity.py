@@ -982,3 +982,28 @@ def test_kron_cell_sorted_phi_pass_equals_per_point_pass(A, order, m1, m2, N):
     assert np.all(np.diff(cid) >= 0)
     st = start.cpu().numpy()
     assert st[-1] == N and np.array_equal(np.bincount(cid, minlength=len(st) - 1), np.diff(st))
+
+
+def test_gpmodel_surface_on_every_model_class(A):
+    """trainable_variables / predict_y / predict_log_density (the GPflow GPModel methods the scripts call) exist on all three
+    model classes and agree with the posterior moments."""
+    from scipy.stats import norm
+    rng = np.random.default_rng(8)
+    N = 800
+    X = rng.uniform(0.01, 0.99, (N, 2))
+    y = np.sin(5 * X[:, :1]) + X[:, 1:] + 0.1 * rng.normal(size=(N, 1))
+    bases = [A.B3Spline(0, 1, 12), A.B3Spline(0, 1, 11)]
+    models = [A.GPR_1d((X[:, :1], y), A.Matern32(), bases[0]),
+              A.GPR_kron((X, y), [A.Matern32(), A.Matern32()], bases),
+              A.GPR_additive((X, y), [A.Matern32(), A.Matern32()], bases)]
+    for m in models:
+        d = 1 if isinstance(m, A.GPR_1d) else 2
+        m.likelihood.variance.assign(0.05)
+        Xs, ys = X[:50, :d], y[:50]
+        assert len(m.trainable_variables) == len(m.trainable_parameters) == (3 if d == 1 else 5)
+        mf, vf = m.predict_f(Xs)
+        my, vy = m.predict_y(Xs)
+        np.testing.assert_allclose(my, mf)
+        np.testing.assert_allclose(vy, vf + 0.05, rtol=1e-12)
+        ld = m.predict_log_density((Xs, ys))
+        np.testing.assert_allclose(ld, norm.logpdf(ys, loc=my, scale=np.sqrt(vy)), rtol=1e-10, atol=1e-12)
