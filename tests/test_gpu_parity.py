@@ -577,7 +577,17 @@ def _shard_worker(rank, world, port, q):
                      process_group=dist.group.WORLD)
     model.likelihood.variance.assign(0.01)
     r = model.elbo_and_grad().cpu().numpy()
-    q.put((rank, model.num_data, model._stats.cpu().numpy(), r))
+    # the 2-D models shard the same way (block band / flat additive buffer through the same all-reduce)
+    rng2 = np.random.default_rng(77)
+    N2 = 6001
+    X2 = rng2.uniform(0.001, 0.999, (N2, 2))
+    y2 = np.sin(5 * X2[:, :1]) + X2[:, 1:] ** 2 + 0.1 * rng2.normal(size=(N2, 1))
+    lo2, hi2 = shard_bounds(N2, world, rank)
+    bases2 = [A.B3Spline(0, 1, 11), A.B3Spline(0, 1, 10)]
+    mk = A.GPR_kron((X2[lo2:hi2], y2[lo2:hi2]), [A.Matern32(), A.Matern32()], bases2, process_group=dist.group.WORLD)
+    ma = A.GPR_additive((X2[lo2:hi2], y2[lo2:hi2]), [A.Matern32(), A.Matern32()], bases2, process_group=dist.group.WORLD)
+    extra = (mk.num_data, mk.elbo().item(), ma.num_data, ma.elbo().item())
+    q.put((rank, model.num_data, model._stats.cpu().numpy(), r, extra))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -604,11 +614,20 @@ def test_two_rank_sharded_model_matches_single_rank(A):
     single.likelihood.variance.assign(0.01)
     r1 = single.elbo_and_grad().cpu().numpy()
     s1 = single._stats.cpu().numpy()
-    for rank, n_glob, stats, r in res:
+    rng2 = np.random.default_rng(77)
+    N2 = 6001
+    X2 = rng2.uniform(0.001, 0.999, (N2, 2))
+    y2 = np.sin(5 * X2[:, :1]) + X2[:, 1:] ** 2 + 0.1 * rng2.normal(size=(N2, 1))
+    bases2 = [A.B3Spline(0, 1, 11), A.B3Spline(0, 1, 10)]
+    ek = A.GPR_kron((X2, y2), [A.Matern32(), A.Matern32()], bases2).elbo().item()
+    ea = A.GPR_additive((X2, y2), [A.Matern32(), A.Matern32()], bases2).elbo().item()
+    for rank, n_glob, stats, r, extra in res:
         assert n_glob == N
         assert np.max(np.abs(stats - s1)) <= 1e-12 * np.max(np.abs(s1))
         assert abs(r[0] - r1[0]) <= elbo_tol(r1[0], N, 1.0, 0.01, float(s1[-1]), bcr=True)
         np.testing.assert_allclose(r[1:4], r1[1:4], rtol=1e-6)
+        assert extra[0] == N2 and extra[2] == N2
+        assert abs(extra[1] - ek) <= 1e-9 * abs(ek) and abs(extra[3] - ea) <= 1e-9 * abs(ea)
 
 
 def test_split_prior_and_data_chain_equals_fused_call(A):
