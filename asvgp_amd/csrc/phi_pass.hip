@@ -1268,7 +1268,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
                               (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
       const bool prof = g_prof_on && g_prof_n < PROF_RING && (g_prof_calls++ % g_prof_every == 0);
-      if (prof) hipEventRecord(g_prof_ev[g_prof_n][0], st);
+      if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
       if (v4) {
         auto k4 = vec ? phi_bucket_kernel<K, true> : phi_bucket_kernel<K, false>;
         size_t band_bytes = sizeof(double) * (size_t)(K + 2) * ncols;
@@ -1295,7 +1295,7 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
                            inv_delta, cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n, s0);
       }
       zeroed = true;
-      if (prof) { hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
+      if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
       int E1 = (K + 2) * ncols + 1;
       int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
       hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, partials, G, ncols, K,
@@ -1343,7 +1343,7 @@ extern "C" int asvgp_profile_read(double* phi_kernel_ms_sum, int64_t* launches) 
   for (long i = 0; i < g_prof_n; ++i) {
     if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return ASVGP_ERR_HIP; }
     float ms = 0.f;
-    hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]);
+    (void)hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]);
     tot += ms;
   }
   *phi_kernel_ms_sum = tot;
