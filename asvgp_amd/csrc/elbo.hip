@@ -261,14 +261,14 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    double v = wave_sum(acc[i]);
+    double v = wave_sum_dpp(acc[i]);
     if (lane == 0) part[wv][i] = v;
   }
   __syncthreads();
   double tot[NACC];
   if (threadIdx.x < 64) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) tot[i] = wave_sum(lane < nw ? part[lane][i] : 0.0);
+    for (int i = 0; i < NACC; ++i) tot[i] = wave_sum_dpp(lane < nw ? part[lane][i] : 0.0);
   }
   (void)scratch;
   __shared__ int is_last;
