@@ -1026,3 +1026,31 @@ def test_gpmodel_surface_on_every_model_class(A):
         np.testing.assert_allclose(vy, vf + 0.05, rtol=1e-12)
         ld = m.predict_log_density((Xs, ys))
         np.testing.assert_allclose(ld, norm.logpdf(ys, loc=my, scale=np.sqrt(vy)), rtol=1e-10, atol=1e-12)
+
+
+def test_predict_paths_odd_counts_unaligned_and_staged(A, S):
+    """predict_1d: the vector path (two points per lane, 16-B loads), its odd tail, the scalar path for an unaligned input
+    slice, and the LDS-staged form (n* >= 65 536) all give the posterior of the banded oracle."""
+    X, y = S["X"], S["Y"]
+    bs = A.B3Spline(-3.5, 10.5, 40)
+    model = A.GPR_1d((X, y), A.Matern32(variance=0.8, lengthscales=1.0), bs)
+    model.likelihood.variance.assign(0.08)
+    ob = O.Basis(3, -3.5, 10.5, 40)
+    Ab, b, yy = O.sufficient_stats_direct(ob, X[:, 0], y)
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 3, 7, 4096, 65_537, 70_001):
+        xs = rng.uniform(-3.4, 10.4, n + 1)
+        om, ov = O.predict_f_1d_banded(ob, 1, Ab, b, 0.8, 1.0, 0.08, xs[1:].reshape(-1, 1)) if n <= 4096 else (None, None)
+        for view in (dev(xs[1:].copy()), dev(xs)[1:]):              # aligned copy / 8-byte-offset slice
+            mean, var = model.predict_f_device(view.reshape(-1, 1))
+            assert mean.shape == (n, 1) and var.shape == (n, 1)
+            if om is not None:
+                np.testing.assert_allclose(mean.cpu().numpy(), om, rtol=0, atol=1e-8)
+                np.testing.assert_allclose(var.cpu().numpy(), ov, rtol=0, atol=1e-8)
+            else:                                                    # large n: the two load paths must agree bit for bit
+                ref = model.predict_f_device(dev(xs[1:].copy()).reshape(-1, 1))
+                assert torch.equal(mean, ref[0]) and torch.equal(var, ref[1])
+                sub = slice(0, 500)
+                om2, ov2 = O.predict_f_1d_banded(ob, 1, Ab, b, 0.8, 1.0, 0.08, xs[1:][sub].reshape(-1, 1))
+                np.testing.assert_allclose(mean.cpu().numpy()[sub], om2, rtol=0, atol=1e-8)
+                np.testing.assert_allclose(var.cpu().numpy()[sub], ov2, rtol=0, atol=1e-8)
