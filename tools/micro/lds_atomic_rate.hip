@@ -25,6 +25,22 @@ __global__ __launch_bounds__(1024) void k(T* out, int words, int iters, unsigned
     if (MODE == 0) {   // 20 adds at 20 unrelated offsets (like the band scatter: 5 rows x different planes)
 #pragma unroll
       for (int j = 0; j < 20; ++j) lds_add<T>(lds + ((a + j * 2049u) & (unsigned)(words - 1)), v);
+    } else if (MODE == 2) {   // random cells, but the 16 lanes of a group hit 16 different (address mod 16): bank-conflict-free
+      const unsigned a16 = (a & ~15u) | ((threadIdx.x * 5u + (s >> 28)) & 15u);   // (x5: a permutation of 0..15 across the group)
+#pragma unroll
+      for (int j = 0; j < 20; ++j) lds_add<T>(lds + ((a16 + j * 2048u) & (unsigned)(words - 1)), v);
+    } else if (MODE == 3) {   // random cells, (address mod 32) distinct within each half-wave of 32 lanes
+      const unsigned a32 = (a & ~31u) | ((threadIdx.x * 5u + (s >> 27)) & 31u);
+#pragma unroll
+      for (int j = 0; j < 20; ++j) lds_add<T>(lds + ((a32 + j * 2048u) & (unsigned)(words - 1)), v);
+    } else if (MODE == 4) {   // random cells, (address mod 64) distinct over the whole wave
+      const unsigned a64 = (a & ~63u) | ((threadIdx.x * 5u + (s >> 26)) & 63u);
+#pragma unroll
+      for (int j = 0; j < 20; ++j) lds_add<T>(lds + ((a64 + j * 2048u) & (unsigned)(words - 1)), v);
+    } else if (MODE == 5) {   // consecutive addresses (lane l -> base + l): the ideal
+      const unsigned ab = (a & ~63u) | (threadIdx.x & 63u);
+#pragma unroll
+      for (int j = 0; j < 20; ++j) lds_add<T>(lds + ((ab + j * 2048u) & (unsigned)(words - 1)), v);
     } else {           // plain stores for reference
 #pragma unroll
       for (int j = 0; j < 20; ++j) lds[(a + j * 2049u) & (unsigned)(words - 1)] = v;
@@ -63,6 +79,10 @@ int main() {
   run<unsigned long long, 0>("ds_add_u64", 8192);
   run<float, 0>("ds_add_f32", 8192);
   run<unsigned, 0>("ds_add_u32", 8192);
+  run<unsigned long long, 2>("ds_add_u64 bank-distinct per 16 lanes", 8192);
+  run<unsigned long long, 3>("ds_add_u64 distinct mod 32 per 32 lanes", 8192);
+  run<unsigned long long, 4>("ds_add_u64 distinct mod 64 per wave", 8192);
+  run<unsigned long long, 5>("ds_add_u64 consecutive", 8192);
   run<double, 1>("ds_write_b64", 8192);
   run<float, 1>("ds_write_b32", 8192);
   return 0;
