@@ -762,27 +762,34 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
       const int e = tid + q * BCR_THREADS;
       dv[q] = (e < nb * B) ? Wn(e / B).get(Lay::W_L + (e % B) * B + (e % B)) : N::make(1.0, 0.0);
     }
+    double prod = 1.0;   // ... then ONE log of the product (<= 16 factors between ~1e-4 and ~1e4: no range problem) instead of RMAX logs
 #pragma unroll
-    for (int q = 0; q < RMAX; ++q) {   // ... then the logs
-      ld_acc += 2.0 * log(N::val(dv[q]));
+    for (int q = 0; q < RMAX; ++q) {
+      prod *= N::val(dv[q]);
       dld_acc += 2.0 * N::tan(dv[q]) / N::val(dv[q]);
     }
+    ld_acc = 2.0 * log(prod);
   }
-  // reductions
-  double tot = block_sum(ld_acc, red);
-  double dtot = block_sum(dld_acc, red);
-  stamp();
-  if (tid == 0) {
-    logdet[0] = tot;
-    logdet[1] = dtot;
+  // one combined reduction (log-det, its tangent, first failing column) with a single barrier
+  {
+    const double a = wave_sum_dpp(ld_acc), b = wave_sum_dpp(dld_acc);
+    int bm = bad ? bad : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(bm, off, 64); bm = o < bm ? o : bm; }
+    int* sbad = reinterpret_cast<int*>(red + 32);
+    const int lane_ = tid & 63, w_ = tid >> 6;
+    if (lane_ == 0) { red[w_] = a; red[16 + w_] = b; sbad[w_] = bm; }
+    __syncthreads();
+    stamp();
+    if (tid == 0) {
+      double tot = 0.0, dtot = 0.0;
+      int bmin = 0x7fffffff;
+      for (int w = 0; w < BCR_THREADS / 64; ++w) { tot += red[w]; dtot += red[16 + w]; bmin = sbad[w] < bmin ? sbad[w] : bmin; }
+      logdet[0] = tot;
+      logdet[1] = dtot;
+      *info = (bmin == 0x7fffffff) ? 0 : bmin;
+    }
   }
-  int* sbad = reinterpret_cast<int*>(red + 32);  // smallest failing column + 1 over the workgroup
-  __syncthreads();
-  if (tid == 0) *sbad = 0x7fffffff;
-  __syncthreads();
-  if (bad) atomicMin(sbad, bad);
-  __syncthreads();
-  if (tid == 0) *info = (*sbad == 0x7fffffff) ? 0 : *sbad;
 }
 
 }  // namespace asvgp
