@@ -176,6 +176,38 @@ def main():
         t_phi = t_comm = t_band = 0.0
     out4 = model._out.cpu().numpy()
 
+    # Extra, N > 1 only: the same step with the BASELINE N on EVERY rank (weak scaling).  `value` above stays the strong-scaling
+    # figure the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
+    weak = None
+    if world > 1 and not os.environ.get("ASVGP_BENCH_NOWEAK"):
+        try:
+            xw, yw = synth(N, seed=1234 + rank)
+            del model
+            xd = torch.from_numpy(xw).cuda().reshape(-1, 1)
+            yd = torch.from_numpy(yw).cuda().reshape(-1, 1)
+            model = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
+            model.likelihood.variance.assign(theta[2])
+            model.num_data = N * world
+            stats = model._stats
+            marks.clear()
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tw0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tw = torch.tensor([time.perf_counter() - tw0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            weak = {"value": N * world / (tw.item() / args.steps) / 1e6, "unit": "Mpoints/s", "points_per_rank": N,
+                    "ms_per_step": tw.item() / args.steps * 1e3, "scaling": "weak"}
+        except Exception as exc:   # never let the extra measurement break the contract line
+            weak = {"error": repr(exc)[:200]}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         kern_us = ms_sum.value / max(launches.value, 1) * 1e3
@@ -205,6 +237,8 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local},
             "elbo": float(out4[0]), "grad": [float(v) for v in out4[1:4]],
         }
+        if weak is not None:
+            line["weak_scaling_extra"] = weak
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, M, theta)
         print(json.dumps(line), flush=True)
