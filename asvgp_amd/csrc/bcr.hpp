@@ -15,6 +15,7 @@
 //       S_ia = -(G_a S_aa + G_b S_ba),  S_ib = -(G_a S_ab + G_b S_bb),  S_ii = D_i^-1 - S_ia G_a^T - S_ib G_b^T
 //   T = double, or Dual for the forward-mode tangent (d/d lengthscale of band(Kuu^-1)).
 #pragma once
+#include <type_traits>
 #include "band_sweeps.hpp"
 #include "bcr_lane.hpp"
 
@@ -361,115 +362,122 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
       stamp();
       continue;
     }
-    for (int m0 = 0; m0 < ne; m0 += BCR_THREADS) {   // more eliminated nodes than threads: several rounds
-      const int m = m0 + tid;
-      const bool act = m < ne;
-      const int i = h + m * 2 * h, a = i - h, b = i + h;
-      const bool hasb = act && (b < nb);
-      T Ua[B][B], Ub[B][B], D[B][B], invd[B];
-      double z[B];
-      if (act) {
-        // load D_i, A[i,a] (= E(a)), A[b,i]^T (= E(i)^T), y_i
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c < B; ++c) {
-            if (l == 0) {
-              D[r][c] = (c <= r) ? band_D<T, B, Src>(A, M, i, r, c) : N::zero();
-              Ua[r][c] = band_E<T, B, Src>(A, M, a, r, c);
-              Ub[r][c] = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
-            } else {
-              D[r][c] = (c <= r) ? F.getD(r * B + c, i >> 1) : N::zero();
-              Ua[r][c] = F.getE(r * B + c, a >> 1);
-              Ub[r][c] = hasb ? F.getE(c * B + r, i >> 1) : N::zero();
+    // level 0 and the deeper levels get separate copies of the one-thread-per-node body (own register allocation, no band
+    // gather code in the deeper levels)
+    auto fwd_thread = [&](auto is0) {
+      constexpr bool IS0 = decltype(is0)::value;
+      for (int m0 = 0; m0 < ne; m0 += BCR_THREADS) {   // more eliminated nodes than threads: several rounds
+        const int m = m0 + tid;
+        const bool act = m < ne;
+        const int i = h + m * 2 * h, a = i - h, b = i + h;
+        const bool hasb = act && (b < nb);
+        T Ua[B][B], Ub[B][B], D[B][B], invd[B];
+        double z[B];
+        if (act) {
+          // load D_i, A[i,a] (= E(a)), A[b,i]^T (= E(i)^T), y_i
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {
+              if constexpr (IS0) {
+                D[r][c] = (c <= r) ? band_D<T, B, Src>(A, M, i, r, c) : N::zero();
+                Ua[r][c] = band_E<T, B, Src>(A, M, a, r, c);
+                Ub[r][c] = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
+              } else {
+                D[r][c] = (c <= r) ? F.getD(r * B + c, i >> 1) : N::zero();
+                Ua[r][c] = F.getE(r * B + c, a >> 1);
+                Ub[r][c] = hasb ? F.getE(c * B + r, i >> 1) : N::zero();
+              }
+            }
+          blk_chol<T, B>(D, invd, bad, i * B);
+          __builtin_amdgcn_sched_barrier(0);   // (phase fences: keep the scheduler from overlapping the phases' live ranges - Dual blocks spill otherwise)
+          blk_solve_L<T, B, B>(D, invd, Ua);
+          __builtin_amdgcn_sched_barrier(0);
+          blk_solve_L<T, B, B>(D, invd, Ub);
+          __builtin_amdgcn_sched_barrier(0);
+          if (NRHS) {
+  #pragma unroll
+            for (int r = 0; r < B; ++r) {
+              double t = xs[i * B + r];
+  #pragma unroll
+              for (int p = 0; p < r; ++p) t = fma(-N::val(D[r][p]), z[p], t);
+              z[r] = t * N::val(invd[r]);
             }
           }
-        blk_chol<T, B>(D, invd, bad, i * B);
-        __builtin_amdgcn_sched_barrier(0);   // (phase fences: keep the scheduler from overlapping the phases' live ranges - Dual blocks spill otherwise)
-        blk_solve_L<T, B, B>(D, invd, Ua);
-        __builtin_amdgcn_sched_barrier(0);
-        blk_solve_L<T, B, B>(D, invd, Ub);
-        __builtin_amdgcn_sched_barrier(0);
-        if (NRHS) {
-#pragma unroll
+          // factors -> workspace (log-determinant terms are summed from the stored diagonals after the solve)
+  #pragma unroll
           for (int r = 0; r < B; ++r) {
-            double t = xs[i * B + r];
-#pragma unroll
-            for (int p = 0; p < r; ++p) t = fma(-N::val(D[r][p]), z[p], t);
-            z[r] = t * N::val(invd[r]);
+            Wn(i).set(Lay::W_I + r, invd[r]);
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {
+              Wn(i).set(Lay::W_L + r * B + c, (c <= r) ? D[r][c] : N::zero());
+              Wn(i).set(Lay::W_UA + r * B + c, Ua[r][c]);
+              Wn(i).set(Lay::W_UB + r * B + c, Ub[r][c]);
+            }
+          }
+          if (NRHS) {
+  #pragma unroll
+            for (int r = 0; r < B; ++r) xs[i * B + r] = z[r];  // z_i overwrites y_i (read back in the backward pass)
+          }
+          // phase A: left neighbour a
+          const int sa = a >> 1;
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c <= r; ++c) {  // D_a -= Ua^T Ua (symmetric, keep both halves)
+              T t = F.getD(r * B + c, sa);
+  #pragma unroll
+              for (int p = 0; p < B; ++p) t = N::nfma(Ua[p][r], Ua[p][c], t);
+              F.setD(r * B + c, sa, t);
+              if (c != r) F.setD(c * B + r, sa, t);
+            }
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {  // E(a) := A'[b,a] = -Ub^T Ua
+              T t = N::zero();
+  #pragma unroll
+              for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ua[p][c], t);
+              F.setE(r * B + c, sa, t);
+            }
+          if (NRHS) {
+  #pragma unroll
+            for (int r = 0; r < B; ++r) {
+              double t = xs[a * B + r];
+  #pragma unroll
+              for (int p = 0; p < B; ++p) t = fma(-N::val(Ua[p][r]), z[p], t);
+              xs[a * B + r] = t;
+            }
           }
         }
-        // factors -> workspace (log-determinant terms are summed from the stored diagonals after the solve)
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-          Wn(i).set(Lay::W_I + r, invd[r]);
-#pragma unroll
-          for (int c = 0; c < B; ++c) {
-            Wn(i).set(Lay::W_L + r * B + c, (c <= r) ? D[r][c] : N::zero());
-            Wn(i).set(Lay::W_UA + r * B + c, Ua[r][c]);
-            Wn(i).set(Lay::W_UB + r * B + c, Ub[r][c]);
+        bcr_barrier<BIG>();
+        if (hasb) {  // phase B: right neighbour b
+          const int sb = b >> 1;
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c <= r; ++c) {
+              T t = F.getD(r * B + c, sb);
+  #pragma unroll
+              for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ub[p][c], t);
+              F.setD(r * B + c, sb, t);
+              if (c != r) F.setD(c * B + r, sb, t);
+            }
+          if (NRHS) {
+  #pragma unroll
+            for (int r = 0; r < B; ++r) {
+              double t = xs[b * B + r];
+  #pragma unroll
+              for (int p = 0; p < B; ++p) t = fma(-N::val(Ub[p][r]), z[p], t);
+              xs[b * B + r] = t;
+            }
           }
         }
-        if (NRHS) {
-#pragma unroll
-          for (int r = 0; r < B; ++r) xs[i * B + r] = z[r];  // z_i overwrites y_i (read back in the backward pass)
-        }
-        // phase A: left neighbour a
-        const int sa = a >> 1;
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c <= r; ++c) {  // D_a -= Ua^T Ua (symmetric, keep both halves)
-            T t = F.getD(r * B + c, sa);
-#pragma unroll
-            for (int p = 0; p < B; ++p) t = N::nfma(Ua[p][r], Ua[p][c], t);
-            F.setD(r * B + c, sa, t);
-            if (c != r) F.setD(c * B + r, sa, t);
-          }
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c < B; ++c) {  // E(a) := A'[b,a] = -Ub^T Ua
-            T t = N::zero();
-#pragma unroll
-            for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ua[p][c], t);
-            F.setE(r * B + c, sa, t);
-          }
-        if (NRHS) {
-#pragma unroll
-          for (int r = 0; r < B; ++r) {
-            double t = xs[a * B + r];
-#pragma unroll
-            for (int p = 0; p < B; ++p) t = fma(-N::val(Ua[p][r]), z[p], t);
-            xs[a * B + r] = t;
-          }
-        }
+        bcr_barrier<BIG>();
       }
-      bcr_barrier<BIG>();
-      if (hasb) {  // phase B: right neighbour b
-        const int sb = b >> 1;
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c <= r; ++c) {
-            T t = F.getD(r * B + c, sb);
-#pragma unroll
-            for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ub[p][c], t);
-            F.setD(r * B + c, sb, t);
-            if (c != r) F.setD(c * B + r, sb, t);
-          }
-        if (NRHS) {
-#pragma unroll
-          for (int r = 0; r < B; ++r) {
-            double t = xs[b * B + r];
-#pragma unroll
-            for (int p = 0; p < B; ++p) t = fma(-N::val(Ub[p][r]), z[p], t);
-            xs[b * B + r] = t;
-          }
-        }
-      }
-      bcr_barrier<BIG>();
-    }
+    };
+    if (l == 0) fwd_thread(std::true_type{});
+    else fwd_thread(std::false_type{});
     stamp();
   }
 
@@ -631,116 +639,123 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
       stamp();
       continue;
     }
-    for (int m0 = 0; m0 < ne; m0 += BCR_THREADS) {
-      const int m = m0 + tid;
-      if (m < ne) {
-        const int i = h + m * 2 * h, a = i - h, b = i + h;
-        const bool hasb = b < nb;
-        T L[B][B], invd[B], Ga[B][B], Gb[B][B];
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-          invd[r] = Wn(i).get(Lay::W_I + r);
-#pragma unroll
-          for (int c = 0; c < B; ++c) {
-            L[r][c] = Wn(i).get(Lay::W_L + r * B + c);
-            Ga[r][c] = Wn(i).get(Lay::W_UA + r * B + c);
-            Gb[r][c] = Wn(i).get(Lay::W_UB + r * B + c);
-          }
-        }
-        if (NRHS) {  // x_i = L^-T (z - Ua x_a - Ub x_b)
-          double t[B];
-#pragma unroll
+    // level 0 and the deeper levels get separate copies of the one-thread-per-node body (own register allocation, no band
+    // gather / output code where it is not needed)
+    auto bwd_thread = [&](auto is0) {
+      constexpr bool IS0 = decltype(is0)::value;
+      for (int m0 = 0; m0 < ne; m0 += BCR_THREADS) {
+        const int m = m0 + tid;
+        if (m < ne) {
+          const int i = h + m * 2 * h, a = i - h, b = i + h;
+          const bool hasb = b < nb;
+          T L[B][B], invd[B], Ga[B][B], Gb[B][B];
+  #pragma unroll
           for (int r = 0; r < B; ++r) {
-            double v = xs[i * B + r];
-#pragma unroll
-            for (int p = 0; p < B; ++p) {
-              v = fma(-N::val(Ga[r][p]), xs[a * B + p], v);
-              if (hasb) v = fma(-N::val(Gb[r][p]), xs[b * B + p], v);
+            invd[r] = Wn(i).get(Lay::W_I + r);
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {
+              L[r][c] = Wn(i).get(Lay::W_L + r * B + c);
+              Ga[r][c] = Wn(i).get(Lay::W_UA + r * B + c);
+              Gb[r][c] = Wn(i).get(Lay::W_UB + r * B + c);
             }
-            t[r] = v;
           }
-#pragma unroll
-          for (int r = B - 1; r >= 0; --r) {
-            double v = t[r];
-#pragma unroll
-            for (int p = r + 1; p < B; ++p) v = fma(-N::val(L[p][r]), t[p], v);
-            t[r] = v * N::val(invd[r]);
+          if (NRHS) {  // x_i = L^-T (z - Ua x_a - Ub x_b)
+            double t[B];
+  #pragma unroll
+            for (int r = 0; r < B; ++r) {
+              double v = xs[i * B + r];
+  #pragma unroll
+              for (int p = 0; p < B; ++p) {
+                v = fma(-N::val(Ga[r][p]), xs[a * B + p], v);
+                if (hasb) v = fma(-N::val(Gb[r][p]), xs[b * B + p], v);
+              }
+              t[r] = v;
+            }
+  #pragma unroll
+            for (int r = B - 1; r >= 0; --r) {
+              double v = t[r];
+  #pragma unroll
+              for (int p = r + 1; p < B; ++p) v = fma(-N::val(L[p][r]), t[p], v);
+              t[r] = v * N::val(invd[r]);
+            }
+  #pragma unroll
+            for (int r = 0; r < B; ++r) xs[i * B + r] = t[r];
           }
-#pragma unroll
-          for (int r = 0; r < B; ++r) xs[i * B + r] = t[r];
+          __builtin_amdgcn_sched_barrier(0);
+          blk_solve_LT<T, B, B>(L, invd, Ga);  // G_a = L^-T U_a = D^-1 A[i,a]
+          __builtin_amdgcn_sched_barrier(0);
+          blk_solve_LT<T, B, B>(L, invd, Gb);
+          __builtin_amdgcn_sched_barrier(0);
+          // neighbour blocks of the inverse
+          T Saa[B][B], Sbb[B][B], Sba[B][B];
+          const bool e_is_a = ((a / (2 * h)) & 1) != 0;  // which of a,b was eliminated at level l+1
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {
+              Saa[r][c] = Wn(a).get(Lay::W_SD + r * B + c);
+              if (hasb) {
+                Sbb[r][c] = Wn(b).get(Lay::W_SD + r * B + c);
+                // Sigma_ba: e = a -> (C_a^b)^T ; e = b -> C_b^a
+                Sba[r][c] = e_is_a ? Wn(a).get(Lay::W_CB + c * B + r) : Wn(b).get(Lay::W_CA + r * B + c);
+              } else {
+                Sbb[r][c] = N::zero();
+                Sba[r][c] = N::zero();
+              }
+            }
+          T Ca[B][B], Cb[B][B], Sii[B][B];
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {
+              T ta = N::zero(), tb = N::zero();
+  #pragma unroll
+              for (int p = 0; p < B; ++p) {
+                ta = N::nfma(Ga[r][p], Saa[p][c], ta);       // -(Ga Saa)
+                ta = N::nfma(Gb[r][p], Sba[p][c], ta);       // -(Gb Sba)
+                tb = N::nfma(Ga[r][p], Sba[c][p], tb);       // -(Ga Sab), Sab = Sba^T
+                tb = N::nfma(Gb[r][p], Sbb[p][c], tb);       // -(Gb Sbb)
+              }
+              Ca[r][c] = ta;
+              Cb[r][c] = tb;
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          // D_i^-1 = L^-T L^-1
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c < B; ++c) Sii[r][c] = (r == c) ? N::make(1.0, 0.0) : N::zero();
+          blk_solve_L<T, B, B>(L, invd, Sii);
+          blk_solve_LT<T, B, B>(L, invd, Sii);
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int r = 0; r < B; ++r)
+  #pragma unroll
+            for (int c = 0; c < B; ++c) {
+              T t = Sii[r][c];
+  #pragma unroll
+              for (int p = 0; p < B; ++p) {
+                t = N::nfma(Ca[r][p], Ga[c][p], t);
+                t = N::nfma(Cb[r][p], Gb[c][p], t);
+              }
+              if constexpr (!IS0) {   // blocks a deeper level will read (nothing reads a level-0 node again)
+                Wn(i).set(Lay::W_SD + r * B + c, t);
+                Wn(i).set(Lay::W_CA + r * B + c, Ca[r][c]);
+                Wn(i).set(Lay::W_CB + r * B + c, Cb[r][c]);
+              }
+              // the band of the inverse leaves from here (see the lane-distributed branch)
+              if (c <= r && i * B + r < M) S.store((long)(r - c) * M + i * B + c, t);
+              if constexpr (IS0) {
+                if (r <= c && i * B + r < M) S.store((long)(B + r - c) * M + a * B + c, Ca[r][c]);
+                if (hasb && c <= r && b * B + c < M) S.store((long)(B + c - r) * M + i * B + r, Cb[r][c]);
+              }
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        blk_solve_LT<T, B, B>(L, invd, Ga);  // G_a = L^-T U_a = D^-1 A[i,a]
-        __builtin_amdgcn_sched_barrier(0);
-        blk_solve_LT<T, B, B>(L, invd, Gb);
-        __builtin_amdgcn_sched_barrier(0);
-        // neighbour blocks of the inverse
-        T Saa[B][B], Sbb[B][B], Sba[B][B];
-        const bool e_is_a = ((a / (2 * h)) & 1) != 0;  // which of a,b was eliminated at level l+1
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c < B; ++c) {
-            Saa[r][c] = Wn(a).get(Lay::W_SD + r * B + c);
-            if (hasb) {
-              Sbb[r][c] = Wn(b).get(Lay::W_SD + r * B + c);
-              // Sigma_ba: e = a -> (C_a^b)^T ; e = b -> C_b^a
-              Sba[r][c] = e_is_a ? Wn(a).get(Lay::W_CB + c * B + r) : Wn(b).get(Lay::W_CA + r * B + c);
-            } else {
-              Sbb[r][c] = N::zero();
-              Sba[r][c] = N::zero();
-            }
-          }
-        T Ca[B][B], Cb[B][B], Sii[B][B];
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c < B; ++c) {
-            T ta = N::zero(), tb = N::zero();
-#pragma unroll
-            for (int p = 0; p < B; ++p) {
-              ta = N::nfma(Ga[r][p], Saa[p][c], ta);       // -(Ga Saa)
-              ta = N::nfma(Gb[r][p], Sba[p][c], ta);       // -(Gb Sba)
-              tb = N::nfma(Ga[r][p], Sba[c][p], tb);       // -(Ga Sab), Sab = Sba^T
-              tb = N::nfma(Gb[r][p], Sbb[p][c], tb);       // -(Gb Sbb)
-            }
-            Ca[r][c] = ta;
-            Cb[r][c] = tb;
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        // D_i^-1 = L^-T L^-1
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c < B; ++c) Sii[r][c] = (r == c) ? N::make(1.0, 0.0) : N::zero();
-        blk_solve_L<T, B, B>(L, invd, Sii);
-        blk_solve_LT<T, B, B>(L, invd, Sii);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-          for (int c = 0; c < B; ++c) {
-            T t = Sii[r][c];
-#pragma unroll
-            for (int p = 0; p < B; ++p) {
-              t = N::nfma(Ca[r][p], Ga[c][p], t);
-              t = N::nfma(Cb[r][p], Gb[c][p], t);
-            }
-            if (l > 0) {   // blocks a deeper level will read (nothing reads a level-0 node again)
-              Wn(i).set(Lay::W_SD + r * B + c, t);
-              Wn(i).set(Lay::W_CA + r * B + c, Ca[r][c]);
-              Wn(i).set(Lay::W_CB + r * B + c, Cb[r][c]);
-            }
-            // the band of the inverse leaves from here (see the lane-distributed branch)
-            if (c <= r && i * B + r < M) S.store((long)(r - c) * M + i * B + c, t);
-            if (l == 0) {
-              if (r <= c && i * B + r < M) S.store((long)(B + r - c) * M + a * B + c, Ca[r][c]);
-              if (hasb && c <= r && b * B + c < M) S.store((long)(B + c - r) * M + i * B + r, Cb[r][c]);
-            }
-          }
+        __syncthreads();
       }
-      __syncthreads();
-    }
+    };
+    if (l == 0) bwd_thread(std::true_type{});
+    else bwd_thread(std::false_type{});
     stamp();
   }
 
