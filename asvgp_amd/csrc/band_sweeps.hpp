@@ -23,10 +23,28 @@ template <typename T> struct BandPtr;  // read-only band (value [+ tangent]) row
 template <> struct BandPtr<double> {
   const double* v; const double* d;
   __device__ __forceinline__ double load(long off, bool ok) const { return ok ? v[off] : 0.0; }
+  // eight consecutive band entries with 16-B loads (off a multiple of 2, v 16-B aligned)
+  __device__ __forceinline__ void load8(long off, double (&o)[8]) const {
+    const double2* p = reinterpret_cast<const double2*>(v + off);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double2 t = p[q]; o[2 * q] = t.x; o[2 * q + 1] = t.y; }
+  }
+  __device__ __forceinline__ bool aligned16() const { return (reinterpret_cast<uintptr_t>(v) & 15) == 0; }
 };
 template <> struct BandPtr<Dual> {
   const double* v; const double* d;
   __device__ __forceinline__ Dual load(long off, bool ok) const { return ok ? Dual{v[off], d[off]} : Dual{0.0, 0.0}; }
+  __device__ __forceinline__ void load8(long off, Dual (&o)[8]) const {
+    const double2* p = reinterpret_cast<const double2*>(v + off);
+    const double2* q2 = reinterpret_cast<const double2*>(d + off);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 t = p[q], u = q2[q];
+      o[2 * q] = Dual{t.x, u.x};
+      o[2 * q + 1] = Dual{t.y, u.y};
+    }
+  }
+  __device__ __forceinline__ bool aligned16() const { return ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(d)) & 15) == 0; }
 };
 template <typename T> struct BandOut;
 template <> struct BandOut<double> {

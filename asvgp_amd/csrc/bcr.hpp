@@ -154,6 +154,17 @@ struct BandSumP {
   const double* A; const double* Kuu; double inv_s;   // A * (1/s): within 1 ulp of the reference's A / s (gpr.py:72); 40 fp64
                                                       // divisions per node on the prepass / level-0 chain were ~4 % of the P chain
   __device__ __forceinline__ double load(long off, bool ok) const { return ok ? __dadd_rn(__dmul_rn(A[off], inv_s), Kuu[off]) : 0.0; }
+  __device__ __forceinline__ void load8(long off, double (&o)[8]) const {
+    const double2* p = reinterpret_cast<const double2*>(A + off);
+    const double2* q2 = reinterpret_cast<const double2*>(Kuu + off);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 t = p[q], u = q2[q];
+      o[2 * q] = __dadd_rn(__dmul_rn(t.x, inv_s), u.x);
+      o[2 * q + 1] = __dadd_rn(__dmul_rn(t.y, inv_s), u.y);
+    }
+  }
+  __device__ __forceinline__ bool aligned16() const { return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Kuu)) & 15) == 0; }
 };
 
 template <typename T, int B, typename Src>
@@ -229,8 +240,14 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
     }
   };
 
+  // FAST0 (k = 4, M a multiple of 8, 16-B aligned bands, level 0 in one-thread-per-node form, one round): thread m reads the
+  // band slab of its node pair (2m, 2m+1) - 5 diagonals x 64 contiguous bytes, 16-B loads, coalesced across the wave - inside
+  // level 0 and writes the updated D_2m straight to the LDS; the pre-pass gather (8-B loads at a 64-B stride) is skipped.
+  // (One round only: a second round's D_2m would not be in the LDS yet when the first round's phase B updates it.)
+  const int ne0 = (nb > 1) ? nb / 2 : 0;
+  const bool fast0 = (B == 4) && ((M & 7) == 0) && A.aligned16() && (ne0 > LANE_MAX_NODES) && (ne0 <= BCR_THREADS);
   // pre-pass: even nodes -> LDS slots (D lower part + mirrored upper); all gathers issued before the first LDS store
-  for (int n = 2 * tid; n < nb; n += 2 * BCR_THREADS) {
+  for (int n = 2 * tid; n < nb && !fast0; n += 2 * BCR_THREADS) {
     const int s = n >> 1;
     T tmp[B * (B + 1) / 2];
     int e = 0;
@@ -371,24 +388,47 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
         const bool act = m < ne;
         const int i = h + m * 2 * h, a = i - h, b = i + h;
         const bool hasb = act && (b < nb);
-        T Ua[B][B], Ub[B][B], D[B][B], invd[B];
+        T Ua[B][B], Ub[B][B], D[B][B], Da[B][B], invd[B];
         double z[B];
         if (act) {
           // load D_i, A[i,a] (= E(a)), A[b,i]^T (= E(i)^T), y_i
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {
               if constexpr (IS0) {
-                D[r][c] = (c <= r) ? band_D<T, B, Src>(A, M, i, r, c) : N::zero();
-                Ua[r][c] = band_E<T, B, Src>(A, M, a, r, c);
-                Ub[r][c] = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
+                if (!fast0) {
+                  D[r][c] = (c <= r) ? band_D<T, B, Src>(A, M, i, r, c) : N::zero();
+                  Ua[r][c] = band_E<T, B, Src>(A, M, a, r, c);
+                  Ub[r][c] = hasb ? band_E<T, B, Src>(A, M, i, c, r) : N::zero();  // transpose: A[i,b] = A[b,i]^T
+                }
               } else {
                 D[r][c] = (c <= r) ? F.getD(r * B + c, i >> 1) : N::zero();
                 Ua[r][c] = F.getE(r * B + c, a >> 1);
                 Ub[r][c] = hasb ? F.getE(c * B + r, i >> 1) : N::zero();
               }
             }
+          if constexpr (IS0 && B == 4) {
+            if (fast0) {   // slab[d][0..3] = node a = 2m, slab[d][4..7] = node i = 2m + 1  (band[d][8m .. 8m+7])
+              T slab[B + 1][2 * B];
+#pragma unroll
+              for (int d = 0; d <= B; ++d) {
+                T row8[8];   // (fixed size keeps the other bandwidths' instantiations well-formed; fast0 implies B == 4)
+                A.load8((long)d * M + (long)a * B, row8);
+#pragma unroll
+                for (int q = 0; q < 2 * B && q < 8; ++q) slab[d][q] = row8[q];
+              }
+#pragma unroll
+              for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int c = 0; c < B; ++c) {
+                  D[r][c] = (c <= r) ? slab[r - c][B + c] : N::zero();                       // D_i
+                  Da[r][c] = (c <= r) ? slab[r - c][c] : N::zero();                          // D_a (goes to the LDS in phase A)
+                  Ua[r][c] = (r <= c) ? slab[B + r - c][c] : N::zero();                      // E(a)[r][c] = A[iB + r, aB + c]
+                  Ub[r][c] = (hasb && c <= r) ? slab[B + c - r][B + r] : N::zero();          // E(i)^T[r][c] = A[bB + c, iB + r]
+                }
+            }
+          }
           blk_chol<T, B>(D, invd, bad, i * B);
           __builtin_amdgcn_sched_barrier(0);   // (phase fences: keep the scheduler from overlapping the phases' live ranges - Dual blocks spill otherwise)
           blk_solve_L<T, B, B>(D, invd, Ua);
@@ -396,19 +436,19 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           blk_solve_L<T, B, B>(D, invd, Ub);
           __builtin_amdgcn_sched_barrier(0);
           if (NRHS) {
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < B; ++r) {
               double t = xs[i * B + r];
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < r; ++p) t = fma(-N::val(D[r][p]), z[p], t);
               z[r] = t * N::val(invd[r]);
             }
           }
           // factors -> workspace (log-determinant terms are summed from the stored diagonals after the solve)
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r) {
             Wn(i).set(Lay::W_I + r, invd[r]);
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {
               Wn(i).set(Lay::W_L + r * B + c, (c <= r) ? D[r][c] : N::zero());
               Wn(i).set(Lay::W_UA + r * B + c, Ua[r][c]);
@@ -416,35 +456,35 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
             }
           }
           if (NRHS) {
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < B; ++r) xs[i * B + r] = z[r];  // z_i overwrites y_i (read back in the backward pass)
           }
           // phase A: left neighbour a
           const int sa = a >> 1;
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c <= r; ++c) {  // D_a -= Ua^T Ua (symmetric, keep both halves)
-              T t = F.getD(r * B + c, sa);
-  #pragma unroll
+              T t = (IS0 && fast0) ? Da[r][c] : F.getD(r * B + c, sa);
+#pragma unroll
               for (int p = 0; p < B; ++p) t = N::nfma(Ua[p][r], Ua[p][c], t);
               F.setD(r * B + c, sa, t);
               if (c != r) F.setD(c * B + r, sa, t);
             }
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {  // E(a) := A'[b,a] = -Ub^T Ua
               T t = N::zero();
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ua[p][c], t);
               F.setE(r * B + c, sa, t);
             }
           if (NRHS) {
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < B; ++r) {
               double t = xs[a * B + r];
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) t = fma(-N::val(Ua[p][r]), z[p], t);
               xs[a * B + r] = t;
             }
@@ -453,21 +493,21 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
         bcr_barrier<BIG>();
         if (hasb) {  // phase B: right neighbour b
           const int sb = b >> 1;
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c <= r; ++c) {
               T t = F.getD(r * B + c, sb);
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) t = N::nfma(Ub[p][r], Ub[p][c], t);
               F.setD(r * B + c, sb, t);
               if (c != r) F.setD(c * B + r, sb, t);
             }
           if (NRHS) {
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < B; ++r) {
               double t = xs[b * B + r];
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) t = fma(-N::val(Ub[p][r]), z[p], t);
               xs[b * B + r] = t;
             }
@@ -649,10 +689,10 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           const int i = h + m * 2 * h, a = i - h, b = i + h;
           const bool hasb = b < nb;
           T L[B][B], invd[B], Ga[B][B], Gb[B][B];
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r) {
             invd[r] = Wn(i).get(Lay::W_I + r);
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {
               L[r][c] = Wn(i).get(Lay::W_L + r * B + c);
               Ga[r][c] = Wn(i).get(Lay::W_UA + r * B + c);
@@ -661,24 +701,24 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           }
           if (NRHS) {  // x_i = L^-T (z - Ua x_a - Ub x_b)
             double t[B];
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < B; ++r) {
               double v = xs[i * B + r];
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) {
                 v = fma(-N::val(Ga[r][p]), xs[a * B + p], v);
                 if (hasb) v = fma(-N::val(Gb[r][p]), xs[b * B + p], v);
               }
               t[r] = v;
             }
-  #pragma unroll
+#pragma unroll
             for (int r = B - 1; r >= 0; --r) {
               double v = t[r];
-  #pragma unroll
+#pragma unroll
               for (int p = r + 1; p < B; ++p) v = fma(-N::val(L[p][r]), t[p], v);
               t[r] = v * N::val(invd[r]);
             }
-  #pragma unroll
+#pragma unroll
             for (int r = 0; r < B; ++r) xs[i * B + r] = t[r];
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -689,9 +729,9 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
           // neighbour blocks of the inverse
           T Saa[B][B], Sbb[B][B], Sba[B][B];
           const bool e_is_a = ((a / (2 * h)) & 1) != 0;  // which of a,b was eliminated at level l+1
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {
               Saa[r][c] = Wn(a).get(Lay::W_SD + r * B + c);
               if (hasb) {
@@ -704,12 +744,12 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
               }
             }
           T Ca[B][B], Cb[B][B], Sii[B][B];
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {
               T ta = N::zero(), tb = N::zero();
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) {
                 ta = N::nfma(Ga[r][p], Saa[p][c], ta);       // -(Ga Saa)
                 ta = N::nfma(Gb[r][p], Sba[p][c], ta);       // -(Gb Sba)
@@ -721,19 +761,19 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
             }
           __builtin_amdgcn_sched_barrier(0);
           // D_i^-1 = L^-T L^-1
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) Sii[r][c] = (r == c) ? N::make(1.0, 0.0) : N::zero();
           blk_solve_L<T, B, B>(L, invd, Sii);
           blk_solve_LT<T, B, B>(L, invd, Sii);
           __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < B; ++r)
-  #pragma unroll
+#pragma unroll
             for (int c = 0; c < B; ++c) {
               T t = Sii[r][c];
-  #pragma unroll
+#pragma unroll
               for (int p = 0; p < B; ++p) {
                 t = N::nfma(Ca[r][p], Ga[c][p], t);
                 t = N::nfma(Cb[r][p], Gb[c][p], t);
