@@ -114,6 +114,10 @@ using namespace asvgp;
 
 extern "C" size_t asvgp_phi_cross_workspace_bytes(int64_t m_i, int64_t m_j) {
   if (m_i < 1 || m_j < 1) return 0;
+  // the per-workgroup partial images exist only on the LDS path (launch_cross: 8 (E + n_i + n_j) <= CROSS_LDS_BUDGET with
+  // n = m - order + 1 >= m - ASVGP_MAX_ORDER + 1); larger blocks accumulate with L2 atomics and never touch the workspace
+  const long n_min = (m_i > ASVGP_MAX_ORDER ? m_i - ASVGP_MAX_ORDER + 1 : 2) + (m_j > ASVGP_MAX_ORDER ? m_j - ASVGP_MAX_ORDER + 1 : 2);
+  if (sizeof(double) * ((size_t)m_i * (size_t)m_j + (size_t)n_min) > CROSS_LDS_BUDGET) return 8;
   return (size_t)256 * (size_t)m_i * (size_t)m_j * sizeof(double);
 }
 

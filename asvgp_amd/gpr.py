@@ -11,6 +11,7 @@ import math
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import kernels, utils
 from . import kernels as kernels_mod
@@ -23,6 +24,43 @@ from .inducing_features import SplineFeatures1D
 def _to_device(a, device):
     t = torch.as_tensor(a)
     return f64c(t.to(device))
+
+
+def _require_inside(col, a, b, strict, what):
+    """gpr.py:24-25 asserts a < X < b; raised explicitly so that `python -O` cannot strip it: the fixed-point Phi pass
+    assumes t in [0, 1] and would return finite but wrong statistics for points outside the mesh (or NaN)."""
+    if col.numel() == 0:
+        return
+    lo, hi = torch.aminmax(col)
+    lo, hi = lo.item(), hi.item()
+    ok = (lo > a and hi < b) if strict else (lo >= a and hi <= b)
+    if not ok or lo != lo or hi != hi:
+        raise AssertionError("%s: inputs must lie %s the basis domain (%g, %g); got [%g, %g]"
+                             % (what, "strictly inside" if strict else "inside", a, b, lo, hi))
+
+
+class _ShardedStats:
+    """N-sharded statistics: every (re)run of the local Phi pass is followed by the ONE all-reduce of the
+    packed buffer, so `_stats` (and the views KufKfu / Kuf_y / tr_yTy into it) are always the global sums."""
+    _pg = None
+    _distributed = False
+
+    def _setup_dist(self, process_group, distributed):
+        self._pg = process_group
+        self._distributed = bool(process_group is not None if distributed is None else distributed)
+
+    def _allreduce_stats(self):
+        if self._distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._pg) > 1:
+            dist.all_reduce(self._stats, op=dist.ReduceOp.SUM, group=self._pg)
+
+    def phi_pass(self, allreduce=True, **kw):
+        """(Re)run the fused N-dependent pass over this rank's rows; with allreduce=True (default) a sharded model then
+        sums the packed buffer across ranks, exactly as the constructor does.  allreduce=False leaves the LOCAL statistics
+        in place (bench.py times the collective separately)."""
+        self._phi_pass_local(**kw)
+        if allreduce:
+            self._allreduce_stats()
+        return self._stats
 
 
 class _GPModelSurface:
@@ -44,7 +82,7 @@ class _GPModelSurface:
         return -0.5 * (np.log(2 * np.pi * var) + (Ynew - mean) ** 2 / var)
 
 
-class GPR_1d(_GPModelSurface):
+class GPR_1d(_GPModelSurface, _ShardedStats):
     def __init__(self, data, kernel, basis, process_group=None, distributed=None):
         # Check inputs (gpr.py:22-26)
         assert isinstance(kernel, (kernels.Matern12, kernels.Matern32, kernels.Matern52))
@@ -54,10 +92,7 @@ class GPR_1d(_GPModelSurface):
         if self.y.dim() == 1:
             self.y = self.y.reshape(-1, 1)
         require_cuda(self.X, self.y)
-        if self.X.shape[0] > 0:
-            lo, hi = torch.aminmax(self.X)
-            assert lo.item() > basis.a
-            assert hi.item() < basis.b
+        _require_inside(self.X, basis.a, basis.b, True, "GPR_1d")
         # Init model (gpr.py:29-34)
         self.kernel = kernel
         self.likelihood = kernels.Gaussian()
@@ -73,10 +108,9 @@ class GPR_1d(_GPModelSurface):
         wsb = lib.asvgp_phi_workspace_bytes(M, k, D)
         self._phi_ws = torch.empty(wsb // 8, dtype=torch.float64, device=dev)
         self._wsb = wsb
-        self.phi_pass()
-        if distributed is None:
-            distributed = process_group is not None
-        self.num_data = allreduce_stats(self._stats, self.num_data_local, process_group) if distributed \
+        self._setup_dist(process_group, distributed)
+        self._phi_pass_local()
+        self.num_data = allreduce_stats(self._stats, self.num_data_local, process_group) if self._distributed \
             else self.num_data_local
         self.KufKfu = self._stats[:(k + 1) * M].view(k + 1, M)
         self.Kuf_y = self._stats[(k + 1) * M:(k + 1) * M + M * D].view(M, D)
@@ -87,8 +121,8 @@ class GPR_1d(_GPModelSurface):
         self._post = None
 
     # ------------------------------------------------------------------------------------------------------
-    def phi_pass(self):
-        """(Re)run the fused N-dependent pass: asvgp_phi_accumulate_1d -> packed [band | Phi y | y^T y]."""
+    def _phi_pass_local(self):
+        """asvgp_phi_accumulate_1d over this rank's rows -> packed [band | Phi y | y^T y] (local sums)."""
         b = self.basis
         check(get_lib().asvgp_phi_accumulate_1d(self.X.data_ptr(), self.y.data_ptr(), self.X.shape[0], self.D,
                                                 b.mesh.data_ptr(), b.mesh.shape[0], b.delta_np, b.order, b.m,
@@ -242,7 +276,7 @@ class GPR_1d(_GPModelSurface):
         return mean, var
 
 
-class GPR_kron(_GPModelSurface):
+class GPR_kron(_GPModelSurface, _ShardedStats):
     """Drop-in for asvgp/gpr.py:239-359 (d = 2): GPR_kron((X[N,2], y[N,1]), kernels, bases) with elbo(),
     maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew).  Never densifies: KufKfu is a block band
     (asvgp_phi_accumulate_kron2d), Kuu = K1 (x) K2 is handled factor-wise (log|Kuu| = m2 log|K1| + m1 log|K2|, the trace
@@ -261,9 +295,7 @@ class GPR_kron(_GPModelSurface):
             assert isinstance(kern, (kernels_mod.Matern12, kernels_mod.Matern32, kernels_mod.Matern52))
         assert bases[0].order == bases[1].order
         for i, bs in enumerate(bases):
-            if self.n:
-                lo, hi = torch.aminmax(self.X[:, i])
-                assert lo.item() >= bs.a and hi.item() <= bs.b
+            _require_inside(self.X[:, i], bs.a, bs.b, False, "GPR_kron dimension %d" % i)
         self.kernels, self.bases = kernels, bases
         self.kernel = kernels[-1]                            # gpr.py:254 passes the leaked loop variable
         self.likelihood = kernels_mod.Gaussian()
@@ -276,10 +308,9 @@ class GPR_kron(_GPModelSurface):
         self.Mtot = m1 * m2
         self.noff = k * (2 * k + 1) + k + 1
         self._stats = torch.empty(lib.asvgp_kron_stats_doubles(m1, m2, k), dtype=torch.float64, device=dev)
-        self.phi_pass()
-        if distributed is None:
-            distributed = process_group is not None
-        self.num_data = allreduce_stats(self._stats, self.n, process_group) if distributed else self.n
+        self._setup_dist(process_group, distributed)
+        self._phi_pass_local()
+        self.num_data = allreduce_stats(self._stats, self.n, process_group) if self._distributed else self.n
         self.KufKfu_blockband = self._stats[:self.noff * self.Mtot].view(self.noff, self.Mtot)
         self.Kuf_y = self._stats[self.noff * self.Mtot:self.noff * self.Mtot + self.Mtot].view(self.Mtot, 1)
         self.tr_yTy = self._stats[-1]
@@ -302,8 +333,8 @@ class GPR_kron(_GPModelSurface):
         start[1:] = torch.cumsum(counts, 0)
         return self.X[order].contiguous(), self.y[order].contiguous(), start
 
-    def phi_pass(self, sorted_cells=True):
-        """The N-dependent pass -> [block band | Kuf y | y^T y].  Default: cell-sorted accumulation (one atomic per band entry and
+    def _phi_pass_local(self, sorted_cells=True):
+        """The N-dependent pass over this rank's rows -> [block band | Kuf y | y^T y].  Default: cell-sorted accumulation (one atomic per band entry and
         cell); sorted_cells=False: the per-point atomic kernel (asvgp_phi_accumulate_kron2d), same statistics."""
         b1, b2 = self.bases
         lib = get_lib()
@@ -531,7 +562,7 @@ class GPR_kron(_GPModelSurface):
         return mean.reshape(-1, 1), var.reshape(-1, 1)
 
 
-class GPR_additive(_GPModelSurface):
+class GPR_additive(_GPModelSurface, _ShardedStats):
     """Drop-in for asvgp/gpr.py:139-236: GPR_additive((X[N,d], y[N,1]), kernels, bases) with elbo(),
     maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew), fit().
 
@@ -558,9 +589,7 @@ class GPR_additive(_GPModelSurface):
         assert all(x == bandwidths[0] for x in bandwidths)
         self.bandwidth = k = bases[0].order
         for i, bs in enumerate(bases):
-            if self.n:
-                lo, hi = torch.aminmax(self.X[:, i])
-                assert lo.item() > bs.a and hi.item() < bs.b
+            _require_inside(self.X[:, i], bs.a, bs.b, True, "GPR_additive dimension %d" % i)
         lib = get_lib()
         ms = [bs.m for bs in bases]
         self.offsets = [0]
@@ -582,16 +611,15 @@ class GPR_additive(_GPModelSurface):
                   [lib.asvgp_phi_cross_workspace_bytes(ms[i], ms[j]) for (i, j) in self._cross_off] + [8])
         self._ws = torch.empty(wsb // 8 + 1, dtype=torch.float64, device=dev)
         self._wsb = wsb
-        self.phi_pass()
-        if distributed is None:
-            distributed = process_group is not None
-        self.num_data = allreduce_stats(self._stats, self.n, process_group) if distributed else self.n
+        self._setup_dist(process_group, distributed)
+        self._phi_pass_local()
+        self.num_data = allreduce_stats(self._stats, self.n, process_group) if self._distributed else self.n
         self.tr_yTy = self._stats[self._diag_off[0] + (k + 2) * ms[0]]      # gpr.py:168
         self._info = torch.zeros(1, dtype=torch.int32, device=dev)
         self._dense = None
 
     # ------------------------------------------------------------------------------------------------------
-    def phi_pass(self):
+    def _phi_pass_local(self):
         lib, k = get_lib(), self.bandwidth
         for i, bs in enumerate(self.bases):
             out = self._stats[self._diag_off[i]:]

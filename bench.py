@@ -7,7 +7,9 @@ one all-reduce(sum) of the packed band buffer (RCCL, only when N>1) -> banded EL
 BASELINE workload is N = 10M points in total, sharded contiguously over the ranks.
 
 Prints ONE JSON line on rank 0.  python bench.py [--gpus N --steps K --warmup W]
-(N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+With --gpus N > 1 and no torchrun environment (RANK unset) the script launches itself: the parent - before any GPU
+call - starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` on this
+file and exits with its return code; under torchrun (RANK set) it is the worker.
 """
 import argparse
 import ctypes
@@ -48,20 +50,51 @@ def measured_traffic(n_local):
     return None
 
 
-def cpu_baseline(sample_n, M, theta):
+def cpu_baseline(x, y, M, theta, kind, gpu_stats=None, gpu_out=None):
     """The reference's CPU steps restated in numpy/scipy (oracle/, kind 'port'): piece polynomials -> csr_matrix ->
-    Phi@y, Phi@Phi.T -> band (gpr.py:39-44) + one banded ELBO+gradient, on a bounded sample, single core."""
+    Phi@y, Phi@Phi.T -> band (gpr.py:39-44) + one banded ELBO+gradient, single core, on (a prefix of) the SAME points the
+    GPU processed.  When the sample is the whole workload the oracle's numbers double as the parity check of this very
+    run: `parity` = statistics / ELBO / gradient of the timed GPU path against the oracle (fp64, reference elimination
+    order) and against the oracle's long-double evaluation of the same recurrences."""
     from oracle import asvgp_oracle as O
-    x, y = synth(sample_n, seed=4321)
+    n = x.shape[0]
     bs = O.Basis(4, 0, 1, M)
     t0 = time.perf_counter()
     A, b, yy = O.sufficient_stats(bs, x.reshape(-1, 1), y.reshape(-1, 1))
     t1 = time.perf_counter()
-    O.elbo_grad_1d(bs, O.MATERN32, A, b, yy, sample_n, *theta)
+    oe, og, _ = O.elbo_grad_1d(bs, kind, A, b, yy, n, *theta)
     t2 = time.perf_counter()
-    return dict(value=sample_n / (t2 - t0) / 1e6, unit="Mpoints/s", cores=1, kind="port",
-                sample="N=%d of the same synthetic workload, M=%d: scipy CSR build + SpGEMM %.2fs, python banded ELBO+grad %.2fs"
-                       % (sample_n, M, t1 - t0, t2 - t1))
+    base = dict(value=n / (t2 - t0) / 1e6, unit="Mpoints/s", cores=1, kind="port",
+                sample="N=%d of the same synthetic workload (same seed, same points), M=%d: scipy CSR build + SpGEMM %.2fs, "
+                       "python banded ELBO+grad %.2fs" % (n, M, t1 - t0, t2 - t1))
+    parity = None
+    if gpu_stats is not None:
+        ref = np.concatenate([A.reshape(-1), b.reshape(-1), [yy]])
+        ee, ge = O.elbo_grad_1d_extended(bs, kind, A, b, yy, n, *theta)
+        g = np.asarray(gpu_out[1:4])
+        parity = {"stats_max_abs_over_max": float(np.max(np.abs(gpu_stats - ref)) / np.max(np.abs(ref))),
+                  "elbo_gpu": float(gpu_out[0]), "elbo_oracle_f64": oe, "elbo_oracle_long_double": ee,
+                  "abs_elbo_vs_oracle": abs(float(gpu_out[0]) - oe), "abs_elbo_vs_long_double": abs(float(gpu_out[0]) - ee),
+                  "abs_oracle_vs_long_double": abs(oe - ee),
+                  "grad_max_rel_vs_oracle": float(np.max(np.abs((g - og) / og))),
+                  "grad_max_rel_vs_long_double": float(np.max(np.abs((g - ge) / ge))),
+                  "gates": "stats 1e-12 of the largest entry; |dELBO| <= 1e-9|ELBO| + 5 x |oracle - long double|; gradient rel 1e-6"}
+    return base, parity
+
+
+def self_launch(argv, n):
+    """Parent of an N-GPU run: no GPU call has happened in this process; the workers are torchrun children."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -73,12 +106,15 @@ def main():
     ap.add_argument("--features", type=int, default=2048)
     ap.add_argument("--sorted", action="store_true", help="secondary case: time-series (sorted) inputs")
     ap.add_argument("--matern", type=int, default=32, choices=(12, 32, 52), help="kernel of the workload (BASELINE config 3 uses 52)")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="points of the workload the CPU oracle is timed on (a prefix; "
+                    "parity is reported when it covers the whole workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
     ap.add_argument("--kernel-events", type=int, default=10, help="HIP events around every n-th Phi kernel launch")
     ap.add_argument("--phase-events", type=int, default=25, help="record per-phase events on every n-th step (0 = never)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -86,6 +122,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if os.environ.get("ASVGP_BENCH_DRY"):
+        # launcher rehearsal on a box without a GPU (tests/test_cabi_and_host.py): rendezvous, one all-reduce, one line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "ranks_seen": int(t.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -240,7 +290,13 @@ def main():
         if weak is not None:
             line["weak_scaling_extra"] = weak
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, M, theta)
+            ns = min(args.cpu_sample, N)
+            full = (ns == N)
+            okind = {12: 0, 32: 1, 52: 2}[args.matern]
+            line["cpu_baseline"], parity = cpu_baseline(x[:ns], y[:ns], M, theta, okind,
+                                                        stats.cpu().numpy() if full else None, out4 if full else None)
+            if parity is not None:
+                line["parity"] = parity
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

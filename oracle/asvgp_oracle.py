@@ -505,6 +505,108 @@ def elbo_grad_1d(basis, kind, A, b, yy, N, v, l, s):
     return float(elbo), np.array([d_v, d_l, d_s]), dict(alpha=alpha, SK=SK, SP=SP, LK=LK, LP=LP, c=c)
 
 
+def elbo_grad_1d_extended(basis, kind, A, b, yy, N, v, l, s):
+    """The same bound and gradient as elbo_grad_1d (gpr.py:49-89) with every banded recurrence
+    carried in numpy long double (x86: 80-bit, 64-bit mantissa) from the fp64 inputs Kuu, dKuu/dl, A, b.  This is the
+    'truth' the fp64 evaluation orders are measured against when cond(Kuu) eats digits (tests at the BASELINE
+    size): it shows how much of a difference is rounding of the reference's own fp64 order.  D = 1 only."""
+    ld = np.longdouble
+    Kuu, dKl = make_Kuu(basis, kind, v, l, want_dl=True)
+    k, M = Kuu.shape[0] - 1, Kuu.shape[1]
+    assert b.shape[1] == 1
+
+    def chol(Kb, dKb=None):
+        L = np.zeros((k + 1, M), ld)
+        dL = np.zeros((k + 1, M), ld) if dKb is not None else None
+        for j in range(M):
+            for i in range(j, min(j + k, M - 1) + 1):
+                lo = max(0, i - k)
+                p = np.arange(lo, j)
+                sacc = ld(Kb[i - j, j]) - np.sum(L[i - p, p] * L[j - p, p])
+                if dKb is not None:
+                    dacc = ld(dKb[i - j, j]) - np.sum(dL[i - p, p] * L[j - p, p] + L[i - p, p] * dL[j - p, p])
+                if i == j:
+                    L[0, j] = np.sqrt(sacc)
+                    if dKb is not None:
+                        dL[0, j] = dacc / (2 * L[0, j])
+                else:
+                    L[i - j, j] = sacc / L[0, j]
+                    if dKb is not None:
+                        dL[i - j, j] = (dacc - L[i - j, j] * dL[0, j]) / L[0, j]
+        return L, dL
+
+    def takahashi(L, dL=None):
+        S = np.zeros((k + 1, M), ld)
+        dS = np.zeros((k + 1, M), ld) if dL is not None else None
+
+        def sget(X, p, i):
+            return X[p - i, i] if p >= i else X[i - p, p]
+        for j in range(M - 1, -1, -1):
+            hi = min(j + k, M - 1)
+            ljj = L[0, j]
+            for i in range(hi, j - 1, -1):
+                acc = (ld(1) / ljj) if i == j else ld(0)
+                dacc = (-dL[0, j] / (ljj * ljj)) if (dL is not None and i == j) else ld(0)
+                for p in range(j + 1, hi + 1):
+                    acc -= L[p - j, j] * sget(S, p, i)
+                    if dL is not None:
+                        dacc -= dL[p - j, j] * sget(S, p, i) + L[p - j, j] * sget(dS, p, i)
+                S[i - j, j] = acc / ljj
+                if dL is not None:
+                    dS[i - j, j] = (dacc - S[i - j, j] * dL[0, j]) / ljj
+        return S, dS
+
+    def trsv(L, x, trans):
+        x = x.astype(ld).copy()
+        if not trans:
+            for i in range(M):
+                p = np.arange(max(0, i - k), i)
+                x[i] = (x[i] - np.sum(L[i - p, p] * x[p])) / L[0, i]
+        else:
+            for i in range(M - 1, -1, -1):
+                p = np.arange(i + 1, min(i + k, M - 1) + 1)
+                x[i] = (x[i] - np.sum(L[p - i, i] * x[p])) / L[0, i]
+        return x
+
+    def symdot(S, B):
+        B = B.astype(ld)
+        return np.sum(S[0] * B[0]) + 2 * np.sum(S[1:] * B[1:])
+
+    def symmv(B, x):
+        B = B.astype(ld)
+        out = B[0] * x
+        for d in range(1, k + 1):
+            out[d:] += B[d, :M - d] * x[:M - d]
+            out[:M - d] += B[d, :M - d] * x[d:]
+        return out
+
+    Al, bl = A.astype(ld), b.reshape(-1).astype(ld)
+    v_, l_, s_, N_, yy_ = ld(v), ld(l), ld(s), ld(N), ld(yy)
+    LK, dLK = chol(Kuu, dKl)
+    SK, dSK = takahashi(LK, dLK)
+    P = Al / s_ + Kuu.astype(ld)
+    LP, _ = chol(P)
+    SP, _ = takahashi(LP)
+    c = trsv(LP, bl, False) / s_
+    alpha = trsv(LP, c, True)
+    logdet_K = 2 * np.sum(np.log(LK[0]))
+    logdet_P = 2 * np.sum(np.log(LP[0]))
+    trKA = symdot(SK, A)
+    two_pi = 2 * np.arctan(ld(1)) * 4
+    elbo = (-N_ / 2 * np.log(two_pi * s_) - logdet_P / 2 + logdet_K / 2 - yy_ / (2 * s_) + np.sum(c * c) / 2
+            - N_ * v_ / (2 * s_) + trKA / (2 * s_))
+
+    def G_dot(Kdot, dtr):
+        aKa = np.sum(alpha * symmv(Kdot, alpha))
+        return (symdot(SK, Kdot) - symdot(SP, Kdot) - aKa + dtr / s_) / 2
+    d_l = G_dot(dKl, symdot(dSK, A))
+    d_v = G_dot(-Kuu / v, trKA / v_) - N_ / (2 * s_)
+    aAa = np.sum(alpha * symmv(A, alpha))
+    d_s = (-N_ / (2 * s_) + symdot(SP, A) / (2 * s_ ** 2) + yy_ / (2 * s_ ** 2) + aAa / (2 * s_ ** 2)
+           - np.sum(bl * alpha) / s_ ** 2 + N_ * v_ / (2 * s_ ** 2) - trKA / (2 * s_ ** 2))
+    return float(elbo), np.array([float(d_v), float(d_l), float(d_s)])
+
+
 def predict_f_1d(basis, kind, A, b, v, l, s, Xnew):
     """gpr.py:94-120 (full_cov=False): mean = Phi*^T P^-1 b / s ; var = v + |L_P^-1 Phi*|^2 - Phi*^T Kuu^-1 Phi*.
     Dense textbook evaluation (the reference uses CHOLMOD with natural ordering == band Cholesky)."""

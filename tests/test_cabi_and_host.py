@@ -170,3 +170,19 @@ def test_two_rank_gloo_band_allreduce_matches_single_rank():
     e2, _ = O.elbo_1d(O.make_Kuu(O.Basis(4, 0, 1, M), 1, 1.0, 0.1), p[:5 * M].reshape(5, M), p[5 * M:6 * M].reshape(M, 1),
                       p[-1], N, 1.0, 0.05)
     assert abs(e1 - e2) <= 1e-10 * abs(e1)
+
+
+def test_bench_self_launch_dry_two_ranks():
+    """bench.py --gpus 2 without a torchrun environment spawns its own workers before any GPU call (VERDICT r1 item 2);
+    ASVGP_BENCH_DRY=1 stops after the rendezvous + one all-reduce so that the launcher can be rehearsed without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ASVGP_BENCH_DRY"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry": True, "n_gpus": 2, "ranks_seen": 2}

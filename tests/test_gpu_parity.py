@@ -577,6 +577,12 @@ def _shard_worker(rank, world, port, q):
                      process_group=dist.group.WORLD)
     model.likelihood.variance.assign(0.01)
     r = model.elbo_and_grad().cpu().numpy()
+    # re-running the Phi pass on a sharded model all-reduces again (it used to leave the local shard behind)
+    model.phi_pass()
+    r_again = model.elbo_and_grad().cpu().numpy()
+    assert np.allclose(r_again, r, rtol=1e-9, atol=0), (r_again, r)
+    local = model.phi_pass(allreduce=False).clone()
+    assert float(local[-1]) < 0.75 * float(model.phi_pass()[-1])      # y^T y of one shard vs the global sum
     # the 2-D models shard the same way (block band / flat additive buffer through the same all-reduce)
     rng2 = np.random.default_rng(77)
     N2 = 6001
@@ -1054,3 +1060,58 @@ def test_predict_paths_odd_counts_unaligned_and_staged(A, S):
                 om2, ov2 = O.predict_f_1d_banded(ob, 1, Ab, b, 0.8, 1.0, 0.08, xs[1:][sub].reshape(-1, 1))
                 np.testing.assert_allclose(mean.cpu().numpy()[sub], om2, rtol=0, atol=1e-8)
                 np.testing.assert_allclose(var.cpu().numpy()[sub], ov2, rtol=0, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE headline size
+def test_headline_config_parity_n10m(A):
+    """BASELINE.json north star, exactly as bench.py runs it: N = 10M, M = 2048, B4, Matern-3/2, theta = (1, 0.05, 0.01),
+    default_rng(1234).  Statistics <= 1e-12 of the largest entry against the oracle's direct accumulation; ELBO and gradient
+    against the oracle (fp64, reference elimination order) AND the oracle's long-double evaluation of the same recurrences.
+    Gate for the bound: 1e-9 |ELBO| + 5 x |oracle - long double| - cond(Kuu) = 3.5e7 costs the reference's own
+    fp64 order 0.018 here, and a path that is more than 5x further from the truth than that does not "match"."""
+    import bench
+    N, M = 10_000_000, 2048
+    v, l, s = 1.0, 0.05, 0.01
+    x, y = bench.synth(N)
+    xd, yd = dev(x).reshape(-1, 1), dev(y).reshape(-1, 1)
+    model = A.GPR_1d((xd, yd), A.Matern32(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(s)
+    got = model._stats.cpu().numpy()
+    r = model.elbo_and_grad().cpu().numpy()
+    ob = O.Basis(4, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+    ref = np.concatenate([Ab.reshape(-1), b.reshape(-1), [yy]])
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    oe, og, _ = O.elbo_grad_1d(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
+    ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
+    assert abs(oe - ee) <= 0.05                     # the reference order itself: 0.018 (6e-9 relative)
+    gate = 1e-9 * abs(ee) + 5 * abs(oe - ee)
+    assert abs(r[0] - ee) <= gate, ("ELBO vs long double", r[0], ee, oe, gate)
+    assert abs(r[0] - oe) <= gate + abs(oe - ee), ("ELBO vs oracle", r[0], oe)
+    np.testing.assert_allclose(r[1:4], ge, rtol=1e-6)
+    np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
+    # sorted (time-series) order of the same points: same statistics (run mode of the Phi pass), same bound
+    o = np.argsort(x)
+    ms = A.GPR_1d((dev(x[o]).reshape(-1, 1), dev(y[o]).reshape(-1, 1)), A.Matern32(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
+    ms.likelihood.variance.assign(s)
+    assert np.max(np.abs(ms._stats.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert abs(ms.elbo_and_grad().cpu().numpy()[0] - ee) <= gate
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no torchrun environment must launch its own workers (the driver's SCALE command);
+    rehearsed with gloo and both ranks on the one GPU of the test box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ASVGP_BENCH_BACKEND"] = "gloo"
+    env["ASVGP_BENCH_NOWEAK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--points", "400000", "--features", "512"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "roofline" in d
