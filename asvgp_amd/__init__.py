@@ -10,13 +10,21 @@ from .kernels import Gaussian, Matern12, Matern32, Matern52  # noqa: F401
 
 
 def set_band_algorithm(algo):
-    """0 = auto, 1 = sequential single-wave sweeps, 2 = block cyclic reduction (asvgp_set_band_algorithm)."""
-    from ._lib import check, get_lib
-    check(get_lib().asvgp_set_band_algorithm(int(algo)), "set_band_algorithm")
+    """0 = auto, 1 = sequential single-wave sweeps, 2 = block cyclic reduction on the GPU, 3 = block cyclic reduction with the
+    planned (host, long double) prior forward pass (asvgp_set_band_algorithm) - applied to every live model handle and to
+    models created later."""
+    from ._lib import AsvgpError, get_lib, set_default_algorithms
+    get_lib()
+    if int(algo) not in (0, 1, 2, 3):
+        raise AsvgpError("set_band_algorithm: 0..3")
+    set_default_algorithms(band=int(algo))
 
 
 def set_phi_algorithm(algo):
-    """0 = auto, 1 = fp64 LDS atomic scatter, 2 = counting sort + per-cell moments, 3 = fixed-point band scatter,
-    4 = per-cell buckets + moments (asvgp_set_phi_algorithm)."""
-    from ._lib import check, get_lib
-    check(get_lib().asvgp_set_phi_algorithm(int(algo)), "set_phi_algorithm")
+    """0 = auto, 1 = fp64 LDS atomic band scatter, 3 = fixed-point band scatter, 5 = fixed-point centred-moment scatter
+    (asvgp_set_phi_algorithm) - applied to every live model handle and to models created later."""
+    from ._lib import AsvgpError, get_lib, set_default_algorithms
+    get_lib()
+    if int(algo) not in (0, 1, 3, 5):
+        raise AsvgpError("set_phi_algorithm: 0, 1, 3 or 5")
+    set_default_algorithms(phi=int(algo))

@@ -16,9 +16,11 @@ SIGNATURES = {
     "asvgp_last_error_string": (_c.c_char_p, []),
     "asvgp_status_name": (_c.c_char_p, [_I]),
     "asvgp_phi_workspace_bytes": (_Z, [_L, _I, _L]),
-    "asvgp_phi_accumulate_1d": (_I, [_P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
-    "asvgp_set_phi_algorithm": (_I, [_I]),
-    "asvgp_set_phi_workgroups": (_I, [_I]),
+    "asvgp_create": (_I, [_c.POINTER(_P)]),
+    "asvgp_destroy": (_I, [_P]),
+    "asvgp_phi_accumulate_1d": (_I, [_P, _P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
+    "asvgp_set_phi_algorithm": (_I, [_P, _I]),
+    "asvgp_set_phi_workgroups": (_I, [_P, _I]),
     "asvgp_phi_index_1d": (_I, [_P, _L, _P, _L, _D, _P, _P]),
     "asvgp_phi_evaluate_1d": (_I, [_P, _L, _P, _L, _D, _I, _I, _P, _P, _P]),
     "asvgp_matern_coeffs": (_I, [_I, _D, _D, _c.POINTER(_D), _c.POINTER(_D), _c.POINTER(_I)]),
@@ -33,15 +35,18 @@ SIGNATURES = {
     "asvgp_pack_dense_matrix_to_banded": (_I, [_P, _P, _L, _I, _I, _P]),
     "asvgp_band_trace_sym": (_I, [_P, _P, _L, _I, _P, _P]),
     "asvgp_elbo_workspace_bytes": (_Z, [_L, _I, _L]),
-    "asvgp_set_band_algorithm": (_I, [_I]),
-    "asvgp_elbo_grad_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
-    "asvgp_elbo_chain_sync": (_I, [_I]),
-    "asvgp_elbo_prior_chain_1d": (_I, [_P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _Z, _P]),
-    "asvgp_elbo_data_chain_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
-    "asvgp_posterior_prepare_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),
+    "asvgp_set_band_algorithm": (_I, [_P, _I]),
+    "asvgp_prior_plan_1d": (_I, [_P, _P, _I, _L, _I, _c.POINTER(_I)]),
+    "asvgp_prior_table_doubles": (_Z, [_P, _I, _L, _I]),
+    "asvgp_prior_forward_host": (_I, [_P, _I, _L, _I, _P, _P, _P, _Z, _P]),
+    "asvgp_elbo_grad_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_elbo_chain_sync": (_I, [_P, _I]),
+    "asvgp_elbo_prior_chain_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _Z, _P]),
+    "asvgp_elbo_data_chain_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_posterior_prepare_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "asvgp_predict_1d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),
-    "asvgp_profile_enable": (_I, [_I]),
-    "asvgp_profile_read": (_I, [_c.POINTER(_D), _c.POINTER(_L)]),
+    "asvgp_profile_enable": (_I, [_P, _I]),
+    "asvgp_profile_read": (_I, [_P, _c.POINTER(_D), _c.POINTER(_L)]),
     "asvgp_kron_stats_doubles": (_Z, [_L, _L, _I]),
     "asvgp_phi_accumulate_kron2d": (_I, [_P, _P, _L, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P]),
     "asvgp_kron_evaluate_2d": (_I, [_P, _L, _P, _L, _D, _P, _L, _D, _L, _I, _P, _P, _P]),
@@ -90,6 +95,73 @@ def check(status, what=""):
         lib = get_lib()
         raise AsvgpError("%s failed: %s (%s)" % (what or "asvgp call", lib.asvgp_status_name(status).decode(),
                                                   lib.asvgp_last_error_string().decode()))
+
+
+class Handle:
+    """asvgp_create / asvgp_destroy: the library state of ONE model (algorithm choices, Phi workgroup count, chain events,
+    timing ring, prior-chain plan).  Models own one each, so two models may step on two streams / host threads."""
+    _defaults = {"band": 0, "phi": 0}
+    _live = None
+
+    def __init__(self):
+        import weakref
+        lib = get_lib()
+        h = _P()
+        check(lib.asvgp_create(ctypes.byref(h)), "asvgp_create")
+        self.ptr = h
+        self._lib = lib
+        if Handle._live is None:
+            Handle._live = weakref.WeakSet()
+        Handle._live.add(self)
+        if Handle._defaults["band"]:
+            self.set_band_algorithm(Handle._defaults["band"])
+        if Handle._defaults["phi"]:
+            self.set_phi_algorithm(Handle._defaults["phi"])
+
+    def set_band_algorithm(self, algo):
+        check(self._lib.asvgp_set_band_algorithm(self.ptr, int(algo)), "set_band_algorithm")
+
+    def set_phi_algorithm(self, algo):
+        check(self._lib.asvgp_set_phi_algorithm(self.ptr, int(algo)), "set_phi_algorithm")
+
+    def set_phi_workgroups(self, n):
+        check(self._lib.asvgp_set_phi_workgroups(self.ptr, int(n)), "set_phi_workgroups")
+
+    def chain_sync(self, on):
+        check(self._lib.asvgp_elbo_chain_sync(self.ptr, int(on)), "elbo_chain_sync")
+
+    def prior_plan(self, static_stack_host, n_terms, M, k):
+        """asvgp_prior_plan_1d from a host (numpy, C-contiguous fp64) copy of the static-band stack; returns True when planned."""
+        ok = _I(0)
+        ptr = None if static_stack_host is None else static_stack_host.ctypes.data
+        check(self._lib.asvgp_prior_plan_1d(self.ptr, ptr, int(n_terms), int(M), int(k), ctypes.byref(ok)), "prior_plan_1d")
+        return bool(ok.value)
+
+    def close(self):
+        if getattr(self, "ptr", None) is not None and self.ptr:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                self._lib.asvgp_destroy(self.ptr)
+            except Exception:
+                pass
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+def set_default_algorithms(band=None, phi=None):
+    """Algorithm choice for every live handle and for handles created later (asvgp_amd.set_band_algorithm / set_phi_algorithm)."""
+    if band is not None:
+        Handle._defaults["band"] = int(band)
+    if phi is not None:
+        Handle._defaults["phi"] = int(phi)
+    for h in list(Handle._live or ()):
+        if band is not None:
+            h.set_band_algorithm(band)
+        if phi is not None:
+            h.set_phi_algorithm(phi)
 
 
 def stream_ptr():

@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libasvgp_hip.so")
-SOURCES = ["phi_pass.hip", "band_ops.hip", "elbo.hip", "kron.hip", "additive.hip"]
+SOURCES = ["phi_pass.hip", "band_ops.hip", "elbo.hip", "kron.hip", "additive.hip", "handle.hip"]
+HOST_SOURCES = ["prior_plan.cpp"]   # plain C++ (host planner of the prior chain): no FMA contraction, see prior_plan.cpp
 ELBO_KS = (1, 2, 3, 4, 5, 6)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics"]
 
@@ -34,6 +35,9 @@ def _units():
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         units.append((os.path.join(OBJ, s.replace(".hip", ".o")), src, [], hdrs + [src]))
+    for s in HOST_SOURCES:
+        src = os.path.join(CSRC, s)
+        units.append((os.path.join(OBJ, s.replace(".cpp", ".o")), src, ["-ffp-contract=off", "-x", "c++"], hdrs + [src]))
     src = os.path.join(CSRC, "elbo.hip")
     for k in ELBO_KS:   # longest first; part 1 = ELBO + gradient (tangent chains), part 2 = posterior
         for part in (2, 1):
@@ -52,7 +56,8 @@ def build(force=False, verbose=True, jobs=None):
 
     def compile_one(u):
         obj, src, extra, _ = u
-        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
+        flags = [f for f in FLAGS if not (src.endswith(".cpp") and f.startswith(("--offload-arch", "-munsafe")))]
+        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)

@@ -11,25 +11,19 @@
 //   phase 3  finalize : log-dets (gpr.py:57,74), band traces (gpr.py:60-70), 7-term bound (gpr.py:78-87), gradient
 #include <stdlib.h>
 
-#include "bcr16.hpp"
+#include "bcr_pre.hpp"
+#include "handle.hpp"
 
 namespace asvgp {
 
-// optional fine-grained ordering between the prior chain (stream A) and the data chain (stream B), owned by the library:
-// evK = Kuu assembled (the P chain may start), evP = prior chain complete (the finalize may start).
 // (elbo.hip is compiled once per bandwidth with -DASVGP_ELBO_ONLY_K=k - those units hold the template instantiations -
-// and once without: the C entry points and the process-wide state.  asvgp_amd/build.py runs the units in parallel.)
-#ifdef ASVGP_ELBO_ONLY_K
-extern bool g_sync_on;
-extern hipEvent_t g_evK, g_evP;
-extern int g_band_algo;
-#else
-bool g_sync_on = false;
-hipEvent_t g_evK = nullptr, g_evP = nullptr;
-int g_band_algo = 0;
-#endif
-                             // 0 auto (= 2 when it fits the LDS), 1 sequential sweeps, 2 hybrid BCR (one thread per node on
-                             // wide levels, lane-distributed on narrow levels), 3 fully lane-distributed BCR
+// and once without: the C entry points.  asvgp_amd/build.py runs the units in parallel.)
+// Band algorithm (Handle::band_algo): 0 auto, 1 sequential single-wave sweeps (the reference's elimination order),
+// 2 block cyclic reduction, both chains on the GPU, 3 block cyclic reduction with the PLANNED prior chain: forward pass of
+// the Kuu chain on the host in long double over the distinct nodes (prior_plan.cpp), backward pass on the GPU (bcr_pre.hpp).
+// Auto = 3 when the handle holds a plan (asvgp_prior_plan_1d) for this (M, k, kind), else 2, else 1 (D > 1 or LDS).
+// With asvgp_elbo_chain_sync the prior chain (stream A) and the data chain (stream B) of algorithm 2 are ordered by the
+// handle's own events: evK = Kuu assembled (the P chain may start), evP = prior chain complete (the finalize may start).
 
 struct Ws {
   double *Kuu, *dK, *P, *LK, *dLK, *LP, *SK, *dSK, *SP, *c, *alpha, *logdets, *fin, *bcrK, *bcrP;
@@ -41,12 +35,13 @@ static size_t bcr_ws_chain(int planes, int k, bool big) {
   if (big) ns *= 2;
   return (size_t)planes * (7 * k * k + k) * 2 * ns + (big ? (size_t)planes * k * k * ns : 0);
 }
-static size_t bcr_ws_K(int k) { size_t a = bcr_ws_chain(2, k, false), b = bcr_ws_chain(2, k, true); return (a > b ? a : b) + 64; }
-static size_t bcr_ws_P(int k) { size_t a = bcr_ws_chain(1, k, false), b = bcr_ws_chain(1, k, true); return (a > b ? a : b) + 64; }
-static size_t bcr_ws_total(long M, int k) {
-  (void)M;
-  return bcr_ws_K(k) + bcr_ws_P(k);
+static size_t bcr_ws_K(int k, long M) {   // the all-GPU Dual chain's factor records, or the planned chain's Sigma records (bcr_pre.hpp)
+  size_t a = bcr_ws_chain(2, k, false), b = bcr_ws_chain(2, k, true), c = bcr_pre_ws_doubles(k, (M + k - 1) / k);
+  a = a > b ? a : b;
+  return (a > c ? a : c) + 64;
 }
+static size_t bcr_ws_P(int k) { size_t a = bcr_ws_chain(1, k, false), b = bcr_ws_chain(1, k, true); return (a > b ? a : b) + 64; }
+static size_t bcr_ws_total(long M, int k) { return bcr_ws_K(k, M) + bcr_ws_P(k); }
 static size_t ws_doubles(long M, int k, long D) {
   return (size_t)9 * (k + 1) * M + (size_t)2 * M * D + 64 + 32 + bcr_ws_total(M, k);
 }
@@ -59,18 +54,18 @@ static Ws carve(void* ws, long M, int k, long D) {
   w.c = p; p += (size_t)M * D; w.alpha = p; p += (size_t)M * D;
   w.logdets = p; p += 64;
   w.fin = p; p += 32;   // 14 partial-sum slots + the arrival ticket of elbo_finalize_kernel (zero between calls)
-  w.bcrK = p; p += bcr_ws_K(k);
+  w.bcrK = p; p += bcr_ws_K(k, M);
   w.bcrP = p;
   return w;
 }
 
 // launchers: declared for every unit, defined (and explicitly instantiated) only in the per-bandwidth units
 template <int K> struct ElboLauncher {
-  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
+  static int run(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
                  double* out, int* info, void* ws, hipStream_t st, int part);
 };
 template <int K> struct PostLauncher {
-  static int run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+  static int run(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
                  double* alpha, double* W, int* info, void* ws, hipStream_t st);
 };
 
@@ -172,21 +167,19 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_data_kernel(const double
                                          st ? st + 24 : nullptr);
 }
 
-// the same with the lane-distributed solver (bcr16.hpp), 1024 threads per chain
-template <int K, bool TANGENT>
-__global__ __launch_bounds__(BCR16_THREADS) void elbo_bcr16_kernel(const double* Kuu, const double* dK, const double* P,
-                                                                   const double* b, int M, double* wsK, double* wsP,
-                                                                   double* SK, double* dSK, double* SP, double* x,
-                                                                   double* logdets, int* info, int do_stamps,
-                                                                   int first_chain) {
+// Planned prior chain (band algorithm 3): block 0 = the P chain (as elbo_bcr_data_kernel), block 1 = the backward pass of the
+// Kuu chain from the host's factor table.  ONE launch for both chains: neither reads the other's output.
+template <int K, bool BIG>
+__global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* Kuu, const double* A, const double* b, int M,
+                                                                  double* wsP, double* SP, double* x, double* logdets, int* info,
+                                                                  double s, const double* tab, int n_rec, const int* node_rec,
+                                                                  double* wsK, double* SK, double* dSK,
+                                                                  unsigned long long* done_flag, unsigned long long seq) {
   extern __shared__ double lds[];
-  double* st = do_stamps ? logdets + 8 : nullptr;
-  if (blockIdx.x + first_chain == 0) {
-    if (TANGENT) bcr16_solve<Dual, K, 0>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
-    else bcr16_solve<double, K, 0>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
-  } else {
-    bcr16_solve<double, K, 1>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
-  }
+  if (blockIdx.x == 0)
+    bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, nullptr);
+  else
+    bcr_backward_pre<K>(tab, n_rec, node_rec, M, wsK, lds, BandOut<Dual>{SK, dSK}, logdets, info, done_flag, seq);
 }
 
 // sym-band quadratic form helper: x^T sym(S) x over columns handled by this thread
@@ -328,7 +321,7 @@ static __global__ void scale_kernel(double* __restrict__ x, double f, long n) {
 }
 
 template <int K, bool TANGENT>
-static int run_chains(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+static int run_chains(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
                       Ws w, int* info, hipStream_t st, bool& use_bcr, int part = 0, bool scale_alpha = true) {
   KuuCoefs2 cf;
   for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
@@ -338,41 +331,67 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
   const double* A = stats;
   const double* b = stats ? stats + E : nullptr;
   const long nb = (M + K - 1) / K;
+  const int algo = h->band_algo;
+  // the planned prior chain needs the LDS only for the P chain and the factor table
+  const bool have_plan = h->plan && prior_plan_M(h->plan) == M && prior_plan_k(h->plan) == K && prior_plan_terms(h->plan) == cf.n;
+  if (algo == 3 && !have_plan) { set_error("band algorithm 3 needs asvgp_prior_plan_1d for this (M, k, kernel)"); return ASVGP_ERR_BAD_ARG; }
   size_t ldsK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0>(nb) : bcr_lds_doubles<double, K, 0>(nb));
   size_t ldsP = sizeof(double) * bcr_lds_doubles<double, K, 1>(nb);
-  size_t lds_bytes = ldsK > ldsP ? ldsK : ldsP;
+  bool planned = (D == 1) && have_plan && (algo == 0 || algo == 3);
+  size_t lds_bytes = planned ? ldsP : (ldsK > ldsP ? ldsK : ldsP);
   bool fits = lds_bytes <= 160 * 1024 - 256;
   bool big = false;   // BIG layout (bcr.hpp): twice the nodes, couplings in an L2-resident plane - M up to 4096 at k = 4
   constexpr bool HAS_BIG = (K <= 5);   // (the k = 6 BIG instantiation alone costs ~5 minutes of compile time)
-  if (HAS_BIG && !fits && g_band_algo != 3) {
+  if (HAS_BIG && !fits) {
     size_t bK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0, true>(nb) : bcr_lds_doubles<double, K, 0, true>(nb));
     size_t bP = sizeof(double) * bcr_lds_doubles<double, K, 1, true>(nb);
-    size_t bb = bK > bP ? bK : bP;
+    size_t bb = planned ? bP : (bK > bP ? bK : bP);
     if (bb <= 160 * 1024 - 256) { big = true; fits = true; lds_bytes = bb; }
   }
-  use_bcr = (D == 1) && (g_band_algo == 2 || g_band_algo == 3 || (g_band_algo == 0 && fits));
-  const bool lane16 = (g_band_algo == 3);   // auto = hybrid BCR (bcr.hpp: thread-per-node wide levels, lane-distributed narrow levels)
-  if (part != 0 && !use_bcr) {   // split scheduling exists for the BCR path only: the sweeps run as one unit in the data call
+  use_bcr = (D == 1) && (algo == 2 || algo == 3 || (algo == 0 && fits));
+  planned = planned && use_bcr;
+  if (part != 0 && (!use_bcr || planned)) {
+    // split scheduling exists for the all-GPU BCR path only: the sweeps and the planned chain run as one unit in the data call
     if (part == 1) return ASVGP_OK;
     part = 0;
   }
+  if (planned) {
+    // ---- host: forward pass of the Kuu chain for this theta (prior_plan.cpp, ~20 us) into the next slot of the pinned ring.
+    // Kuu / dKuu (finalize traces, P = A/s + Kuu in the P chain's gathers) are assembled by the prepare kernel meanwhile.
+    if (!fits) { set_error("BCR needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
+    hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s, w.Kuu,
+                       TANGENT ? w.dK : (double*)nullptr, (double*)nullptr);
+    unsigned long long seq = 0;
+    int slot = 0;
+    double* tab = handle_table_acquire(h, &seq, &slot);
+    (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);   // a non-positive pivot is reported through `info` by the kernel
+    const int n_rec = prior_plan_nrec(h->plan);
+    size_t lds_pre = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
+    if (lds_pre > lds_bytes) lds_bytes = lds_pre;
+    auto kern = big ? elbo_chains_kernel<K, HAS_BIG> : elbo_chains_kernel<K, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+    hipLaunchKernelGGL(kern, dim3(2), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
+                       h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK,
+                       h->done_dev + slot, seq);
+    if (scale_alpha) {
+      long n = M * D;
+      hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
+    }
+    return check_launch("elbo chains (planned prior)");
+  }
   // Kuu/dKuu (theta only) are written by the prior part, P = A/s + Kuu by the data part (which re-forms Kuu in registers)
-  const bool pfly = (part == 2) && use_bcr && !lane16;   // data chain of the split call: P formed inside the BCR gathers
+  const bool pfly = (part == 2) && use_bcr;   // data chain of the split call: P formed inside the BCR gathers
   if (!pfly)
     hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s,
                        part == 2 ? w.LK : w.Kuu, part == 2 ? (double*)nullptr : w.dK, part == 1 ? (double*)nullptr : w.P);
-  if (g_sync_on && part == 1) (void)hipEventRecord(g_evK, st);
-  if (g_sync_on && part == 2) (void)hipStreamWaitEvent(st, g_evK, 0);
+  if (h->sync_on && part == 1) (void)hipEventRecord(h->evK, st);
+  if (h->sync_on && part == 2) (void)hipStreamWaitEvent(st, h->evK, 0);
   if (use_bcr) {
     if (!fits) { set_error("BCR forced but needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
-    hipError_t e = lane16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(elbo_bcr16_kernel<K, TANGENT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                          : hipFuncSetAttribute(big ? reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT, HAS_BIG>) : reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT, HAS_BIG>) : reinterpret_cast<const void*>(elbo_bcr_kernel<K, TANGENT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-    if (lane16)
-      hipLaunchKernelGGL((elbo_bcr16_kernel<K, TANGENT>), dim3(part == 0 ? 2 : 1), dim3(BCR16_THREADS), lds_bytes, st, w.Kuu, w.dK,
-                         w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
-                         getenv("ASVGP_BCR_STAMPS") ? 1 : 0, part == 2 ? 1 : 0);
-    else if (part == 1 && TANGENT) {
+    if (part == 1 && TANGENT) {
       if constexpr (TANGENT) {
         auto kern = big ? elbo_bcr_prior_kernel<K, HAS_BIG> : elbo_bcr_prior_kernel<K, false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -393,7 +412,7 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
                          getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, 0.0);
     }
     if (part == 1) {
-      if (g_sync_on) (void)hipEventRecord(g_evP, st);
+      if (h->sync_on) (void)hipEventRecord(h->evP, st);
       return check_launch("elbo prior chain");
     }
   } else if (D == 1) {
@@ -418,14 +437,14 @@ static int run_chains(const double* stats, const double* S, int kind, double v, 
 }
 
 template <int K>
-int ElboLauncher<K>::run(const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
+int ElboLauncher<K>::run(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
                          double* out, int* info, void* ws, hipStream_t st, int part) {
   {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
-    int rc = run_chains<K, true>(stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false);
-    if (rc || part == 1) return rc;
-    if (g_sync_on && part == 2 && bcr) (void)hipStreamWaitEvent(st, g_evP, 0);
+    int rc = run_chains<K, true>(h, stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false);
+    if (rc || (part == 1)) return rc;
+    if (h->sync_on && part == 2 && bcr && h->evP) (void)hipStreamWaitEvent(st, h->evP, 0);
     ElboScalars th{v, l, s, (double)N};
     const int fin_blocks = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
     hipLaunchKernelGGL(elbo_finalize_kernel<K>, dim3(fin_blocks), dim3(256), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK,
@@ -435,12 +454,12 @@ int ElboLauncher<K>::run(const double* stats, const double* S, int kind, double 
   }
 }
 template <int K>
-int PostLauncher<K>::run(const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
+int PostLauncher<K>::run(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
                          double* alpha, double* W, int* info, void* ws, hipStream_t st) {
   {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
-    int rc = run_chains<K, false>(stats, S, kind, v, l, s, M, D, w, info, st, bcr);
+    int rc = run_chains<K, false>(h, stats, S, kind, v, l, s, M, D, w, info, st, bcr);
     if (rc) return rc;
     long E = (long)(K + 1) * M;
     hipLaunchKernelGGL(scale_sub_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, w.SP, w.SK, W, E);
@@ -465,24 +484,6 @@ template struct PostLauncher<ASVGP_ELBO_ONLY_K>;
 #ifndef ASVGP_ELBO_ONLY_K
 using namespace asvgp;
 
-extern "C" int asvgp_set_band_algorithm(int algo) {
-  if (algo < 0 || algo > 3) { set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 BCR one thread per node, 3 BCR lane-distributed"); return ASVGP_ERR_BAD_ARG; }
-  g_band_algo = algo;
-  return ASVGP_OK;
-}
-
-extern "C" int asvgp_elbo_chain_sync(int enable) {
-  if (enable && !g_evK) {
-    if (hipEventCreateWithFlags(&g_evK, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
-        hipEventCreateWithFlags(&g_evP, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
-      set_error("elbo_chain_sync: hipEventCreate failed");
-      return ASVGP_ERR_HIP;
-    }
-  }
-  g_sync_on = enable != 0;
-  return ASVGP_OK;
-}
-
 extern "C" size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D) {
   if (M < 1 || k < 1 || D < 1) return 0;
   return sizeof(double) * ws_doubles(M, k, D);
@@ -500,48 +501,51 @@ static int elbo_args_ok(const void* stats, const void* S, const void* out, int64
   return ASVGP_OK;
 }
 
-extern "C" int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind, double variance,
+extern "C" int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                                   double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                                   double* out, int* info, void* workspace, size_t workspace_bytes,
                                   asvgp_stream_t stream) {
   int rc = elbo_args_ok(stats, static_bands, out, M, k, D, variance, lengthscale, noise_variance, workspace,
                         workspace_bytes, info, "elbo_grad_1d");
   if (rc) return rc;
+  Handle* h = as_handle(handle);
   hipStream_t st = as_stream(stream);
-#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 0);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 0);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
 #undef ELBO_CASE
   return ASVGP_ERR_UNSUPPORTED;
 }
 
-extern "C" int asvgp_elbo_prior_chain_1d(const double* static_bands, int kind, double variance, double lengthscale,
+extern "C" int asvgp_elbo_prior_chain_1d(asvgp_handle_t handle, const double* static_bands, int kind, double variance, double lengthscale,
                                          double noise_variance, int64_t M, int k, int64_t D, int* info, void* workspace,
                                          size_t workspace_bytes, asvgp_stream_t stream) {
   int rc = elbo_args_ok(static_bands, static_bands, static_bands, M, k, D, variance, lengthscale, noise_variance, workspace,
                         workspace_bytes, info, "elbo_prior_chain_1d");
   if (rc) return rc;
+  Handle* h = as_handle(handle);
   hipStream_t st = as_stream(stream);
-#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(nullptr, static_bands, kind, variance, lengthscale, noise_variance, 0, (long)M, (long)D, nullptr, info, workspace, st, 1);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(h, nullptr, static_bands, kind, variance, lengthscale, noise_variance, 0, (long)M, (long)D, nullptr, info, workspace, st, 1);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
 #undef ELBO_CASE
   return ASVGP_ERR_UNSUPPORTED;
 }
 
-extern "C" int asvgp_elbo_data_chain_1d(const double* stats, const double* static_bands, int kind, double variance,
+extern "C" int asvgp_elbo_data_chain_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                                         double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                                         double* out, int* info, void* workspace, size_t workspace_bytes,
                                         asvgp_stream_t stream) {
   int rc = elbo_args_ok(stats, static_bands, out, M, k, D, variance, lengthscale, noise_variance, workspace,
                         workspace_bytes, info, "elbo_data_chain_1d");
   if (rc) return rc;
+  Handle* h = as_handle(handle);
   hipStream_t st = as_stream(stream);
-#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 2);
+#define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 2);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
 #undef ELBO_CASE
   return ASVGP_ERR_UNSUPPORTED;
 }
 
-extern "C" int asvgp_posterior_prepare_1d(const double* stats, const double* static_bands, int kind, double variance,
+extern "C" int asvgp_posterior_prepare_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                                           double lengthscale, double noise_variance, int64_t M, int k, int64_t D,
                                           double* alpha, double* W, int* info, void* workspace, size_t workspace_bytes,
                                           asvgp_stream_t stream) {
@@ -549,8 +553,9 @@ extern "C" int asvgp_posterior_prepare_1d(const double* stats, const double* sta
                         workspace_bytes, info, "posterior_prepare_1d");
   if (rc) return rc;
   if (!W) { set_error("posterior_prepare_1d: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  Handle* h = as_handle(handle);
   hipStream_t st = as_stream(stream);
-#define POST_CASE(KK) case KK: return PostLauncher<KK>::run(stats, static_bands, kind, variance, lengthscale, noise_variance, (long)M, (long)D, alpha, W, info, workspace, st);
+#define POST_CASE(KK) case KK: return PostLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)M, (long)D, alpha, W, info, workspace, st);
   switch (k) { POST_CASE(1) POST_CASE(2) POST_CASE(3) POST_CASE(4) POST_CASE(5) POST_CASE(6) }
 #undef POST_CASE
   return ASVGP_ERR_UNSUPPORTED;

@@ -1,0 +1,207 @@
+// asvgp_create / asvgp_destroy and the per-handle settings (C-ABI, include/asvgp_hip.h).
+#include <sched.h>
+#include <string.h>
+#include <time.h>
+
+#include <mutex>
+
+#include "handle.hpp"
+
+namespace asvgp {
+
+static Handle* g_default = nullptr;
+static std::mutex g_default_mu;
+
+Handle* as_handle(asvgp_handle_t h) {
+  if (h) return reinterpret_cast<Handle*>(h);
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default) {
+    g_default = new Handle;
+    (void)hipGetDevice(&g_default->device);
+  }
+  return g_default;
+}
+
+static void plan_release(Handle* h) {
+  if (h->plan) { prior_plan_destroy(h->plan); h->plan = nullptr; }
+  if (h->node_rec_dev) { (void)hipFree(h->node_rec_dev); h->node_rec_dev = nullptr; }
+  if (h->tab_host) { (void)hipHostFree(h->tab_host); h->tab_host = nullptr; h->tab_dev = nullptr; }
+  if (h->done_host) { (void)hipHostFree(h->done_host); h->done_host = nullptr; h->done_dev = nullptr; }
+  h->slot_doubles = 0;
+}
+
+double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out) {
+  const unsigned long long seq = ++h->seq;
+  const int slot = (int)(seq % TAB_SLOTS);
+  if (seq > TAB_SLOTS) {   // the slot's previous table (sequence seq - TAB_SLOTS) must have been read by its kernel
+    const unsigned long long need = seq - TAB_SLOTS;
+    volatile unsigned long long* flag = h->done_host + slot;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    while (*flag < need) {
+      sched_yield();
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) > 2) { (void)hipDeviceSynchronize(); break; }   // (a failed launch never sets the flag)
+    }
+  }
+  *seq_out = seq;
+  *slot_out = slot;
+  return h->tab_host + (size_t)slot * h->slot_doubles;
+}
+
+}  // namespace asvgp
+
+using namespace asvgp;
+
+extern "C" int asvgp_create(asvgp_handle_t* out) {
+  if (!out) { set_error("asvgp_create: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  Handle* h = new Handle;
+  if (hipGetDevice(&h->device) != hipSuccess) { delete h; set_error("asvgp_create: no HIP device"); return ASVGP_ERR_HIP; }
+  *out = reinterpret_cast<asvgp_handle_t>(h);
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_destroy(asvgp_handle_t handle) {
+  if (!handle) return ASVGP_OK;
+  Handle* h = reinterpret_cast<Handle*>(handle);
+  if (h->magic != 0x41535647u) { set_error("asvgp_destroy: not a handle"); return ASVGP_ERR_BAD_ARG; }
+  plan_release(h);
+  if (h->evK) (void)hipEventDestroy(h->evK);
+  if (h->evP) (void)hipEventDestroy(h->evP);
+  if (h->prof_made)
+    for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(h->prof_ev[i][0]); (void)hipEventDestroy(h->prof_ev[i][1]); }
+  h->magic = 0;
+  delete h;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo) {
+  if (algo != 0 && algo != 1 && algo != 3 && algo != 5) {
+    set_error("set_phi_algorithm: 0 auto (= 5), 1 fp64 LDS-atomic band scatter, 3 fixed-point band scatter, 5 fixed-point centred-moment scatter");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  as_handle(handle)->phi_algo = algo;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_set_phi_workgroups(asvgp_handle_t handle, int n) {
+  if (n < 0 || n > 256) { set_error("set_phi_workgroups: 0 (default, one per CU) .. 256"); return ASVGP_ERR_BAD_ARG; }
+  as_handle(handle)->phi_blocks = n;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo) {
+  if (algo < 0 || algo > 3) {
+    set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 block cyclic reduction on the GPU, 3 block cyclic reduction with the planned (host, long double) prior forward pass");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  as_handle(handle)->band_algo = algo;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_elbo_chain_sync(asvgp_handle_t handle, int enable) {
+  Handle* h = as_handle(handle);
+  if (enable && !h->evK) {
+    if (hipEventCreateWithFlags(&h->evK, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evP, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
+      set_error("elbo_chain_sync: hipEventCreate failed");
+      return ASVGP_ERR_HIP;
+    }
+  }
+  h->sync_on = enable != 0;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_profile_enable(asvgp_handle_t handle, int on) {
+  Handle* h = as_handle(handle);
+  if (on && !h->prof_made) {
+    for (int i = 0; i < PROF_RING; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (hipEventCreateWithFlags(&h->prof_ev[i][j], hipEventReleaseToDevice) != hipSuccess) { set_error("hipEventCreate failed"); return ASVGP_ERR_HIP; }
+    h->prof_made = true;
+  }
+  h->prof_on = on != 0;
+  h->prof_every = on > 1 ? on : 1;   // on = n > 1: every n-th launch
+  h->prof_calls = 0;
+  h->prof_n = 0;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_profile_read(asvgp_handle_t handle, double* phi_kernel_ms_sum, int64_t* launches) {
+  Handle* h = as_handle(handle);
+  if (!phi_kernel_ms_sum || !launches) { set_error("profile_read: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  double tot = 0.0;
+  for (long i = 0; i < h->prof_n; ++i) {
+    if (hipEventSynchronize(h->prof_ev[i][1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return ASVGP_ERR_HIP; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->prof_ev[i][0], h->prof_ev[i][1]);
+    tot += ms;
+  }
+  *phi_kernel_ms_sum = tot;
+  *launches = h->prof_n;
+  h->prof_n = 0;
+  return ASVGP_OK;
+}
+
+// Plan of the prior chain for one (basis, kernel kind): static_bands_host = the (n_terms, k+1, M) HOST copy of the array the
+// ELBO entry points receive on the device.  Returns ASVGP_OK with *planned = 1, or *planned = 0 when the bands have no
+// Toeplitz structure to exploit (the all-GPU chain is used then).
+extern "C" int asvgp_prior_plan_1d(asvgp_handle_t handle, const double* static_bands_host, int n_terms, int64_t M, int k,
+                                   int* planned) {
+  Handle* h = as_handle(handle);
+  if (planned) *planned = 0;
+  plan_release(h);
+  if (!static_bands_host) return ASVGP_OK;     // NULL: drop the plan
+  char err[256] = "";
+  PriorPlan* p = prior_plan_create(static_bands_host, n_terms, (long)M, k, err, sizeof(err));
+  if (!p) {
+    if (strstr(err, "bad argument")) { set_error("%s", err); return ASVGP_ERR_BAD_ARG; }
+    return ASVGP_OK;                           // unstructured band: no plan, not an error
+  }
+  const int nb = prior_plan_nb(p);
+  h->slot_doubles = (prior_plan_table_doubles(p) + 63) / 64 * 64;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&h->node_rec_dev), sizeof(int) * (size_t)nb) == hipSuccess &&
+            hipMemcpy(h->node_rec_dev, prior_plan_node_rec(p), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&h->tab_host), sizeof(double) * h->slot_doubles * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&h->tab_dev), h->tab_host, 0) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&h->done_host), sizeof(unsigned long long) * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&h->done_dev), h->done_host, 0) == hipSuccess;
+  if (!ok) {
+    prior_plan_destroy(p);
+    plan_release(h);
+    set_error("prior_plan_1d: device / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    return ASVGP_ERR_HIP;
+  }
+  memset(h->done_host, 0, sizeof(unsigned long long) * TAB_SLOTS);
+  h->plan = p;
+  h->plan_terms = n_terms;
+  h->seq = 0;
+  if (planned) *planned = 1;
+  return ASVGP_OK;
+}
+
+// Host-only evaluation of the planner (no device): table of prior_plan_eval and the node -> record map for one theta.
+// table_host needs asvgp_prior_table_doubles entries, node_rec_host ceil(M / k) ints.  Used by the CPU tests; the product
+// path goes through asvgp_prior_plan_1d + the ELBO entry points.
+extern "C" size_t asvgp_prior_table_doubles(const double* static_bands_host, int n_terms, int64_t M, int k) {
+  char err[256];
+  PriorPlan* p = prior_plan_create(static_bands_host, n_terms, (long)M, k, err, sizeof(err));
+  if (!p) return 0;
+  const size_t n = prior_plan_table_doubles(p);
+  prior_plan_destroy(p);
+  return n;
+}
+
+extern "C" int asvgp_prior_forward_host(const double* static_bands_host, int n_terms, int64_t M, int k, const double* coef_host,
+                                        const double* dcoef_dl_host, double* table_host, size_t table_doubles, int* node_rec_host) {
+  if (!coef_host || !dcoef_dl_host || !table_host || !node_rec_host) { set_error("prior_forward_host: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  char err[256] = "";
+  PriorPlan* p = prior_plan_create(static_bands_host, n_terms, (long)M, k, err, sizeof(err));
+  if (!p) { set_error("%s", err); return strstr(err, "bad argument") ? ASVGP_ERR_BAD_ARG : ASVGP_ERR_UNSUPPORTED; }
+  if (table_doubles < prior_plan_table_doubles(p)) { prior_plan_destroy(p); set_error("prior_forward_host: table too small"); return ASVGP_ERR_WORKSPACE; }
+  (void)prior_plan_eval(p, coef_host, dcoef_dl_host, table_host);
+  memcpy(node_rec_host, prior_plan_node_rec(p), sizeof(int) * (size_t)prior_plan_nb(p));
+  prior_plan_destroy(p);
+  return ASVGP_OK;
+}

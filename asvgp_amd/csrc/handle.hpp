@@ -1,0 +1,44 @@
+// The opaque library handle (asvgp_create / asvgp_destroy): everything that used to be process-wide state -
+// algorithm choices, the Phi-pass workgroup count, the chain-ordering events, the kernel-timing ring, and the host
+// planner of the prior chain with its pinned factor-table ring - lives here, one handle per model / stream / host thread.
+#pragma once
+#include "asvgp_common.hpp"
+#include "prior_plan.hpp"
+
+namespace asvgp {
+
+constexpr int PROF_RING = 1024;
+constexpr int TAB_SLOTS = 16;
+
+struct Handle {
+  unsigned magic = 0x41535647u;   // 'ASVG'
+  int device = 0;
+  // Phi pass
+  int phi_algo = 0, phi_blocks = 0;
+  // band algebra
+  int band_algo = 0;
+  bool sync_on = false;
+  hipEvent_t evK = nullptr, evP = nullptr;
+  // timing ring around the dominant kernel (bench.py's roofline figure)
+  bool prof_on = false, prof_made = false;
+  int prof_every = 1;
+  long prof_calls = 0, prof_n = 0;
+  hipEvent_t prof_ev[PROF_RING][2];
+  // prior chain planner (prior_plan.cpp): host forward pass, factor tables handed to the GPU through a pinned ring
+  PriorPlan* plan = nullptr;
+  int* node_rec_dev = nullptr;            // device copy of the node -> record map
+  double* tab_host = nullptr;             // TAB_SLOTS x slot_doubles, pinned + mapped
+  double* tab_dev = nullptr;              // the same memory as seen from the device
+  unsigned long long* done_host = nullptr;   // per slot: sequence number of the last table the GPU has finished reading
+  unsigned long long* done_dev = nullptr;
+  size_t slot_doubles = 0;
+  unsigned long long seq = 0;
+  int plan_terms = 0;
+};
+
+Handle* as_handle(asvgp_handle_t h);      // NULL -> the process-wide default handle (created on first use)
+
+// next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
+double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);
+
+}  // namespace asvgp

@@ -9,7 +9,7 @@
 // HBM roofline: 16 B/point (x and y read once, fp64).  Everything else is on-chip.
 #include <stdlib.h>
 
-#include "asvgp_common.hpp"
+#include "handle.hpp"
 
 namespace asvgp {
 
@@ -360,29 +360,8 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
 }
 
 
-// =================================================================================================
-// Phi pass v2: tile-local counting sort + per-cell moment accumulation in registers.
-//
-// The per-point LDS fp64 atomics of v1 (20 per point, ~30 cycles per wave-instruction under random
-// addresses) are replaced by:  (1) one returning u32 LDS atomic per point (rank inside its cell),
-// (2) an exclusive scan of the per-cell counts, (3) one 16-B LDS write of (s, y), s = t - 1/2,
-// (4) the thread that OWNS the cell (thread tau owns cells tau and tau+1024 of the chunk) reads its
-// points back and accumulates the 3k+2 sufficient statistics  S_p = sum s^p (p<=2k), T_p = sum y s^p (p<=k)
-// in registers - no fp64 atomics in the streaming loop.  After the last tile the moments are converted
-// once per workgroup into band / rhs entries (products of the piece polynomials expanded in s with exact
-// integer coefficients), flushed, and reduced across workgroups exactly like v1.
-// Cells holding more than HEAVY points of a tile (sorted / clustered inputs) are accumulated by the
-// whole wavefront cooperatively, so time-series order is not a worst case.
-// =================================================================================================
-// Workgroup barrier that orders LDS traffic only: global loads issued before it (the next tile's prefetch) stay
-// in flight across it.  __syncthreads() would make hipcc drain them with s_waitcnt vmcnt(0) (cdna guide, "Pipelining
-// across barriers"), serialising HBM time with compute.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-constexpr int MOM_THREADS = 1024;
-constexpr int MOM_CELLS = 2048;   // cells per pass (2 per thread)
-constexpr int MOM_HEAVY = 40;
-
+// Centred-moment coefficient tables: v_i(s + 1/2) and v_i v_j as polynomials in s = t - 1/2 with exact integer-ratio
+// coefficients (used by the centred-moment Phi pass to turn per-cell moments into band / rhs entries).
 using i128 = __int128;
 // Compile-time coefficient tables (constexpr constructor => guaranteed constant evaluation; every use below has
 // static indices after unrolling, so the entries fold into instruction literals).
@@ -426,608 +405,6 @@ template <int K> struct MomCoef {
   static constexpr MomTab<K> tab{};
 };
 
-template <int K>
-__device__ __forceinline__ void mom_accumulate(double s, double y, double (&S)[2 * K + 1], double (&T)[K + 1]) {
-  double pw = 1.0;
-  S[0] += 1.0;
-  T[0] += y;
-#pragma unroll
-  for (int p = 1; p <= 2 * K; ++p) {
-    pw *= s;
-    S[p] += pw;
-    if (p <= K) T[p] = fma(y, pw, T[p]);
-  }
-}
-
-
-// Heavy cells of a wave's 128 owned cells (sorted / clustered input): the whole wavefront walks the cell's points, in TWO
-// passes (S moments, then T moments) so that at most 2k+1 temporaries are live next to the 2 (3k+2) owner accumulators - the
-// one-pass version cost 64 spilled VGPRs in the streaming loop - and reduces on the VALU (DPP).  Wave-uniform control flow.
-template <int K>
-__device__ __forceinline__ void mom_heavy_cells(const double2* buf, unsigned nA, unsigned oA, bool hvA, unsigned nB, unsigned oB,
-                                                bool hvB, int lane, double (&SA)[2 * K + 1], double (&TA)[K + 1],
-                                                double (&SB)[2 * K + 1], double (&TB)[K + 1]) {
-  unsigned long long ma = __ballot(hvA), mb = __ballot(hvB);
-  while (ma | mb) {
-    const bool isA = ma != 0ull;
-    const unsigned long long m = isA ? ma : mb;
-    const int h = __ffsll((long long)m) - 1;
-    if (isA) ma &= ma - 1; else mb &= mb - 1;
-    const unsigned nh = (unsigned)__builtin_amdgcn_readlane((int)(isA ? nA : nB), h);
-    const unsigned oh = (unsigned)__builtin_amdgcn_readlane((int)(isA ? oA : oB), h);
-    const bool meA = isA && lane == h, meB = !isA && lane == h;
-    {
-      double S2[2 * K + 1];
-#pragma unroll
-      for (int p = 0; p <= 2 * K; ++p) S2[p] = 0.0;
-      for (unsigned j = lane; j < nh; j += 64) {
-        const double sv = buf[oh + j].x;
-        double pw = 1.0;
-        S2[0] += 1.0;
-#pragma unroll
-        for (int p = 1; p <= 2 * K; ++p) { pw *= sv; S2[p] += pw; }
-      }
-#pragma unroll
-      for (int p = 0; p <= 2 * K; ++p) {
-        const double t = wave_sum_dpp(S2[p]);
-        SA[p] += meA ? t : 0.0;
-        SB[p] += meB ? t : 0.0;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      double T2[K + 1];
-#pragma unroll
-      for (int p = 0; p <= K; ++p) T2[p] = 0.0;
-      for (unsigned j = lane; j < nh; j += 64) {
-        const double2 pt = buf[oh + j];
-        double pw = 1.0;
-        T2[0] += pt.y;
-#pragma unroll
-        for (int p = 1; p <= K; ++p) { pw *= pt.x; T2[p] = fma(pt.y, pw, T2[p]); }
-      }
-#pragma unroll
-      for (int p = 0; p <= K; ++p) {
-        const double t = wave_sum_dpp(T2[p]);
-        TA[p] += meA ? t : 0.0;
-        TB[p] += meB ? t : 0.0;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// both cells of one owner lane in ONE loop (trip = max(nA, nB) instead of nA + nB, two independent FMA streams);
-// a missing point is fed as (s, y) = (0, 0), which only touches S_0 - masked explicitly.
-template <int K>
-__device__ __forceinline__ void mom_own_two_cells(const double2* buf, unsigned nA, unsigned oA, unsigned nB, unsigned oB,
-                                                  int lane, double (&SA)[2 * K + 1], double (&TA)[K + 1],
-                                                  double (&SB)[2 * K + 1], double (&TB)[K + 1]) {
-  const bool hvA = nA > MOM_HEAVY, hvB = nB > MOM_HEAVY;
-  const unsigned la = hvA ? 0u : nA, lb = hvB ? 0u : nB;
-  const unsigned n = la > lb ? la : lb;
-  for (unsigned j = 0; j < n; ++j) {
-    const bool a = j < la, b = j < lb;
-    double2 pa = a ? buf[oA + j] : make_double2(0.0, 0.0);
-    double2 pb = b ? buf[oB + j] : make_double2(0.0, 0.0);
-    double wa = pa.x, wb = pb.x;
-    SA[0] += a ? 1.0 : 0.0;
-    SB[0] += b ? 1.0 : 0.0;
-    TA[0] += pa.y;
-    TB[0] += pb.y;
-    SA[1] += wa; SB[1] += wb;
-    TA[1] = fma(pa.y, wa, TA[1]); TB[1] = fma(pb.y, wb, TB[1]);
-#pragma unroll
-    for (int p = 2; p <= 2 * K; ++p) {
-      wa *= pa.x; wb *= pb.x;
-      SA[p] += wa; SB[p] += wb;
-      if (p <= K) { TA[p] = fma(pa.y, wa, TA[p]); TB[p] = fma(pb.y, wb, TB[p]); }
-    }
-  }
-  if (__any(hvA || hvB)) mom_heavy_cells<K>(buf, nA, oA, hvA, nB, oB, hvB, lane, SA, TA, SB, TB);
-}
-
-// moments of cell c -> band / rhs contributions (exact integer-ratio coefficients, centred monomials)
-template <int K>
-__device__ __forceinline__ void mom_to_band(const double (&S)[2 * K + 1], const double (&T)[K + 1], int c, int ncols,
-                                            int do_band, double* band, double* rhs) {
-  if (S[0] == 0.0) return;
-#pragma unroll
-  for (int i = 0; i <= K; ++i) {
-    double r = 0.0;
-#pragma unroll
-    for (int p = 0; p <= K; ++p) r = fma(MomCoef<K>::tab.single[i][p], T[p], r);
-    lds_add(rhs + c + K - i, r);
-    if (do_band) {
-#pragma unroll
-      for (int j = i; j <= K; ++j) {
-        double b = 0.0;
-#pragma unroll
-        for (int p = 0; p <= 2 * K; ++p) b = fma(MomCoef<K>::tab.pair[i][j][p], S[p], b);
-        lds_add(band + (j - i) * ncols + c + K - j, b);
-      }
-    }
-  }
-}
-
-template <int K, int TP, bool VEC, int ablate = 0>
-__global__ __launch_bounds__(MOM_THREADS) void phi_moments_kernel(
-    const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
-    const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
-    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n) {
-  extern __shared__ double lds[];
-  if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
-  constexpr int T = TP * MOM_THREADS;
-  double2* buf = reinterpret_cast<double2*>(lds);                      // T sorted (s, y)
-  unsigned* cnt = reinterpret_cast<unsigned*>(lds + 2 * T);            // MOM_CELLS
-  unsigned* off = cnt + MOM_CELLS;                                     // MOM_CELLS + 1
-  unsigned* wtot = off + MOM_CELLS + 1;                                // 16 wave totals (+pad)
-  double* red = reinterpret_cast<double*>(wtot + 32);                  // 16 doubles
-  int* flag = reinterpret_cast<int*>(red + 16);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int NC = cell1 - cell0;
-
-  // ---- is the mesh table bit-identical to numpy's linspace arithmetic  i*step + a ?  (then no table lookups)
-  const double m0 = mesh_g[0];
-  const double step = (mesh_g[n_mesh - 1] - m0) / (double)(n_mesh - 1);
-  if (tid == 0) *flag = 1;
-  for (int e = tid; e < 2 * MOM_CELLS; e += MOM_THREADS) cnt[e] = 0;   // cnt and off
-  __syncthreads();
-  {
-    bool ok = true;
-    for (int e = tid; e < n_mesh - 1; e += MOM_THREADS) ok = ok && (__dadd_rn(__dmul_rn((double)e, step), m0) == mesh_g[e]);
-    if (!ok) *flag = 0;
-  }
-  __syncthreads();
-  const bool arith = (*flag != 0);
-  auto knot = [&](int i) -> double { return arith ? __dadd_rn(__dmul_rn((double)i, step), m0) : mesh_g[i]; };
-
-  // diagnostic variant 9: per-phase cycle stamps of thread 0 (written over this block's partial after the flush)
-  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-  auto stamp = [&](int i) {
-    if constexpr (ablate == 9) {
-      unsigned long long t = __builtin_amdgcn_s_memtime();
-      if (i >= 0) ph[i] += t - tprev;
-      tprev = t;
-    }
-  };
-  double SA[2 * K + 1], TA[K + 1], SB[2 * K + 1], TB[K + 1];
-#pragma unroll
-  for (int p = 0; p <= 2 * K; ++p) { SA[p] = 0.0; SB[p] = 0.0; }
-#pragma unroll
-  for (int p = 0; p <= K; ++p) { TA[p] = 0.0; TB[p] = 0.0; }
-  double yy = 0.0;
-
-  const long beg = (long)blockIdx.x * ppb;
-  long end = beg + ppb;
-  if (end > N) end = N;
-
-  double xs[TP], ys[TP];
-  // point q of this thread: VEC -> pairs (base + 2*(q2*1024+tid) + {0,1}).  The tile is fetched in TP/2 slices so that
-  // no phase issues more than ~32 KB per CU at once (a whole tile exceeds what a CU keeps in flight and the issue blocks).
-  auto load_slice = [&](long base, int q0, int q1) {
-#pragma unroll
-    for (int q = 0; q < TP; q += 2) {
-      if (q < q0 || q >= q1) continue;
-      if (VEC) {
-        long i = base + 2 * ((long)(q >> 1) * MOM_THREADS + tid);
-        if (i + 1 < end) {
-          double2 xv = *reinterpret_cast<const double2*>(x + i);
-          double2 yv = *reinterpret_cast<const double2*>(y + i);
-          xs[q] = xv.x; xs[q + 1] = xv.y; ys[q] = yv.x; ys[q + 1] = yv.y;
-        } else {
-          xs[q] = (i < end) ? x[i] : __builtin_nan("");
-          ys[q] = (i < end) ? y[i] : 0.0;
-          xs[q + 1] = __builtin_nan(""); ys[q + 1] = 0.0;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          long i = base + (long)(q + u) * MOM_THREADS + tid;
-          xs[q + u] = (i < end) ? x[i] : __builtin_nan("");
-          ys[q + u] = (i < end) ? y[i * y_stride] : 0.0;
-        }
-      }
-    }
-  };
-
-  auto load_tile = [&](long base) { load_slice(base, 0, TP); };
-  constexpr int SL = (TP / 2 + 2) / 3 * 2;  // points per slice (3 slices)
-  if (beg < end) load_tile(beg);
-  for (long base = beg; base < end; base += T) {
-    stamp(-1);
-    // ---- P1: cell, centred coordinate, rank within the cell
-    double sv[TP], yv[TP];
-    int cr[TP];  // cell << 13 | rank   (rank < 8192), -1 = not in this chunk / out of range
-    {
-      int ci[TP];
-      bool slow = false;
-#pragma unroll
-      for (int q = 0; q < TP; ++q) {
-        const double xv = xs[q];
-        yv[q] = ys[q];
-        double g = floor((xv - m0) * inv_delta);
-        int i = (g < 0.0) ? 0 : ((g > (double)(n_mesh - 2)) ? (n_mesh - 2) : (int)g);   // NaN -> 0
-        // branch-free +-1 fix-up against the knots (the floor guess is off by at most one on a monotone mesh) ...
-        i -= (i > 0 && !(knot(i) < xv)) ? 1 : 0;
-        i += (i < n_mesh - 2 && knot(i + 1) < xv) ? 1 : 0;
-        // ... verified; anything else (wildly non-uniform table) takes the exact search below
-        const double lo = knot(i), hi = knot(i + 1);
-        const bool good = (lo < xv || i == 0) && (!(hi < xv) || i == n_mesh - 2);
-        slow = slow || (!good && xv == xv);
-        ci[q] = i;
-        sv[q] = fma(xv - lo, inv_delta, -0.5);
-      }
-      if (__any(slow)) {  // rare: exact searchsorted semantics by linear walk
-#pragma unroll
-        for (int q = 0; q < TP; ++q) {
-          const double xv = xs[q];
-          int i = ci[q];
-          while (i > 0 && !(knot(i) < xv)) --i;
-          while (i < n_mesh - 2 && knot(i + 1) < xv) ++i;
-          ci[q] = i;
-          sv[q] = fma(xv - knot(i), inv_delta, -0.5);
-        }
-      }
-      if constexpr (ablate == 1 || ablate == 2) {
-#pragma unroll
-        for (int q = 0; q < TP; ++q) yy += sv[q] + (double)ci[q] + yv[q];
-      } else {
-        unsigned rk[TP];
-#pragma unroll
-        for (int q = 0; q < TP; ++q) {  // all rank atomics of the tile in flight together
-          const int c = ci[q] - cell0;
-          const bool ok = (xs[q] == xs[q]) && c >= 0 && c < NC;
-          cr[q] = ok ? c : -1;
-          rk[q] = ok ? atomicAdd(&cnt[c], 1u) : 0u;
-          yy = ok ? fma(yv[q], yv[q], yy) : yy;
-        }
-#pragma unroll
-        for (int q = 0; q < TP; ++q) cr[q] = (cr[q] >= 0) ? ((cr[q] << 13) | (int)rk[q]) : -1;
-      }
-    }
-    if constexpr (ablate == 1 || ablate == 2) { if (base + T < end) load_tile(base + T); continue; }
-    lds_barrier();
-    stamp(0);
-    const bool more = base + T < end;
-    if constexpr (ablate == 3 || ablate == 4) { if (more) load_tile(base + T); }
-    if constexpr (ablate != 3 && ablate != 4) if (more) load_slice(base + T, 0, SL);  // prefetch the next tile in slices under the sort / owner phases
-    if constexpr (ablate == 3) {
-      lds_barrier();
-      cnt[tid] = 0; cnt[tid + MOM_THREADS] = 0;
-      lds_barrier();
-#pragma unroll
-      for (int q = 0; q < TP; ++q) yy += (double)(cr[q] & 8191);
-      continue;
-    }
-    // ---- P2: exclusive scan of cnt -> off   (thread t scans cells 2t, 2t+1)
-    {
-      unsigned c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
-      unsigned v = c0 + c1, inc = v;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        unsigned o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-      }
-      if (lane == 63) wtot[wv] = inc;
-      lds_barrier();
-      unsigned basew = 0;
-      for (int w = 0; w < wv; ++w) basew += wtot[w];
-      unsigned ex = basew + inc - v;
-      off[2 * tid] = ex;
-      off[2 * tid + 1] = ex + c0;
-    }
-    lds_barrier();
-    stamp(1);
-    if (more) load_slice(base + T, SL, 2 * SL);
-    // ---- P3: scatter (s, y) into cell order
-#pragma unroll
-    for (int q = 0; q < TP; ++q)
-      if (cr[q] >= 0) buf[off[cr[q] >> 13] + (cr[q] & 8191)] = make_double2(sv[q], yv[q]);
-    lds_barrier();
-    stamp(2);
-    if constexpr (ablate == 4) {
-      cnt[tid] = 0; cnt[tid + MOM_THREADS] = 0;
-      lds_barrier();
-      continue;
-    }
-    // ---- P4: owners accumulate their cells' moments
-    if (more) load_slice(base + T, 2 * SL, TP);
-    {
-      const unsigned nA = cnt[tid], oA = off[tid];
-      const unsigned nB = cnt[tid + MOM_THREADS], oB = off[tid + MOM_THREADS];
-      mom_own_two_cells<K>(buf, nA, oA, nB, oB, lane, SA, TA, SB, TB);
-      cnt[tid] = 0;
-      cnt[tid + MOM_THREADS] = 0;
-    }
-    stamp(3);
-    lds_barrier();
-    stamp(4);
-  }
-
-  // ---- moments -> band / rhs (LDS image aliases the sort buffers), then flush like v1
-  double tot = block_sum(yy, red);
-  __syncthreads();
-  const int E = (K + 2) * ncols;
-  for (int e = tid; e < E; e += MOM_THREADS) lds[e] = 0.0;
-  __syncthreads();
-  double* band = lds;
-  double* rhs = band + (K + 1) * ncols;
-  if constexpr (ablate == 5) {  // diagnostic: keep the moments alive, skip the conversion
-    double keep = 0.0;
-#pragma unroll
-    for (int p = 0; p <= 2 * K; ++p) keep += SA[p] + SB[p];
-#pragma unroll
-    for (int p = 0; p <= K; ++p) keep += TA[p] + TB[p];
-    if (tid < ncols) rhs[tid] = keep;
-  } else {
-    if (tid < NC) mom_to_band<K>(SA, TA, tid, ncols, do_band, band, rhs);
-    if (tid + MOM_THREADS < NC) mom_to_band<K>(SB, TB, tid + MOM_THREADS, ncols, do_band, band, rhs);
-  }
-  __syncthreads();
-  double* out = partials + (size_t)blockIdx.x * (E + 1);
-  for (int e = tid; e < E; e += MOM_THREADS) out[e] = lds[e];
-  if (tid == 0) out[E] = tot;
-  if constexpr (ablate == 9) {
-    __syncthreads();
-    if (tid == 0)
-      for (int i = 0; i < 6; ++i) out[i] = (double)ph[i];
-  }
-}
-
-// =================================================================================================
-// Phi pass v4 ("buckets"): per-cell point lists instead of a sort, one barrier per tile.
-//
-// Tile = 2048 points (one 16-B pair per thread), double-buffered in the LDS as raw (x, y).  Rank phase: every thread
-// finds its two cells and takes a slot in the cell's list with ONE returning u32 LDS atomic (count), then stores its
-// 11-bit point index in the slot (6 slots per cell; mean occupancy is 1 at M = 2048).  Points beyond 6 go to a
-// tile-wide overflow list that can hold the whole tile.  Owner phase (next barrier interval, overlapping the rank
-// phase of the following tile): thread tau owns cells 2tau and 2tau+1, reads count + slot words (4 conflict-free
-// ds_read_b64), fetches its points from the raw tile and accumulates the 3k+2 centred moments in registers exactly like
-// v2 - no fp64 atomics, no scan, no scatter of 16-B records.  A wavefront whose 128 points fall into ONE cell (sorted /
-// time-series input) reduces its moments on the VALU (DPP) and posts a single aggregate record instead.
-// =================================================================================================
-constexpr int BK_THREADS = 1024;
-constexpr int BK_T = 2 * BK_THREADS;   // points per tile
-constexpr int BK_CELLS = 2048;         // cells per pass (2 per thread)
-constexpr int BK_SLOTS = 6;
-constexpr int BK_AGG = 16;             // at most one aggregate per wave and tile
-
-template <int K> constexpr int bk_agg_doubles() { return 3 * K + 2 + 2; }   // cell, S[2K+1], T[K+1], pad
-
-template <int K>
-__host__ __device__ constexpr size_t bk_lds_bytes() {
-  return (size_t)2 * BK_T * 16            // raw tiles
-       + (size_t)2 * BK_CELLS * 4         // counts
-       + (size_t)2 * 3 * BK_CELLS * 4     // slot words (3 dwords = 6 u16 per cell), dword-major
-       + (size_t)3 * BK_T * 4             // overflow lists (triple-buffered with their counters)
-       + (size_t)3 * BK_AGG * bk_agg_doubles<K>() * 8
-       + 64 * 8;                          // counters, reduction scratch, flags
-}
-
-template <int K, bool VEC>
-__global__ __launch_bounds__(BK_THREADS) void phi_bucket_kernel(
-    const double* __restrict__ x, const double* __restrict__ y, long y_stride, long N,
-    const double* __restrict__ mesh_g, int n_mesh, double inv_delta, int cell0, int cell1, int ncols,
-    int do_band, double* __restrict__ partials, long ppb, double* __restrict__ zero_ptr, long zero_n) {
-  extern __shared__ double lds[];
-  if (zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_n; e += (long)gridDim.x * blockDim.x) zero_ptr[e] = 0.0;
-  constexpr int NA = bk_agg_doubles<K>();
-  double2* raw = reinterpret_cast<double2*>(lds);                                    // [2][BK_T]
-  unsigned* cnt = reinterpret_cast<unsigned*>(raw + 2 * BK_T);                      // [2][BK_CELLS]
-  unsigned* slotw = cnt + 2 * BK_CELLS;                                             // [2][3][BK_CELLS]
-  unsigned* ovf = slotw + 2 * 3 * BK_CELLS;                                         // [3][BK_T]   cell << 16 | point
-  double* agg = reinterpret_cast<double*>(ovf + 3 * BK_T);                          // [3][BK_AGG][NA]
-  double* red = agg + 3 * BK_AGG * NA;                                              // 16 doubles
-  unsigned* ctr = reinterpret_cast<unsigned*>(red + 16);                            // [3] overflow counts, [3] aggregate counts
-  int* flag = reinterpret_cast<int*>(ctr + 8);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int NC = cell1 - cell0;
-
-  const double m0 = mesh_g[0];
-  const double step = (mesh_g[n_mesh - 1] - m0) / (double)(n_mesh - 1);
-  if (tid == 0) *flag = 1;
-  for (int e = tid; e < 2 * BK_CELLS; e += BK_THREADS) cnt[e] = 0;
-  if (tid < 8) ctr[tid] = 0;
-  __syncthreads();
-  {
-    bool ok = true;
-    for (int e = tid; e < n_mesh - 1; e += BK_THREADS) ok = ok && (__dadd_rn(__dmul_rn((double)e, step), m0) == mesh_g[e]);
-    if (!ok) *flag = 0;
-  }
-  __syncthreads();
-  const bool arith = (*flag != 0);
-  auto knot = [&](int i) -> double { return arith ? __dadd_rn(__dmul_rn((double)i, step), m0) : mesh_g[i]; };
-
-  double SA[2 * K + 1], TA[K + 1], SB[2 * K + 1], TB[K + 1];
-#pragma unroll
-  for (int p = 0; p <= 2 * K; ++p) { SA[p] = 0.0; SB[p] = 0.0; }
-#pragma unroll
-  for (int p = 0; p <= K; ++p) { TA[p] = 0.0; TB[p] = 0.0; }
-  double yy = 0.0;
-  const int cA = 2 * tid, cB = 2 * tid + 1;                 // owned cells (chunk-local)
-  const double uA = knot(min(cell0 + cA, n_mesh - 2)), uB = knot(min(cell0 + cB, n_mesh - 2));
-
-  const long beg = (long)blockIdx.x * ppb;
-  long end = beg + ppb;
-  if (end > N) end = N;
-  const long ntiles = (end > beg) ? (end - beg + BK_T - 1) / BK_T : 0;
-
-  double2 px, py;   // the pair in flight (x0, x1), (y0, y1); NaN x = no point
-  auto load_pair = [&](long t) {
-    const long i = beg + t * BK_T + 2 * tid;
-    if (VEC) {
-      if (i + 1 < end) { px = *reinterpret_cast<const double2*>(x + i); py = *reinterpret_cast<const double2*>(y + i); return; }
-    }
-    px.x = (i < end) ? x[i] : __builtin_nan("");
-    py.x = (i < end) ? y[i * y_stride] : 0.0;
-    px.y = (i + 1 < end) ? x[i + 1] : __builtin_nan("");
-    py.y = (i + 1 < end) ? y[(i + 1) * y_stride] : 0.0;
-  };
-
-  auto find_cell = [&](double xv) -> int {
-    double g = floor((xv - m0) * inv_delta);
-    int i = (g < 0.0) ? 0 : ((g > (double)(n_mesh - 2)) ? (n_mesh - 2) : (int)g);   // NaN -> 0
-    i -= (i > 0 && !(knot(i) < xv)) ? 1 : 0;
-    i += (i < n_mesh - 2 && knot(i + 1) < xv) ? 1 : 0;
-    const double lo = knot(i), hi = knot(i + 1);
-    const bool good = (lo < xv || i == 0) && (!(hi < xv) || i == n_mesh - 2);
-    if (!good && xv == xv) {   // rare: exact searchsorted semantics by linear walk
-      while (i > 0 && !(knot(i) < xv)) --i;
-      while (i < n_mesh - 2 && knot(i + 1) < xv) ++i;
-    }
-    return i;
-  };
-
-  // ---- rank phase of tile t into buffer t & 1
-  auto rank_tile = [&](long t) {
-    const int b = (int)(t & 1), o3 = (int)(t % 3);
-    double2* rw = raw + b * BK_T;
-    unsigned* cn = cnt + b * BK_CELLS;
-    unsigned* sw = slotw + b * 3 * BK_CELLS;
-    const double xv[2] = {px.x, px.y}, yv[2] = {py.x, py.y};
-    rw[2 * tid] = make_double2(xv[0], yv[0]);
-    rw[2 * tid + 1] = make_double2(xv[1], yv[1]);
-    int c[2];
-    bool ok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int ci = find_cell(xv[u]) - cell0;
-      ok[u] = (xv[u] == xv[u]) && ci >= 0 && ci < NC;
-      c[u] = ok[u] ? ci : -1;
-      yy = ok[u] ? fma(yv[u], yv[u], yy) : yy;
-    }
-    if (t + 1 < ntiles) load_pair(t + 1);   // next pair in flight under the LDS work (raw barrier keeps it there)
-    const int c0 = __builtin_amdgcn_readfirstlane(c[0]);
-    if (__all(ok[0] && ok[1] && c[0] == c0 && c[1] == c0)) {   // wave-uniform: one aggregate record
-      const double u = knot(cell0 + c0);
-      double S2[2 * K + 1], T2[K + 1];
-#pragma unroll
-      for (int p = 0; p <= 2 * K; ++p) S2[p] = 0.0;
-#pragma unroll
-      for (int p = 0; p <= K; ++p) T2[p] = 0.0;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) mom_accumulate<K>(fma(xv[q] - u, inv_delta, -0.5), yv[q], S2, T2);
-      unsigned pos = 0;
-      if (lane == 0) pos = atomicAdd(&ctr[3 + o3], 1u);
-      pos = __builtin_amdgcn_readfirstlane(pos);
-      double* rec = agg + ((size_t)o3 * BK_AGG + pos) * NA;
-#pragma unroll
-      for (int p = 0; p <= 2 * K; ++p) { double r = wave_sum_dpp(S2[p]); if (lane == 0) rec[1 + p] = r; }
-#pragma unroll
-      for (int p = 0; p <= K; ++p) { double r = wave_sum_dpp(T2[p]); if (lane == 0) rec[2 + 2 * K + p] = r; }
-      if (lane == 0) rec[0] = (double)c0;
-      return;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (ok[u]) {
-        const unsigned r = atomicAdd(&cn[c[u]], 1u);
-        const unsigned pidx = 2 * tid + u;
-        if (r < BK_SLOTS) {
-          reinterpret_cast<unsigned short*>(sw + (r >> 1) * BK_CELLS + c[u])[r & 1] = (unsigned short)pidx;
-        } else {
-          const unsigned pos = atomicAdd(&ctr[o3], 1u);
-          ovf[o3 * BK_T + pos] = ((unsigned)c[u] << 16) | pidx;
-        }
-      }
-    }
-  };
-
-  // ---- owner phase of tile t
-  auto own_tile = [&](long t) {
-    const int b = (int)(t & 1), o3 = (int)(t % 3);
-    const double2* rw = raw + b * BK_T;
-    unsigned* cn = cnt + b * BK_CELLS;
-    const unsigned* sw = slotw + b * 3 * BK_CELLS;
-    const uint2 n2 = *reinterpret_cast<const uint2*>(cn + cA);
-    const unsigned nA = min(n2.x, (unsigned)BK_SLOTS), nB = min(n2.y, (unsigned)BK_SLOTS);
-    const unsigned nmax = max(nA, nB);
-    if (nmax) {
-      uint2 w[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const uint2*>(sw + q * BK_CELLS + cA);
-      if (n2.x | n2.y) *reinterpret_cast<uint2*>(cn + cA) = make_uint2(0u, 0u);
-#pragma unroll
-      for (int j = 0; j < BK_SLOTS; ++j) {
-        if (j < (int)nmax) {
-          const bool a = j < (int)nA, bb = j < (int)nB;
-          const unsigned ia = (w[j >> 1].x >> (16 * (j & 1))) & 0xffffu, ib = (w[j >> 1].y >> (16 * (j & 1))) & 0xffffu;
-          const double2 pa = a ? rw[ia] : make_double2(0.0, 0.0);
-          const double2 pb = bb ? rw[ib] : make_double2(0.0, 0.0);
-          const double sa = a ? fma(pa.x - uA, inv_delta, -0.5) : 0.0, sb = bb ? fma(pb.x - uB, inv_delta, -0.5) : 0.0;
-          double wa = sa, wb = sb;
-          SA[0] += a ? 1.0 : 0.0;
-          SB[0] += bb ? 1.0 : 0.0;
-          TA[0] += pa.y;
-          TB[0] += pb.y;
-          SA[1] += wa; SB[1] += wb;
-          TA[1] = fma(pa.y, wa, TA[1]); TB[1] = fma(pb.y, wb, TB[1]);
-#pragma unroll
-          for (int p = 2; p <= 2 * K; ++p) {
-            wa *= sa; wb *= sb;
-            SA[p] += wa; SB[p] += wb;
-            if (p <= K) { TA[p] = fma(pa.y, wa, TA[p]); TB[p] = fma(pb.y, wb, TB[p]); }
-          }
-        }
-      }
-    }
-    // overflow list of this tile (cells with more than BK_SLOTS points) and wave aggregates: usually both empty
-    const unsigned nov = ctr[o3], nag = ctr[3 + o3];
-    for (unsigned e = 0; e < nov; ++e) {
-      const unsigned ent = ovf[o3 * BK_T + e];
-      const int cc = (int)(ent >> 16);
-      if (cc == cA || cc == cB) {
-        const double2 pt = rw[ent & 0xffffu];
-        if (cc == cA) mom_accumulate<K>(fma(pt.x - uA, inv_delta, -0.5), pt.y, SA, TA);
-        else mom_accumulate<K>(fma(pt.x - uB, inv_delta, -0.5), pt.y, SB, TB);
-      }
-    }
-    for (unsigned e = 0; e < nag; ++e) {
-      const double* rec = agg + ((size_t)o3 * BK_AGG + e) * NA;
-      const int cc = (int)rec[0];
-      if (cc == cA) {
-#pragma unroll
-        for (int p = 0; p <= 2 * K; ++p) SA[p] += rec[1 + p];
-#pragma unroll
-        for (int p = 0; p <= K; ++p) TA[p] += rec[2 + 2 * K + p];
-      } else if (cc == cB) {
-#pragma unroll
-        for (int p = 0; p <= 2 * K; ++p) SB[p] += rec[1 + p];
-#pragma unroll
-        for (int p = 0; p <= K; ++p) TB[p] += rec[2 + 2 * K + p];
-      }
-    }
-  };
-
-  if (ntiles > 0) {
-    load_pair(0);
-    rank_tile(0);
-  }
-  lds_barrier();
-  for (long t = 0; t < ntiles; ++t) {
-    // counters of tile t + 2 were last read by the owner phase of tile t - 1, which the barrier above has retired
-    if (tid == 0) { ctr[(t + 2) % 3] = 0; ctr[3 + (t + 2) % 3] = 0; }
-    if (t + 1 < ntiles) rank_tile(t + 1);
-    own_tile(t);
-    lds_barrier();
-  }
-
-  // ---- moments -> band / rhs (LDS image aliases the tile buffers), then flush like v1
-  double tot = block_sum(yy, red);
-  __syncthreads();
-  const int E = (K + 2) * ncols;
-  for (int e = tid; e < E; e += BK_THREADS) lds[e] = 0.0;
-  __syncthreads();
-  double* band = lds;
-  double* rhs = band + (K + 1) * ncols;
-  if (cA < NC) mom_to_band<K>(SA, TA, cA, ncols, do_band, band, rhs);
-  if (cB < NC) mom_to_band<K>(SB, TB, cB, ncols, do_band, band, rhs);
-  __syncthreads();
-  double* out = partials + (size_t)blockIdx.x * (E + 1);
-  for (int e = tid; e < E; e += BK_THREADS) out[e] = lds[e];
-  if (tid == 0) out[E] = tot;
-}
 
 // Sum the per-workgroup partials into the packed stats buffer (zeroed beforehand).
 // grid = (ceil((E+1)/256), gsplit); each thread sums its slice of workgroups, then one fp64 global atomic.
@@ -1200,42 +577,27 @@ __global__ __launch_bounds__(1024) void predict_kernel(const double* __restrict_
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// Optional in-library timing of the dominant kernel: HIP events recorded on the launch stream right around
-// phi_accumulate_kernel (bench.py's roofline figure; must agree with the rocprofv3 kernel-trace average).
-constexpr int PROF_RING = 1024;
-static int g_phi_blocks = 0;   // 0 = PHI_MAX_BLOCKS; fewer leaves CUs free for a concurrent prior-chain kernel
-static int g_phi_ablate = 0;   // diagnostic only (ASVGP_PHI_ABLATE): 1 loads, 2 +cell, 3 +rank atomics, 4 +scan/scatter
-static int g_phi_algo = 0;  // 0 auto (= 3: 110 us at N=10M, vs 158 us for 1 and 166 us for 2), 1 = fp64 LDS atomics, 2 = moments, 3 = fixed-point band
-static bool g_prof_on = false;
-static int g_prof_every = 1;     // instrument every n-th Phi launch (events perturb the stream: keep them sparse)
-static long g_prof_calls = 0;
-static hipEvent_t g_prof_ev[PROF_RING][2];
-static bool g_prof_made = false;
-static long g_prof_n = 0;
-
 static int phi_max_cols(int K, long n_mesh, bool fx) {
   long avail = (long)PHI_LDS_BUDGET - (long)n_mesh * 8 - 16 * 8;
   if (avail <= 0) return 0;
   return (int)(avail / (8 * (K + 2 + (fx ? 1 : 0))));
 }
 
+// Band-scatter Phi pass (algorithms 1 and 3): the (k+1)(k+2)/2 + (k+1) products of every point go straight into the
+// workgroup's LDS band image.  Timing events (Handle::prof_*) are recorded on the launch stream right around the kernel.
 template <int K>
-static int launch_phi(const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
+static int launch_phi(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
   const int ncells = (int)n_mesh - 1;
-  const bool fx = (g_phi_algo == 3 || g_phi_algo == 0 || (g_phi_algo == 4 && bk_lds_bytes<K>() > PHI_LDS_BUDGET));
+  const bool fx = (h->phi_algo != 1);
   int maxc = phi_max_cols(K, n_mesh, fx);
   if (maxc < 2 * K + 2) {
     set_error("phi_accumulate_1d: mesh table (%ld knots) leaves no LDS for the band", n_mesh);
     return ASVGP_ERR_LDS_CAPACITY;
   }
   int cells_per_chunk = (M <= maxc) ? ncells : (maxc - K);
-  const bool v2 = (g_phi_algo == 2);
-  const bool v4 = (g_phi_algo == 4) && bk_lds_bytes<K>() <= PHI_LDS_BUDGET;   // (k = 6: the bucket buffers exceed the LDS -> algorithm 3)
-  constexpr int TP = 4;
-  if ((v2 || v4) && cells_per_chunk > MOM_CELLS) cells_per_chunk = MOM_CELLS;
   long nblk = (N + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS);
-  const long gmax = (g_phi_blocks > 0 && g_phi_blocks < PHI_MAX_BLOCKS) ? g_phi_blocks : PHI_MAX_BLOCKS;
+  const long gmax = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
   int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
   long ppb = (N + G - 1) / G;
   ppb = ((ppb + 2 * PHI_THREADS - 1) / (2 * PHI_THREADS)) * (2 * PHI_THREADS);
@@ -1256,46 +618,15 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
                      : (vec ? phi_accumulate_kernel<K, true, false> : phi_accumulate_kernel<K, false, false>);
       int s0 = 50;   // 62 - ceil(log2(points per workgroup)), at most 50 (magic-constant conversion range)
       { long c = 2; int lg = 1; while (c < ppb) { c <<= 1; ++lg; } if (62 - lg < s0) s0 = 62 - lg; }
-      if (v2) {
-        size_t sort_bytes = (size_t)TP * MOM_THREADS * 16 + (size_t)(2 * MOM_CELLS + 1 + 32) * 4 + 16 * 8 + 64;
-        size_t band_bytes = sizeof(double) * (size_t)(K + 2) * ncols;
-        lds_bytes = sort_bytes > band_bytes ? sort_bytes : band_bytes;
-        auto k2 = vec ? phi_moments_kernel<K, TP, true> : phi_moments_kernel<K, TP, false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-      }
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-      const bool prof = g_prof_on && g_prof_n < PROF_RING && (g_prof_calls++ % g_prof_every == 0);
-      if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
-      if (v4) {
-        auto k4 = vec ? phi_bucket_kernel<K, true> : phi_bucket_kernel<K, false>;
-        size_t band_bytes = sizeof(double) * (size_t)(K + 2) * ncols;
-        size_t l4 = bk_lds_bytes<K>() > band_bytes ? bk_lds_bytes<K>() : band_bytes;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", l4, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-        hipLaunchKernelGGL(k4, dim3(G), dim3(BK_THREADS), l4, st, x, yd, (long)D, N, mesh, (int)n_mesh, inv_delta,
-                           cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
-      } else if (v2) {
-        auto k2 = vec ? phi_moments_kernel<K, TP, true> : phi_moments_kernel<K, TP, false>;
-        if (K == 4 && vec && g_phi_ablate >= 1 && g_phi_ablate <= 9) {  // diagnostic builds (tools/phi_ablate.py)
-          if (g_phi_ablate == 1) k2 = phi_moments_kernel<4, TP, true, 1>;
-          if (g_phi_ablate == 2) k2 = phi_moments_kernel<4, TP, true, 2>;
-          if (g_phi_ablate == 3) k2 = phi_moments_kernel<4, TP, true, 3>;
-          if (g_phi_ablate == 4) k2 = phi_moments_kernel<4, TP, true, 4>;
-          if (g_phi_ablate == 5) k2 = phi_moments_kernel<4, TP, true, 5>;
-          if (g_phi_ablate == 9) k2 = phi_moments_kernel<4, TP, true, 9>;
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        }
-        hipLaunchKernelGGL(k2, dim3(G), dim3(MOM_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh, inv_delta,
-                           cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n);
-      } else {
-        hipLaunchKernelGGL(kern, dim3(G), dim3(PHI_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh,
-                           inv_delta, cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n, s0);
-      }
+      const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
+      if (prof) (void)hipEventRecord(h->prof_ev[h->prof_n][0], st);
+      hipLaunchKernelGGL(kern, dim3(G), dim3(PHI_THREADS), lds_bytes, st, x, yd, (long)D, N, mesh, (int)n_mesh,
+                         inv_delta, cell0, cell1, ncols, do_band, partials, ppb, zeroed ? (double*)nullptr : stats, zero_n, s0);
       zeroed = true;
-      if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
+      if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
       int E1 = (K + 2) * ncols + 1;
       int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
       hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, partials, G, ncols, K,
@@ -1309,56 +640,13 @@ static int launch_phi(const double* x, const double* y, long N, long D, const do
 
 using namespace asvgp;
 
-extern "C" int asvgp_set_phi_algorithm(int algo) {
-  if (algo < 0 || algo > 4) { set_error("set_phi_algorithm: 0 auto, 1 fp64 LDS-atomic scatter, 2 counting-sort + moments, 3 fixed-point band scatter, 4 per-cell buckets + moments"); return ASVGP_ERR_BAD_ARG; }
-  g_phi_algo = algo;
-  const char* ab = getenv("ASVGP_PHI_ABLATE");
-  g_phi_ablate = ab ? atoi(ab) : 0;
-  return ASVGP_OK;
-}
-
-extern "C" int asvgp_set_phi_workgroups(int n) {
-  if (n < 0 || n > PHI_MAX_BLOCKS) { set_error("set_phi_workgroups: 0 (default, one per CU) .. %d", PHI_MAX_BLOCKS); return ASVGP_ERR_BAD_ARG; }
-  g_phi_blocks = n;
-  return ASVGP_OK;
-}
-
-extern "C" int asvgp_profile_enable(int on) {
-  if (on && !g_prof_made) {
-    for (int i = 0; i < PROF_RING; ++i)
-      for (int j = 0; j < 2; ++j)
-        if (hipEventCreateWithFlags(&g_prof_ev[i][j], hipEventReleaseToDevice) != hipSuccess) { set_error("hipEventCreate failed"); return ASVGP_ERR_HIP; }
-    g_prof_made = true;
-  }
-  g_prof_on = on != 0;
-  g_prof_every = on > 1 ? on : 1;   // on = n > 1: every n-th launch
-  g_prof_calls = 0;
-  g_prof_n = 0;
-  return ASVGP_OK;
-}
-
-extern "C" int asvgp_profile_read(double* phi_kernel_ms_sum, int64_t* launches) {
-  if (!phi_kernel_ms_sum || !launches) { set_error("profile_read: bad argument"); return ASVGP_ERR_BAD_ARG; }
-  double tot = 0.0;
-  for (long i = 0; i < g_prof_n; ++i) {
-    if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return ASVGP_ERR_HIP; }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]);
-    tot += ms;
-  }
-  *phi_kernel_ms_sum = tot;
-  *launches = g_prof_n;
-  g_prof_n = 0;
-  return ASVGP_OK;
-}
-
 extern "C" size_t asvgp_phi_workspace_bytes(int64_t M, int order, int64_t D) {
   (void)D;
   if (M <= 0 || order < 1 || order > ASVGP_MAX_ORDER) return 0;
   return sizeof(double) * (size_t)PHI_MAX_BLOCKS * ((size_t)(order + 2) * (size_t)M + 1);
 }
 
-extern "C" int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t D, const double* mesh,
+extern "C" int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double* y, int64_t N, int64_t D, const double* mesh,
                                        int64_t n_mesh, double delta, int order, int64_t M, double* stats,
                                        void* workspace, size_t workspace_bytes, asvgp_stream_t stream) {
   if (((!x || !y) && N > 0) || !mesh || !stats || N < 0 || D < 1 || M < 1 || !(delta > 0.0)) {
@@ -1373,14 +661,15 @@ extern "C" int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t
     return ASVGP_ERR_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
+  Handle* h = as_handle(handle);
   double* part = static_cast<double*>(workspace);
   switch (order) {
-    case 1: return launch_phi<1>(x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
-    case 2: return launch_phi<2>(x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
-    case 3: return launch_phi<3>(x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
-    case 4: return launch_phi<4>(x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
-    case 5: return launch_phi<5>(x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
-    default: return launch_phi<6>(x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
+    case 1: return launch_phi<1>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
+    case 2: return launch_phi<2>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
+    case 3: return launch_phi<3>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
+    case 4: return launch_phi<4>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
+    case 5: return launch_phi<5>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
+    default: return launch_phi<6>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
   }
 }
 

@@ -1,0 +1,356 @@
+// Host half of the prior (Kuu) chain: the FORWARD pass of the block cyclic reduction of bcr.hpp, carried out once per
+// hyper-parameter value in long double on the O(log M) DISTINCT nodes of the elimination tree.
+//
+// Why on the host.  Kuu = sum_t c_t(theta) S_t (inducing_features.py:16-44) with static bands S_t that are Toeplitz away
+// from the two boundaries (basis.py:31-45 `_make_banded_matrix`: interior columns constant), so at every level of the
+// odd-even elimination all interior nodes are bit-identical: only the first / last one or two differ.  The whole forward
+// pass therefore needs ~5 node eliminations per level - a few ten thousand flops, microseconds of scalar work - instead of
+// M / k of them.  And it is the forward pass that decides the accuracy of band(Kuu^-1): measured at the BASELINE size
+// (M = 2048, cond(Kuu) = 3.5e7, tools/bcr_accuracy.py) fp64 cyclic reduction leaves tr(Kuu^-1 A) 26x further from an 80-bit
+// evaluation than the reference's sequential fp64 Cholesky + Takahashi (gpr.py:56-59); with the forward factors computed
+// to 64 mantissa bits and the backward (selected inverse) pass in fp64 on the GPU the result is as close as, or closer
+// than, the reference's own order in every configuration tried.  GPUs have no 80-bit type and double-double on one wave
+// would cost ~10x the level latency; the host's x87 unit does it in the time the Phi pass is in flight.
+//
+// The plan (symbolic part, once per basis) assigns every node of every level a class by exact comparison of its inputs;
+// the numeric part (once per theta) eliminates one representative per class.  A band without that structure (more than
+// MAX_CLASSES classes on some level) has no plan and the library falls back to the all-GPU chain.
+#include "prior_plan.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <array>
+#include <map>
+#include <vector>
+
+namespace asvgp {
+
+namespace {
+
+constexpr int MAXB = 6;            // ASVGP_MAX_ORDER
+constexpr int MAX_CLASSES = 24;    // per level
+
+typedef long double ld;
+struct Blk { ld v[MAXB][MAXB]; double d[MAXB][MAXB]; };   // value (long double) + tangent d / d lengthscale (double)
+
+struct Level {
+  std::vector<std::array<int, 3>> node_in;   // per node class: (D class of i, E class of (a, i), E class of (i, b) or -1)
+  std::vector<int> node_count;               // nodes in the class (log-determinant weights)
+  std::vector<int> node_rep;                 // a representative node (reports the failing column)
+  std::vector<std::array<int, 3>> d_next;    // per D class of the next level: (D class now, node class left or -1, right or -1)
+};
+
+}  // namespace
+
+struct PriorPlan {
+  int B = 0, n_terms = 0, nb = 0, levels = 0;
+  long M = 0;
+  std::vector<double> S;                     // host copy of the static bands (n_terms, B + 1, M)
+  std::vector<int> d0_rep, e0_rep;           // level-0 classes: representative block of D(n), of E(n) = A[n+1, n]
+  std::vector<Level> lv;
+  std::vector<int> lvl_off;                  // record offset of every level (+ the root record at the end)
+  std::vector<int> node_rec;                 // per block node: record index
+  int n_rec = 0;
+};
+
+// value of band entry (row, col), row >= col, of static term t; identity padding beyond M (as bcr.hpp band_D / band_E)
+static inline double sband(const PriorPlan& p, int t, long row, long col) {
+  return p.S[((size_t)t * (p.B + 1) + (size_t)(row - col)) * p.M + col];
+}
+
+static void block_key(const PriorPlan& p, int n, bool coupling, std::vector<double>& key) {
+  const int B = p.B;
+  key.clear();
+  for (int r = 0; r < B; ++r)
+    for (int c = 0; c < B; ++c) {
+      long row, col;
+      if (!coupling) { if (c > r) continue; row = (long)n * B + r; col = (long)n * B + c; }
+      else { if (r > c) continue; row = (long)(n + 1) * B + r; col = (long)n * B + c; }   // E(n)[r][c], band offset B + r - c <= B
+      const bool pad = row >= p.M || col >= p.M;
+      key.push_back(pad ? 1.0 : 0.0);
+      for (int t = 0; t < p.n_terms; ++t) key.push_back(pad ? 0.0 : sband(p, t, row, col));
+    }
+}
+
+PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, int k, char* err, size_t errlen) {
+  auto fail = [&](const char* msg) -> PriorPlan* { if (err && errlen) snprintf(err, errlen, "%s", msg); return nullptr; };
+  if (!statics_host || n_terms < 1 || n_terms > ASVGP_MAX_KUU_TERMS || M < 1 || k < 1 || k > MAXB) return fail("prior plan: bad argument");
+  PriorPlan* p = new PriorPlan;
+  p->B = k; p->n_terms = n_terms; p->M = M; p->nb = (int)((M + k - 1) / k);
+  p->S.assign(statics_host, statics_host + (size_t)n_terms * (k + 1) * M);
+  const int nb = p->nb;
+  while ((1 << p->levels) < nb) ++p->levels;
+  // ---- level-0 classes by exact comparison of the static blocks
+  std::vector<int> cur(nb), dcls(nb), ecls(nb > 1 ? nb - 1 : 0);
+  {
+    std::map<std::vector<double>, int> dm, em;
+    std::vector<double> key;
+    for (int n = 0; n < nb; ++n) {
+      cur[n] = n;
+      block_key(*p, n, false, key);
+      auto it = dm.find(key);
+      if (it == dm.end()) { it = dm.emplace(key, (int)dm.size()).first; p->d0_rep.push_back(n); }
+      dcls[n] = it->second;
+      if (n + 1 < nb) {
+        block_key(*p, n, true, key);
+        auto ie = em.find(key);
+        if (ie == em.end()) { ie = em.emplace(key, (int)em.size()).first; p->e0_rep.push_back(n); }
+        ecls[n] = ie->second;
+      }
+    }
+    if ((int)dm.size() > MAX_CLASSES || (int)em.size() > MAX_CLASSES) { delete p; return fail("prior plan: the static bands are not Toeplitz-structured"); }
+  }
+  p->node_rec.assign(nb, -1);
+  int rec = 0;
+  while (cur.size() > 1) {
+    Level L;
+    std::map<std::array<int, 3>, int> nm, dn;
+    const int n = (int)cur.size();
+    std::vector<int> ncls(n, -1);
+    for (int j = 1; j < n; j += 2) {
+      std::array<int, 3> key{dcls[j], ecls[j - 1], (j + 1 < n) ? ecls[j] : -1};
+      auto it = nm.find(key);
+      if (it == nm.end()) {
+        it = nm.emplace(key, (int)nm.size()).first;
+        L.node_in.push_back(key); L.node_count.push_back(0); L.node_rep.push_back(cur[j]);
+      }
+      ncls[j] = it->second;
+      L.node_count[it->second]++;
+      p->node_rec[cur[j]] = rec + it->second;
+    }
+    std::vector<int> ncur, ndcls, necls;
+    for (int j = 0; j < n; j += 2) {
+      std::array<int, 3> key{dcls[j], (j >= 1) ? ncls[j - 1] : -1, (j + 1 < n) ? ncls[j + 1] : -1};
+      auto it = dn.find(key);
+      if (it == dn.end()) { it = dn.emplace(key, (int)dn.size()).first; L.d_next.push_back(key); }
+      ncur.push_back(cur[j]);
+      ndcls.push_back(it->second);
+      if (j + 2 < n) necls.push_back(ncls[j + 1]);   // coupling of the survivors (cur[j], cur[j+2]) = fill of the node between
+    }
+    if ((int)nm.size() > MAX_CLASSES || (int)dn.size() > MAX_CLASSES) { delete p; return fail("prior plan: too many distinct nodes on a level"); }
+    p->lvl_off.push_back(rec);
+    rec += (int)nm.size();
+    p->lv.push_back(std::move(L));
+    cur.swap(ncur); dcls.swap(ndcls); ecls.swap(necls);
+  }
+  p->lvl_off.push_back(rec);      // the root record
+  p->node_rec[0] = rec;
+  p->n_rec = rec + 1;
+  if ((int)p->lv.size() != p->levels) { delete p; return fail("prior plan: level count mismatch"); }
+  return p;
+}
+
+void prior_plan_destroy(PriorPlan* p) { delete p; }
+int prior_plan_nrec(const PriorPlan* p) { return p->n_rec; }
+int prior_plan_nb(const PriorPlan* p) { return p->nb; }
+long prior_plan_M(const PriorPlan* p) { return p->M; }
+int prior_plan_k(const PriorPlan* p) { return p->B; }
+int prior_plan_terms(const PriorPlan* p) { return p->n_terms; }
+const int* prior_plan_node_rec(const PriorPlan* p) { return p->node_rec.data(); }
+size_t prior_plan_table_doubles(const PriorPlan* p) {
+  return PRIOR_TAB_HEADER + (size_t)2 * p->n_rec * prior_rec_fields(p->B);
+}
+
+// Kuu / dKuu entry in fp64 with the reference's rounding sequence (inducing_features.py:16-44; the same sequence as
+// kuu_assemble_kernel / elbo_prepare_kernel: products and sums rounded one by one, no contraction - this file is built
+// with -ffp-contract=off), so the blocks factorised here are bit-identical to the device's Kuu band.
+static inline void kuu_entry(const PriorPlan& p, const double* c, const double* dc, long row, long col, double& kv, double& dv) {
+  double acc = c[0] * sband(p, 0, row, col);
+  double dacc = dc[0] * sband(p, 0, row, col);
+  for (int t = 1; t < p.n_terms; ++t) {
+    const double s = sband(p, t, row, col);
+    const double a = c[t] * s, b = dc[t] * s;
+    acc = acc + a;
+    dacc = dacc + b;
+  }
+  kv = acc; dv = dacc;
+}
+
+int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef, double* tab) {
+  // Values in long double; tangents (d / d lengthscale: the gradient is gated at 1e-6) in double from the rounded values -
+  // two separate recurrences, so the x87 unit carries a third of the flops of a (long double, long double) dual number.
+  const PriorPlan& p = *pp;
+  const int B = p.B, W = prior_rec_fields(B), R = p.n_rec;
+  double* val = tab + PRIOR_TAB_HEADER;
+  double* tan = val + (size_t)R * W;
+  memset(tab, 0, sizeof(double) * PRIOR_TAB_HEADER);
+  // (fixed-size scratch: no heap traffic on the per-step path)
+  Blk bufD[2][MAX_CLASSES], bufE[2][MAX_CLASSES], updA[MAX_CLASSES], updB[MAX_CLASSES];
+  Blk* Dv = bufD[0]; Blk* Dn = bufD[1]; Blk* Ev = bufE[0]; Blk* Enew = bufE[1];
+  // ---- level-0 blocks of the representatives
+  for (size_t q = 0; q < p.d0_rep.size(); ++q) {
+    const int n = p.d0_rep[q];
+    for (int r = 0; r < B; ++r)
+      for (int c = 0; c <= r; ++c) {
+        const long row = (long)n * B + r, col = (long)n * B + c;
+        double kv = (r == c) ? 1.0 : 0.0, dv = 0.0;                // identity padding
+        if (row < p.M) kuu_entry(p, coef, dcoef, row, col, kv, dv);
+        Dv[q].v[r][c] = Dv[q].v[c][r] = kv;
+        Dv[q].d[r][c] = Dv[q].d[c][r] = dv;
+      }
+  }
+  for (size_t q = 0; q < p.e0_rep.size(); ++q) {
+    const int n = p.e0_rep[q];
+    for (int r = 0; r < B; ++r)
+      for (int c = 0; c < B; ++c) {
+        const long row = (long)(n + 1) * B + r, col = (long)n * B + c;
+        double kv = 0.0, dv = 0.0;
+        if (r <= c && row < p.M) kuu_entry(p, coef, dcoef, row, col, kv, dv);
+        Ev[q].v[r][c] = kv; Ev[q].d[r][c] = dv;
+      }
+  }
+  ld logdet = 0.0L;
+  double dlogdet = 0.0;
+  int bad = 0;
+  // Cholesky in place (lower part of D becomes L), inv = 1 / diag(L); then the tangent recurrence on the rounded factor
+  auto chol = [&](Blk& D, ld (&inv)[MAXB], double (&Ld)[MAXB][MAXB], double (&invd)[MAXB], double (&dinv)[MAXB], int col0) {
+    for (int j = 0; j < B; ++j) {
+      ld s = D.v[j][j];
+      for (int q = 0; q < j; ++q) s -= D.v[j][q] * D.v[j][q];
+      if (!(s > 0.0L) && !bad) bad = col0 + j + 1;
+      const ld l = sqrtl(s > 0.0L ? s : 1.0L);
+      D.v[j][j] = l;
+      inv[j] = 1.0L / l;
+      for (int i = j + 1; i < B; ++i) {
+        ld t = D.v[i][j];
+        for (int q = 0; q < j; ++q) t -= D.v[i][q] * D.v[j][q];
+        D.v[i][j] = t * inv[j];
+      }
+    }
+    for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { if (c > r) D.v[r][c] = 0.0L; Ld[r][c] = (double)D.v[r][c]; }
+    for (int j = 0; j < B; ++j) {
+      invd[j] = (double)inv[j];
+      double ds = D.d[j][j];
+      for (int q = 0; q < j; ++q) ds -= 2.0 * D.d[j][q] * Ld[j][q];
+      const double dl = 0.5 * ds * invd[j];
+      D.d[j][j] = dl;
+      dinv[j] = -dl * invd[j] * invd[j];
+      for (int i = j + 1; i < B; ++i) {
+        double dt = D.d[i][j];
+        for (int q = 0; q < j; ++q) dt -= D.d[i][q] * Ld[j][q] + Ld[i][q] * D.d[j][q];
+        D.d[i][j] = (dt - Ld[i][j] * dl) * invd[j];
+      }
+    }
+    for (int r = 0; r < B; ++r) for (int c = r + 1; c < B; ++c) D.d[r][c] = 0.0;
+  };
+  // X <- L^-1 X with its tangent
+  auto solveL = [&](const Blk& L, const ld (&inv)[MAXB], const double (&Ld)[MAXB][MAXB], const double (&invd)[MAXB], Blk& X) {
+    double Xd[MAXB][MAXB];
+    for (int c = 0; c < B; ++c)
+      for (int i = 0; i < B; ++i) {
+        ld t = X.v[i][c];
+        for (int q = 0; q < i; ++q) t -= L.v[i][q] * X.v[q][c];
+        X.v[i][c] = t * inv[i];
+        Xd[i][c] = (double)X.v[i][c];
+      }
+    for (int c = 0; c < B; ++c)
+      for (int i = 0; i < B; ++i) {
+        double dt = X.d[i][c];
+        for (int q = 0; q < i; ++q) dt -= L.d[i][q] * Xd[q][c] + Ld[i][q] * X.d[q][c];
+        X.d[i][c] = (dt - L.d[i][i] * Xd[i][c]) * invd[i];
+      }
+  };
+  auto put = [&](int rec, int f, ld x, double dx) { val[(size_t)rec * W + f] = (double)x; tan[(size_t)rec * W + f] = dx; };
+  ld inv[MAXB];
+  double Ld[MAXB][MAXB], invd[MAXB], dinv[MAXB];
+  for (int l = 0; l < p.levels; ++l) {
+    const Level& L = p.lv[l];
+    const int nq = (int)L.node_in.size();
+    for (int q = 0; q < nq; ++q) {
+      const auto& in = L.node_in[q];
+      Blk D = Dv[in[0]];
+      Blk Ua = Ev[in[1]];                                      // A[i, a] = E(a)
+      Blk Ub;                                                  // A[i, b] = E(i)^T
+      const bool hasb = in[2] >= 0;
+      for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { Ub.v[r][c] = hasb ? Ev[in[2]].v[c][r] : 0.0L; Ub.d[r][c] = hasb ? Ev[in[2]].d[c][r] : 0.0; }
+      chol(D, inv, Ld, invd, dinv, L.node_rep[q] * B);
+      solveL(D, inv, Ld, invd, Ua);
+      if (hasb) solveL(D, inv, Ld, invd, Ub);
+      const int rec = p.lvl_off[l] + q;
+      double ua[MAXB][MAXB], ub[MAXB][MAXB], prod = 1.0;
+      for (int r = 0; r < B; ++r) {
+        put(rec, prior_f_I(B) + r, inv[r], dinv[r]);
+        prod *= Ld[r][r];                                      // (B <= 6 factors between ~1e-4 and ~1e4: no range problem)
+        dlogdet += (double)L.node_count[q] * 2.0 * D.d[r][r] * invd[r];
+        for (int c = 0; c < B; ++c) {
+          put(rec, prior_f_L(B) + r * B + c, D.v[r][c], D.d[r][c]);
+          put(rec, prior_f_UA(B) + r * B + c, Ua.v[r][c], Ua.d[r][c]);
+          put(rec, prior_f_UB(B) + r * B + c, Ub.v[r][c], Ub.d[r][c]);
+          ua[r][c] = (double)Ua.v[r][c]; ub[r][c] = (double)Ub.v[r][c];
+        }
+      }
+      // log L_jj in double: |log| ~ 10 at 1e-16 relative, times the class count - far below the 1e-9 |ELBO| gate of the bound
+      logdet += (ld)L.node_count[q] * 2.0L * (ld)log(prod);
+      for (int r = 0; r < B; ++r)
+        for (int c = 0; c < B; ++c) {
+          ld a = 0.0L, b = 0.0L, e = 0.0L;
+          double da = 0.0, db = 0.0, de = 0.0;
+          for (int q2 = 0; q2 < B; ++q2) {
+            a += Ua.v[q2][r] * Ua.v[q2][c];
+            da += Ua.d[q2][r] * ua[q2][c] + ua[q2][r] * Ua.d[q2][c];
+            if (hasb) {
+              b += Ub.v[q2][r] * Ub.v[q2][c];
+              e -= Ub.v[q2][r] * Ua.v[q2][c];                  // A'[b, a] = -Ub^T Ua
+              db += Ub.d[q2][r] * ub[q2][c] + ub[q2][r] * Ub.d[q2][c];
+              de -= Ub.d[q2][r] * ua[q2][c] + ub[q2][r] * Ua.d[q2][c];
+            }
+          }
+          updA[q].v[r][c] = a; updB[q].v[r][c] = b; Enew[q].v[r][c] = e;
+          updA[q].d[r][c] = da; updB[q].d[r][c] = db; Enew[q].d[r][c] = de;
+        }
+    }
+    for (size_t q = 0; q < L.d_next.size(); ++q) {
+      const auto& in = L.d_next[q];
+      Blk D = Dv[in[0]];
+      for (int r = 0; r < B; ++r)
+        for (int c = 0; c < B; ++c) {
+          if (in[1] >= 0) { D.v[r][c] -= updB[in[1]].v[r][c]; D.d[r][c] -= updB[in[1]].d[r][c]; }   // it was the right neighbour b of the node on its left
+          if (in[2] >= 0) { D.v[r][c] -= updA[in[2]].v[r][c]; D.d[r][c] -= updA[in[2]].d[r][c]; }   // ... and the left neighbour a of the node on its right
+        }
+      Dn[q] = D;
+    }
+    { Blk* t = Dv; Dv = Dn; Dn = t; t = Ev; Ev = Enew; Enew = t; }
+  }
+  // ---- root: L_0, Sigma_00 = D_0^-1
+  {
+    Blk D = Dv[0];
+    chol(D, inv, Ld, invd, dinv, 0);
+    Blk X;
+    for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { X.v[r][c] = (r == c) ? 1.0L : 0.0L; X.d[r][c] = 0.0; }
+    solveL(D, inv, Ld, invd, X);
+    double Xd[MAXB][MAXB];
+    for (int c = 0; c < B; ++c)                                // X <- L^-T X
+      for (int i = B - 1; i >= 0; --i) {
+        ld t = X.v[i][c];
+        for (int q = i + 1; q < B; ++q) t -= D.v[q][i] * X.v[q][c];
+        X.v[i][c] = t * inv[i];
+        Xd[i][c] = (double)X.v[i][c];
+      }
+    for (int c = 0; c < B; ++c)
+      for (int i = B - 1; i >= 0; --i) {
+        double dt = X.d[i][c];
+        for (int q = i + 1; q < B; ++q) dt -= D.d[q][i] * Xd[q][c] + Ld[q][i] * X.d[q][c];
+        X.d[i][c] = (dt - D.d[i][i] * Xd[i][c]) * invd[i];
+      }
+    const int rec = p.n_rec - 1;
+    double prod = 1.0;
+    for (int r = 0; r < B; ++r) {
+      put(rec, prior_f_I(B) + r, inv[r], dinv[r]);
+      prod *= Ld[r][r];
+      dlogdet += 2.0 * D.d[r][r] * invd[r];
+      for (int c = 0; c < B; ++c) {
+        put(rec, prior_f_L(B) + r * B + c, D.v[r][c], D.d[r][c]);
+        put(rec, prior_f_UA(B) + r * B + c, X.v[r][c], X.d[r][c]);   // root: the U_a slot carries Sigma_00
+        put(rec, prior_f_UB(B) + r * B + c, 0.0L, 0.0);
+      }
+    }
+    logdet += 2.0L * (ld)log(prod);
+  }
+  // padding rows contribute log(1) = 0; header: [logdet, dlogdet/dl, first failing column + 1, n_rec]
+  tab[0] = (double)logdet; tab[1] = dlogdet; tab[2] = (double)bad; tab[3] = (double)R;
+  return bad;
+}
+
+}  // namespace asvgp

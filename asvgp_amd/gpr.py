@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 from . import kernels, utils
 from . import kernels as kernels_mod
-from ._lib import AsvgpError, check, f64c, get_lib, require_cuda, stream_ptr
+from ._lib import AsvgpError, Handle, check, f64c, get_lib, require_cuda, stream_ptr
 from .banded import NotPositiveDefiniteError
 from .dist import allreduce_stats
 from .inducing_features import SplineFeatures1D
@@ -104,6 +104,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         k, M, D = self.bandwidth, basis.m, self.D
         # Precompute static quantities (gpr.py:39-44): one fused Phi pass
         lib = get_lib()
+        self._h = Handle()                    # library state of THIS model (asvgp_create)
+        self._planned_kind = None
         self._stats = torch.empty((k + 1) * M + M * D + 1, dtype=torch.float64, device=dev)
         wsb = lib.asvgp_phi_workspace_bytes(M, k, D)
         self._phi_ws = torch.empty(wsb // 8, dtype=torch.float64, device=dev)
@@ -124,7 +126,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
     def _phi_pass_local(self):
         """asvgp_phi_accumulate_1d over this rank's rows -> packed [band | Phi y | y^T y] (local sums)."""
         b = self.basis
-        check(get_lib().asvgp_phi_accumulate_1d(self.X.data_ptr(), self.y.data_ptr(), self.X.shape[0], self.D,
+        check(get_lib().asvgp_phi_accumulate_1d(self._h.ptr, self.X.data_ptr(), self.y.data_ptr(), self.X.shape[0], self.D,
                                                 b.mesh.data_ptr(), b.mesh.shape[0], b.delta_np, b.order, b.m,
                                                 self._stats.data_ptr(), self._phi_ws.data_ptr(), self._wsb,
                                                 stream_ptr()), "phi_accumulate_1d")
@@ -140,11 +142,21 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
     def theta(self):
         return float(self.kernel.variance), float(self.kernel.lengthscales), float(self.likelihood.variance)
 
+    def _statics(self):
+        """Device stack of the static bands of this kernel; on first use (and when the kernel kind changes) the handle plans
+        the prior chain from a host copy (asvgp_prior_plan_1d)."""
+        kind = self.kernel.kind
+        S = self.inducing_features.static_stack(kind)
+        if self._planned_kind != kind:
+            self._h.prior_plan(np.ascontiguousarray(S.cpu().numpy()), S.shape[0], self.basis.m, self.bandwidth)
+            self._planned_kind = kind
+        return S
+
     def _launch_elbo(self):
         v, l, s = self.theta()
         b = self.basis
-        S = self.inducing_features.static_stack(self.kernel.kind)
-        check(get_lib().asvgp_elbo_grad_1d(self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s,
+        S = self._statics()
+        check(get_lib().asvgp_elbo_grad_1d(self._h.ptr, self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s,
                                            self.num_data, b.m, self.bandwidth, self.D, self._out.data_ptr(),
                                            self._info.data_ptr(), self._elbo_ws.data_ptr(),
                                            self._elbo_ws.numel() * 8, stream_ptr()), "elbo_grad_1d")
@@ -155,8 +167,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         """Enqueue the theta-only half (Kuu, its l-tangent, band(Kuu^-1), log|Kuu|) on the CURRENT stream.  It does not
         read the statistics, so it may run on a side stream while the Phi pass / all-reduce are in flight."""
         v, l, s = self.theta()
-        S = self.inducing_features.static_stack(self.kernel.kind)
-        check(get_lib().asvgp_elbo_prior_chain_1d(S.data_ptr(), self.kernel.kind, v, l, s, self.basis.m, self.bandwidth,
+        S = self._statics()
+        check(get_lib().asvgp_elbo_prior_chain_1d(self._h.ptr, S.data_ptr(), self.kernel.kind, v, l, s, self.basis.m, self.bandwidth,
                                                   self.D, self._info.data_ptr(), self._elbo_ws.data_ptr(),
                                                   self._elbo_ws.numel() * 8, stream_ptr()), "elbo_prior_chain_1d")
 
@@ -164,8 +176,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         """Enqueue the data half (P chain + finalize) on the current stream; it must be ordered after launch_prior_chain
         for the same theta (same stream, or current_stream().wait_event(...))."""
         v, l, s = self.theta()
-        S = self.inducing_features.static_stack(self.kernel.kind)
-        check(get_lib().asvgp_elbo_data_chain_1d(self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s,
+        S = self._statics()
+        check(get_lib().asvgp_elbo_data_chain_1d(self._h.ptr, self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s,
                                                  self.num_data, self.basis.m, self.bandwidth, self.D, self._out.data_ptr(),
                                                  self._info.data_ptr(), self._elbo_ws.data_ptr(),
                                                  self._elbo_ws.numel() * 8, stream_ptr()), "elbo_data_chain_1d")
@@ -234,8 +246,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         k, M, D = self.bandwidth, b.m, self.D
         alpha = torch.empty((M, D), dtype=torch.float64, device=self._stats.device)
         W = torch.empty((k + 1, M), dtype=torch.float64, device=self._stats.device)
-        S = self.inducing_features.static_stack(self.kernel.kind)
-        check(get_lib().asvgp_posterior_prepare_1d(self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s, M, k,
+        S = self._statics()
+        check(get_lib().asvgp_posterior_prepare_1d(self._h.ptr, self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s, M, k,
                                                    D, alpha.data_ptr(), W.data_ptr(), self._info.data_ptr(),
                                                    self._elbo_ws.data_ptr(), self._elbo_ws.numel() * 8, stream_ptr()),
               "posterior_prepare_1d")
@@ -611,6 +623,7 @@ class GPR_additive(_GPModelSurface, _ShardedStats):
                   [lib.asvgp_phi_cross_workspace_bytes(ms[i], ms[j]) for (i, j) in self._cross_off] + [8])
         self._ws = torch.empty(wsb // 8 + 1, dtype=torch.float64, device=dev)
         self._wsb = wsb
+        self._h = Handle()
         self._setup_dist(process_group, distributed)
         self._phi_pass_local()
         self.num_data = allreduce_stats(self._stats, self.n, process_group) if self._distributed else self.n
@@ -623,7 +636,7 @@ class GPR_additive(_GPModelSurface, _ShardedStats):
         lib, k = get_lib(), self.bandwidth
         for i, bs in enumerate(self.bases):
             out = self._stats[self._diag_off[i]:]
-            check(lib.asvgp_phi_accumulate_1d(self._cols[i].data_ptr(), self.y.data_ptr(), self.n, 1, bs.mesh.data_ptr(),
+            check(lib.asvgp_phi_accumulate_1d(self._h.ptr, self._cols[i].data_ptr(), self.y.data_ptr(), self.n, 1, bs.mesh.data_ptr(),
                                               bs.mesh.shape[0], bs.delta_np, k, bs.m, out.data_ptr(), self._ws.data_ptr(),
                                               self._wsb, stream_ptr()), "phi_accumulate_1d")
         for (i, j), o in self._cross_off.items():

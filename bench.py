@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="points of the workload the CPU oracle is timed on (a prefix; "
                     "parity is reported when it covers the whole workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3), help="0 auto (planned prior chain), 1 sequential sweeps, "
+                    "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
     ap.add_argument("--kernel-events", type=int, default=10, help="HIP events around every n-th Phi kernel launch")
     ap.add_argument("--phase-events", type=int, default=25, help="record per-phase events on every n-th step (0 = never)")
@@ -146,9 +148,6 @@ def main():
     from asvgp_amd import _lib
     from asvgp_amd.dist import shard_bounds
     lib = _lib.get_lib()
-    lib.asvgp_elbo_chain_sync(1)        # prior chain / data chain ordered by library-internal events
-    lib.asvgp_set_phi_workgroups(248)   # 31 of 32 CUs per XCD: workgroups are dealt per XCD, so the concurrently
-                                        # running prior chain (second stream) finds a free CU wherever it lands
 
     N, M = args.points, args.features
     theta = (1.0, 0.05, 0.01)
@@ -165,6 +164,13 @@ def main():
     model.likelihood.variance.assign(theta[2])
     model.num_data = N
     stats = model._stats
+    hdl = model._h
+    two_stream = (args.band_algo == 2)   # the all-GPU chains of round 1: prior chain on a second stream under the Phi pass
+    if args.band_algo:
+        hdl.set_band_algorithm(args.band_algo)
+    if two_stream:
+        hdl.chain_sync(1)               # prior chain / data chain ordered by the handle's own events
+        hdl.set_phi_workgroups(248)     # 31 of 32 CUs per XCD, so the concurrently running prior chain finds a free CU
 
     ev = lambda: torch.cuda.Event(enable_timing=True)   # (timing events cost ~25 us of stream time each here: sampled)
     marks = []
@@ -177,9 +183,10 @@ def main():
         if record:
             e0, e1, e2, e3 = ev(), ev(), ev(), ev()
             e0.record()
-        side.wait_stream(main)          # previous step's finalize has consumed the prior-chain buffers
-        with torch.cuda.stream(side):
-            model.launch_prior_chain()
+        if two_stream:
+            side.wait_stream(main)      # previous step's finalize has consumed the prior-chain buffers
+            with torch.cuda.stream(side):
+                model.launch_prior_chain()
         model.phi_pass()
         if record:
             e1.record()
@@ -187,7 +194,11 @@ def main():
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         if record:
             e2.record()
-        model.launch_data_chain()       # waits (inside the library) for Kuu, then for the prior chain before the finalize
+        if two_stream:
+            model.launch_data_chain()   # waits (inside the library) for Kuu, then for the prior chain before the finalize
+        else:
+            model._launch_elbo()        # planned prior chain: host forward pass (long double) while the Phi pass is in flight,
+                                        # then ONE launch for the P chain and the Kuu backward pass, then the finalize
         if record:
             e3.record()
             marks.append((e0, e1, e2, e3))
@@ -199,7 +210,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     if not os.environ.get("ASVGP_BENCH_NOPROF"):
-        lib.asvgp_profile_enable(args.kernel_events)   # HIP events around every n-th Phi kernel launch of the timed region
+        lib.asvgp_profile_enable(hdl.ptr, args.kernel_events)   # HIP events around every n-th Phi kernel launch of the timed region
     t0 = time.perf_counter()
     for it in range(args.steps):
         step(record=(args.phase_events > 0 and it % args.phase_events == 0))
@@ -211,8 +222,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_sum, launches = ctypes.c_double(0), ctypes.c_int64(0)
-    lib.asvgp_profile_read(ctypes.byref(ms_sum), ctypes.byref(launches))
-    lib.asvgp_profile_enable(0)
+    lib.asvgp_profile_read(hdl.ptr, ctypes.byref(ms_sum), ctypes.byref(launches))
+    lib.asvgp_profile_enable(hdl.ptr, 0)
     model._check_pd()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -239,6 +250,11 @@ def main():
             model.likelihood.variance.assign(theta[2])
             model.num_data = N * world
             stats = model._stats
+            if args.band_algo:
+                model._h.set_band_algorithm(args.band_algo)
+            if two_stream:
+                model._h.chain_sync(1)
+                model._h.set_phi_workgroups(248)
             marks.clear()
             for _ in range(args.warmup):
                 step()
@@ -279,7 +295,8 @@ def main():
                        "parallelism": "dp%d (contiguous N-shards, one all-reduce of the %d-double band buffer)" % (world, stats.numel()),
                        "points_per_rank": n_local},
             "phases_us": {"phi_pass": t_phi, "band_allreduce": t_comm, "data_chain_after_stats": t_band,
-                          "note": "the theta-only prior chain (Kuu, tangent) runs on a second stream under the Phi pass"},
+                          "note": "planned prior chain: host forward pass under the Phi pass, Kuu backward pass beside the P chain"
+                                  if not two_stream else "the theta-only prior chain (Kuu, tangent) runs on a second stream under the Phi pass"},
             "phi_pass_mpoints_per_s": n_local * world / (t_phi * 1e-6) / 1e6 if t_phi > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "phi_accumulate_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),

@@ -7,7 +7,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in `_host`; the caller owns every buffer
- *     (e.g. torch tensors' data_ptr()); the library allocates nothing.
+ *     (e.g. torch tensors' data_ptr()); the library allocates nothing outside an asvgp_handle_t (asvgp_create / _destroy).
+ *   - state lives in the handle: algorithm choices, the Phi-pass workgroup count, chain-ordering events, the kernel-timing
+ *     ring and the prior-chain plan.  Entry points that take a handle are re-entrant ACROSS handles (one handle per model /
+ *     stream / host thread); a NULL handle means the process-wide default handle (single-threaded convenience).
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and is
  *     asynchronous; no entry point synchronises the device.
  *   - return value: ASVGP_OK or a negative asvgp_status; asvgp_last_error_string() describes the last failure
@@ -29,6 +32,7 @@ extern "C" {
 #endif
 
 typedef void* asvgp_stream_t; /* hipStream_t */
+typedef struct asvgp_handle_s* asvgp_handle_t;
 
 typedef enum {
   ASVGP_OK = 0,
@@ -46,6 +50,11 @@ int asvgp_version(void);
 const char* asvgp_last_error_string(void);
 const char* asvgp_status_name(int status);
 
+/* Handle: bound to the HIP device current at creation.  asvgp_destroy releases the handle's events, its pinned factor-table
+ * ring and device tables (the caller makes sure no work of the handle is still in flight). */
+int asvgp_create(asvgp_handle_t* handle_out);
+int asvgp_destroy(asvgp_handle_t handle);
+
 /* ------------------------------------------------------------------------------------------------
  * Phi pass: B-spline design matrix + sufficient statistics, fused
  * replaces  basis.py:51-76 (SplineBasis.evaluate_basis -> CSR Phi), inducing_features.py:47-48 (make_Kuf),
@@ -56,21 +65,18 @@ const char* asvgp_status_name(int status);
  * This packed buffer is what one RCCL all-reduce(sum) combines across N-shards.
  * ---------------------------------------------------------------------------------------------- */
 size_t asvgp_phi_workspace_bytes(int64_t M, int order, int64_t D);
-int asvgp_phi_accumulate_1d(const double* x, const double* y, int64_t N, int64_t D,
+int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double* y, int64_t N, int64_t D,
                             const double* mesh, int64_t n_mesh, double delta, int order, int64_t M,
                             double* stats, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
-/* Phi-pass algorithm: 0 = auto (= 3), 1 = per-point LDS fp64 atomic scatter into the band, 2 = tile-local counting sort
- * + per-cell moment accumulation in registers (3k+2 sums per point, converted to band entries once per workgroup),
- * 3 = as 1 with the Phi Phi^T products accumulated as 64-bit fixed-point integers (ds_add_u64 runs at twice the
- * ds_add_f64 rate; per-diagonal power-of-two scales, error per addend <= 2^-43 of the diagonal's largest product,
- * order-independent sums), 4 = per-cell point lists (one returning u32 LDS atomic per point, 6 slots per cell, overflow
- * list) + per-cell moments in registers, one barrier per 2048-point tile (VALU-bound where 3 is LDS-bound; same speed
- * at M = 2048).  Same statistics to <= 1e-12 of the band's largest entry.  Process-wide, host-side. */
-int asvgp_set_phi_algorithm(int algo);
+/* Phi-pass algorithm of the handle: 0 = auto (= 3), 1 = per-point LDS fp64 atomic scatter into the band, 3 = as 1 with the
+ * Phi Phi^T products accumulated as 64-bit fixed-point integers (ds_add_u64 runs at twice the ds_add_f64 rate; per-diagonal
+ * power-of-two scales, error per addend <= 2^-43 of the diagonal's largest product, order-independent sums).  Same statistics
+ * to <= 1e-12 of the band's largest entry. */
+int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
 /* workgroups of the Phi-pass kernel: 0 = default (256, one per CU); a smaller number leaves CUs free so that a
  * concurrently enqueued asvgp_elbo_prior_chain_1d (second stream) is resident at the same time. */
-int asvgp_set_phi_workgroups(int n);
+int asvgp_set_phi_workgroups(asvgp_handle_t handle, int n);
 
 /* basis.py:58-59  neighbour_index = relu(searchsorted_left(mesh, x) - 1)  (integer work, bit-exact) */
 int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,
@@ -129,13 +135,28 @@ int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, dou
  * ---------------------------------------------------------------------------------------------- */
 size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D);   /* the workspace must be zero-filled ONCE by the caller
                                                                      (cross-workgroup arrival slots are re-armed by every call) */
-/* band algorithm of the two fused drivers below: 0 = auto (block cyclic reduction, O(log M) dependent levels, when both
- * chains fit the 160 KiB LDS and D == 1; otherwise the sequential single-wave sweeps), 1 = sequential sweeps,
- * 2 = block cyclic reduction, hybrid (one thread per k x k node on wide levels, one lane per block entry on narrow
- * levels; the auto choice); 3 = block cyclic reduction, lane-distributed on every level; 2/3 return
- * ASVGP_ERR_LDS_CAPACITY when the chains do not fit.  Process-wide, host-side. */
-int asvgp_set_band_algorithm(int algo);
-int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind, double variance,
+/* band algorithm of the fused drivers below: 0 = auto, 1 = sequential single-wave sweeps (the reference's elimination order),
+ * 2 = block cyclic reduction (O(log M) dependent levels), both chains on the GPU, 3 = block cyclic reduction with the PLANNED
+ * prior chain (asvgp_prior_plan_1d): forward pass of the Kuu chain on the host in long double over the O(log M) distinct
+ * nodes, backward (selected inverse) pass on the GPU.  Auto = 3 when the handle holds a matching plan, else 2 when both chains
+ * fit the 160 KiB LDS and D == 1, else 1.  2 / 3 return ASVGP_ERR_LDS_CAPACITY when the chains do not fit. */
+int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo);
+/* Plan of the prior chain for one (basis, kernel kind).  static_bands_host: HOST copy of the (n_terms, k+1, M) array the ELBO
+ * entry points receive on the device (inducing_features.py:16-44 order).  Kuu = sum_t c_t(theta) S_t is Toeplitz away from the
+ * boundaries (basis.py:31-45), so every level of the odd-even elimination has only a handful of DISTINCT nodes; the plan
+ * classifies them once, and each later ELBO call eliminates one representative per class on the host in long double
+ * (~20 us at M = 2048) - the forward pass is where fp64 cyclic reduction loses up to three digits against the reference's
+ * sequential Cholesky (gpr.py:56-59) when cond(Kuu) is large.  *planned = 0 (and ASVGP_OK) when the bands have no such
+ * structure; static_bands_host = NULL drops the plan.  The handle owns the plan, a device node->record map and a pinned
+ * factor-table ring. */
+int asvgp_prior_plan_1d(asvgp_handle_t handle, const double* static_bands_host, int n_terms, int64_t M, int k, int* planned);
+/* The planner alone, host memory only (no device): factor table for one theta - header [log|Kuu|, d log|Kuu|/dl, first failing
+ * column + 1, n_rec], then the value plane and the tangent plane of n_rec records [L (k x k) | 1/diag L (k) | U_a | U_b] - and
+ * the node -> record map of the ceil(M / k) block nodes.  coef / dcoef_dl as filled by asvgp_matern_coeffs. */
+size_t asvgp_prior_table_doubles(const double* static_bands_host, int n_terms, int64_t M, int k);
+int asvgp_prior_forward_host(const double* static_bands_host, int n_terms, int64_t M, int k, const double* coef_host,
+                             const double* dcoef_dl_host, double* table_host, size_t table_doubles, int* node_rec_host);
+int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                        double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
@@ -143,15 +164,16 @@ int asvgp_elbo_grad_1d(const double* stats, const double* static_bands, int kind
  * tangent, log|Kuu|) and may be enqueued on another stream concurrently with the Phi pass; the DATA chain
  * (P = Kuu + A/s factor/solve/inverse + the finalize) needs `stats` and must be ordered after the prior chain of the same
  * theta and workspace (stream order or an event).  elbo_prior_chain + elbo_data_chain == elbo_grad_1d. */
-/* asvgp_elbo_chain_sync(1): the library orders the two calls itself with internal events - the prior chain records
+/* asvgp_elbo_chain_sync(h, 1): the handle orders the two calls itself with its own events - the prior chain records
  * "Kuu assembled" and "prior chain complete" on its stream, the data chain waits for the first before factorising P and
  * for the second before the finalize - so the caller needs no event of its own and the P chain overlaps the rest of the
- * prior chain.  One prior/data pair in flight per process (the events are process-wide). */
-int asvgp_elbo_chain_sync(int enable);
-int asvgp_elbo_prior_chain_1d(const double* static_bands, int kind, double variance, double lengthscale,
+ * prior chain.  One prior/data pair in flight per handle.  With the planned prior chain (band algorithm 3) the prior call
+ * is a no-op and the data call runs both chains in one launch. */
+int asvgp_elbo_chain_sync(asvgp_handle_t handle, int enable);
+int asvgp_elbo_prior_chain_1d(asvgp_handle_t handle, const double* static_bands, int kind, double variance, double lengthscale,
                               double noise_variance, int64_t M, int k, int64_t D, int* info, void* workspace,
                               size_t workspace_bytes, asvgp_stream_t stream);
-int asvgp_elbo_data_chain_1d(const double* stats, const double* static_bands, int kind, double variance,
+int asvgp_elbo_data_chain_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                              double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                              double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
@@ -160,7 +182,7 @@ int asvgp_elbo_data_chain_1d(const double* stats, const double* static_bands, in
  * prepare: alpha = P^-1 Phi y / s  (M, D)  and  W = band(P^-1) - band(Kuu^-1)  (k+1, M), once per theta.
  * predict: per test point mean = phi*^T alpha, var = variance + phi*^T W phi*  (full_cov=False only).
  * ---------------------------------------------------------------------------------------------- */
-int asvgp_posterior_prepare_1d(const double* stats, const double* static_bands, int kind, double variance,
+int asvgp_posterior_prepare_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                                double lengthscale, double noise_variance, int64_t M, int k, int64_t D,
                                double* alpha, double* W, int* info, void* workspace, size_t workspace_bytes,
                                asvgp_stream_t stream);
@@ -249,8 +271,8 @@ int asvgp_phi_cross_2d(const double* x_i, const double* x_j, int64_t N, const do
  * every Phi-pass kernel launch (up to 1024 launches); asvgp_profile_read synchronises on them and returns the
  * summed kernel time in milliseconds and the number of launches, then resets the ring.  Host-side, not stream-ordered.
  * ---------------------------------------------------------------------------------------------- */
-int asvgp_profile_enable(int on);   /* 0 off, 1 every launch, n > 1 every n-th launch (events perturb the stream) */
-int asvgp_profile_read(double* phi_kernel_ms_sum_host, int64_t* launches_host);
+int asvgp_profile_enable(asvgp_handle_t handle, int on);   /* 0 off, 1 every launch, n > 1 every n-th launch (events perturb the stream) */
+int asvgp_profile_read(asvgp_handle_t handle, double* phi_kernel_ms_sum_host, int64_t* launches_host);
 
 #ifdef __cplusplus
 }

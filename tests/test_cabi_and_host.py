@@ -40,12 +40,14 @@ def test_host_side_argument_checks_fail_loudly(lib):
     assert lib.asvgp_cholesky_band(None, None, 10, 4, None, None) == -1
     assert b"cholesky_band" in lib.asvgp_last_error_string()
     assert lib.asvgp_cholesky_band(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 9, None, None) == -2   # bandwidth > 8
-    assert lib.asvgp_phi_accumulate_1d(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 7, 0.1, 4, 10,
+    assert lib.asvgp_phi_accumulate_1d(None, ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 7, 0.1, 4, 10,
                                        ctypes.c_void_p(8), None, 0, None) == -4                         # no workspace
-    assert lib.asvgp_phi_accumulate_1d(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 5, 0.1, 4, 10,
+    assert lib.asvgp_phi_accumulate_1d(None, ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 5, 0.1, 4, 10,
                                        ctypes.c_void_p(8), ctypes.c_void_p(8), 1 << 30, None) == -1     # n_mesh != M-k+1
-    assert lib.asvgp_phi_accumulate_1d(ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 7, 0.1, 7, 13,
+    assert lib.asvgp_phi_accumulate_1d(None, ctypes.c_void_p(8), ctypes.c_void_p(8), 10, 1, ctypes.c_void_p(8), 7, 0.1, 7, 13,
                                        ctypes.c_void_p(8), ctypes.c_void_p(8), 1 << 30, None) == -2     # order 7
+    assert lib.asvgp_set_band_algorithm(None, 7) == -1 and lib.asvgp_set_phi_algorithm(None, 2) == -1
+    assert lib.asvgp_destroy(None) == 0
     assert lib.asvgp_phi_workspace_bytes(2048, 4, 1) == 8 * 256 * (6 * 2048 + 1)
     assert lib.asvgp_elbo_workspace_bytes(2048, 4, 1) >= 8 * (9 * 5 * 2048 + 2 * 2048)
     with pytest.raises(_lib.AsvgpError):
@@ -186,3 +188,104 @@ def test_bench_self_launch_dry_two_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0]) == {"dry": True, "n_gpus": 2, "ranks_seen": 2}
+
+
+# ------------------------------------------------------------------------------------------------ planned prior chain (host part)
+def _bcr_forward_long_double(K, B):
+    """Forward pass of block cyclic reduction (odd-even elimination of the B x B block-tridiagonal view of the lower band K),
+    every node, in numpy long double: what asvgp_prior_forward_host must reproduce on its de-duplicated nodes."""
+    ld = np.longdouble
+    k, M = K.shape[0] - 1, K.shape[1]
+    nb = (M + B - 1) // B
+    D = [np.zeros((B, B), ld) for _ in range(nb)]
+    E = [np.zeros((B, B), ld) for _ in range(nb)]
+    for j in range(M):
+        for d in range(k + 1):
+            i = j + d
+            if i < M:
+                if i // B == j // B:
+                    D[i // B][i % B, j % B] = D[i // B][j % B, i % B] = K[d, j]
+                else:
+                    E[j // B][i % B, j % B] = K[d, j]
+    for r in range(M, nb * B):
+        D[r // B][r % B, r % B] = 1
+
+    def chol(A):
+        L = np.zeros_like(A)
+        for j in range(B):
+            L[j, j] = np.sqrt(A[j, j] - np.sum(L[j, :j] ** 2))
+            for i in range(j + 1, B):
+                L[i, j] = (A[i, j] - np.sum(L[i, :j] * L[j, :j])) / L[j, j]
+        return L
+
+    def solve(L, X):
+        X = X.copy()
+        for i in range(B):
+            X[i] = (X[i] - L[i, :i] @ X[:i]) / L[i, i]
+        return X
+    fac, logdet, h = {}, ld(0), 1
+    while h < nb:
+        for i in range(h, nb, 2 * h):
+            a, b = i - h, i + h
+            L = chol(D[i])
+            logdet += 2 * np.sum(np.log(np.diag(L)))
+            Ua = solve(L, E[a])
+            Ub = solve(L, E[i].T) if b < nb else np.zeros((B, B), ld)
+            fac[i] = (L, Ua, Ub)
+            D[a] = D[a] - Ua.T @ Ua
+            if b < nb:
+                D[b] = D[b] - Ub.T @ Ub
+                E[a] = -(Ub.T @ Ua)
+        h *= 2
+    L0 = chol(D[0])
+    logdet += 2 * np.sum(np.log(np.diag(L0)))
+    return fac, L0, logdet
+
+
+@pytest.mark.parametrize("order,M,kind,l", [(4, 2048, 1, 0.05), (4, 2047, 1, 0.05), (4, 1024, 0, 0.1), (3, 333, 2, 0.03), (5, 129, 2, 0.1),
+                                            (6, 90, 1, 0.08), (1, 37, 0, 0.08), (2, 64, 1, 0.08), (4, 13, 0, 0.3)])
+def test_prior_plan_host_forward_vs_long_double_bcr(lib, order, M, kind, l):
+    """asvgp_prior_forward_host eliminates ONE representative per class of bit-identical nodes; every node's factors
+    (through the node -> record map), the log-determinant and the l-tangents must equal the all-nodes long-double forward pass."""
+    bs = O.Basis(order, 0, 1, M)
+    terms = O.kuu_terms(kind, 0.9, l)
+    S = np.ascontiguousarray(np.stack([getattr(bs, nm) for nm, _, _ in terms]))
+    c = np.array([t[1] for t in terms])
+    dc = np.array([t[2] for t in terms])
+    n = lib.asvgp_prior_table_doubles(S.ctypes.data, len(terms), M, order)
+    assert n > 0
+    tab = np.zeros(n)
+    nb = (M + order - 1) // order
+    rec = np.zeros(nb, dtype=np.int32)
+    assert lib.asvgp_prior_forward_host(S.ctypes.data, len(terms), M, order, c.ctypes.data, dc.ctypes.data, tab.ctypes.data, n,
+                                        rec.ctypes.data) == 0
+    B, R = order, int(tab[3])
+    W = 3 * B * B + B
+    assert n == 8 + 2 * R * W and tab[2] == 0 and R <= 3 * 12 and rec.min() >= 0 and rec.max() == R - 1 == rec[0]
+    val, tan = tab[8:8 + R * W].reshape(R, W), tab[8 + R * W:].reshape(R, W)
+    K, dK = O.make_Kuu(bs, kind, 0.9, l, want_dl=True)
+    fac, L0, logdet = _bcr_forward_long_double(K, B)
+    cond_slack = 1e-9 if kind == 2 else 1e-11      # two 64-bit-mantissa evaluations in different operation orders, times cond(Kuu)
+    for i, (L, Ua, Ub) in fac.items():
+        for off, X in ((0, L), (B * B + B, Ua), (2 * B * B + B, Ub)):
+            got = val[rec[i], off:off + B * B].reshape(B, B)
+            assert np.max(np.abs(got - X.astype(np.float64))) <= cond_slack * max(1.0, float(np.max(np.abs(X)))), (i, off)
+        np.testing.assert_allclose(val[rec[i], B * B:B * B + B] * np.diag(L).astype(np.float64), 1.0, rtol=cond_slack)
+    np.testing.assert_allclose(val[rec[0], :B * B].reshape(B, B), L0.astype(np.float64), rtol=0, atol=cond_slack * float(np.max(L0)))
+    assert abs(tab[0] - float(logdet)) <= max(1e-12, cond_slack * 1e-2) * abs(float(logdet))
+    # tangents against central differences of the long-double pass (well-conditioned cases only resolve this)
+    h = 1e-6 * l
+    fp, _, ldp = _bcr_forward_long_double(O.make_Kuu(bs, kind, 0.9, l + h), B)
+    fm, _, ldm = _bcr_forward_long_double(O.make_Kuu(bs, kind, 0.9, l - h), B)
+    assert abs(tab[1] - float((ldp - ldm) / (2 * h))) <= 2e-5 * abs(tab[1])
+    if M <= 129:
+        for i in fac:
+            for off, q in ((0, 0), (B * B + B, 1), (2 * B * B + B, 2)):
+                fd = ((fp[i][q] - fm[i][q]) / (2 * h)).astype(np.float64)
+                got = tan[rec[i], off:off + B * B].reshape(B, B)
+                assert np.max(np.abs(got - fd)) <= 1e-5 * max(1e-12, float(np.max(np.abs(fd)))), (i, off)
+    # a band without Toeplitz structure has no plan
+    rng = np.random.default_rng(0)
+    Sr = np.ascontiguousarray(S + rng.uniform(0, 1e-3, S.shape) * (np.abs(S) > 0))
+    if nb > 64:
+        assert lib.asvgp_prior_table_doubles(Sr.ctypes.data, len(terms), M, order) == 0

@@ -417,9 +417,12 @@ def kuu_cond(ob, kd, v, l):
                                           (4, 4096, 2, 0.002), (4, 4096, 1, 0.004), (3, 3000, 0, 0.01),   # BIG BCR layout (config 3 shape)
                                           (5, 2500, 2, 0.006)])
 def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd, l):
-    """The O(log M) block-cyclic-reduction band solver and the sequential column sweeps are two evaluation orders of
-    the same factorisation: ELBO, gradient and posterior must agree with each other and with the oracle, to the
-    stated tolerance widened by eps * cond(Kuu) when the problem itself is ill-conditioned in fp64."""
+    """Three evaluation orders of the same factorisation - sequential column sweeps (1, the reference's order), all-GPU block
+    cyclic reduction (2) and block cyclic reduction with the planned prior chain (3, the default: forward pass of the Kuu chain
+    in long double on the host) - against the oracle (fp64, reference order) AND its long-double evaluation.
+    Gate for the default path and for the sweeps: 1e-9 |ELBO| + max(5 |oracle - long double|, 2e-11 (N v/2s + y'y/2s)), i.e.
+    within 5x of what the reference's own fp64 order loses (no eps*cond slack).  The all-GPU cyclic reduction is the fast
+    fallback for bands without Toeplitz structure and is only required to stay within eps*cond of the cancelling terms."""
     rng = np.random.default_rng(order * 7 + M)
     N = 4000 if M < 1500 else 40000
     x = rng.uniform(1e-9, 1 - 1e-9, N)
@@ -434,36 +437,37 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
         for algo in (1, 2, 3):
             A.set_band_algorithm(algo)
             model._post = None
-            try:
-                r = model.elbo_and_grad().cpu().numpy()
-            except RuntimeError:
-                if algo == 3 and M > 2048:      # the fully lane-distributed variant has no BIG (M > 2048) layout
-                    continue
-                raise
+            r = model.elbo_and_grad().cpu().numpy()
             mean, var = model.predict_f(xs)
             res[algo] = (r, mean, var)
     finally:
         A.set_band_algorithm(0)
-    assert 1 in res and 2 in res
+    model._post = None
+    r0 = model.elbo_and_grad().cpu().numpy()
+    np.testing.assert_array_equal(r0, res[3][0])          # auto == planned prior chain
     ob = O.Basis(order, 0, 1, M)
     Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
     oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, N, v, l, s)
+    ee, ge = O.elbo_grad_1d_extended(ob, kd, Ab, b, yy, N, v, l, s)
     om, ov = O.predict_f_1d_banded(ob, kd, Ab, b, v, l, s, xs)
     cond = kuu_cond(ob, kd, v, l)
     big = 0.5 * N * v / s + 0.5 * yy / s
-    eps_c = 2.2e-16 * cond                       # what fp64 can resolve of the cancelling O(N v / s) terms
-    for algo in sorted(res):
+    eps_c = 2.2e-16 * cond                       # what fp64 cyclic reduction can lose of the cancelling O(N v / s) terms
+    gate = 1e-9 * abs(ee) + max(5 * abs(oe - ee), 2e-11 * big)
+    for algo in (1, 3):
         r, mean, var = res[algo]
-        tol = elbo_tol(oe, N, v, s, yy, bcr=(algo != 1)) + eps_c * big
-        assert abs(r[0] - oe) <= tol, (algo, r[0], oe, cond)
-        gt = max(1e-6, 50 * eps_c)
-        np.testing.assert_allclose(r[1:4], og, rtol=gt, atol=gt * np.max(np.abs(og)), err_msg="algo %d cond %.1e" % (algo, cond))
-        pt = max(1e-8, 10 * eps_c)
+        assert abs(r[0] - ee) <= gate, (algo, r[0], ee, oe, gate, cond)
+        gt = max(1e-6, 5 * float(np.max(np.abs((og - ge) / ge))))
+        np.testing.assert_allclose(r[1:4], ge, rtol=gt, atol=gt * np.max(np.abs(ge)), err_msg="algo %d cond %.1e" % (algo, cond))
+    r, mean, var = res[2]
+    assert abs(r[0] - ee) <= elbo_tol(ee, N, v, s, yy, bcr=True) + eps_c * big, (2, r[0], ee, cond)
+    gt = max(1e-6, 50 * eps_c)
+    np.testing.assert_allclose(r[1:4], ge, rtol=gt, atol=gt * np.max(np.abs(ge)), err_msg="algo 2 cond %.1e" % cond)
+    for algo in (1, 2, 3):
+        r, mean, var = res[algo]
+        pt = max(1e-8, 10 * eps_c) if algo == 2 else max(1e-8, 5 * float(np.max(np.abs(res[1][2] - ov))))
         np.testing.assert_allclose(mean, om, rtol=0, atol=pt)
         np.testing.assert_allclose(var, ov, rtol=0, atol=pt)
-    assert abs(res[1][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
-    if 3 in res:
-        assert abs(res[3][0][0] - res[2][0][0]) <= elbo_tol(oe, N, v, s, yy, bcr=True) + eps_c * big
 
 
 @pytest.mark.parametrize("order,M,N,sort", [(1, 16, 5000, False), (2, 33, 7001, False), (3, 100, 20000, True), (4, 64, 20000, False),
@@ -637,48 +641,92 @@ def test_two_rank_sharded_model_matches_single_rank(A):
 
 
 def test_split_prior_and_data_chain_equals_fused_call(A):
-    """asvgp_elbo_prior_chain_1d (side stream) + asvgp_elbo_data_chain_1d == asvgp_elbo_grad_1d."""
+    """asvgp_elbo_prior_chain_1d (side stream) + asvgp_elbo_data_chain_1d == asvgp_elbo_grad_1d, for the all-GPU chains
+    (band algorithm 2: two-stream schedule) and for the planned prior chain (3: the prior call is a no-op, the data call runs
+    both chains in one launch) and the sequential sweeps (1)."""
     rng = np.random.default_rng(8)
     N, M = 30000, 1024
     x = rng.uniform(1e-9, 1 - 1e-9, N)
     y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
     model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.01), A.B4Spline(0, 1, M))
     model.likelihood.variance.assign(0.01)
-    fused = model.elbo_and_grad().cpu().numpy()
-    model._out.zero_()
+    ref = model.elbo_and_grad().cpu().numpy()          # auto = planned prior chain
     side = torch.cuda.Stream()
-    done = torch.cuda.Event()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        model.launch_prior_chain()
-        done.record(side)
-    model.phi_pass()
-    torch.cuda.current_stream().wait_event(done)
-    split = model.launch_data_chain()[:4].cpu().numpy()
-    model._check_pd()
-    np.testing.assert_allclose(split, fused, rtol=1e-12)
-    # library-internal ordering (asvgp_elbo_chain_sync): no caller-side event
-    from asvgp_amd import _lib
-    _lib.get_lib().asvgp_elbo_chain_sync(1)
     try:
-        model._out.zero_()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            model.launch_prior_chain()
-        model.phi_pass()
-        split2 = model.launch_data_chain()[:4].cpu().numpy()
-        torch.cuda.current_stream().wait_stream(side)
-    finally:
-        _lib.get_lib().asvgp_elbo_chain_sync(0)
-    np.testing.assert_allclose(split2, fused, rtol=1e-12)
-    for algo in (1, 2, 3):  # the sequential-sweep path goes through the same entry points (prior is a no-op there)
-        A.set_band_algorithm(algo)
+        for algo in (2, 3, 1):
+            A.set_band_algorithm(algo)
+            fused = model.elbo_and_grad().cpu().numpy()
+            np.testing.assert_allclose(fused, ref, rtol=1e-7)
+            model._out.zero_()
+            done = torch.cuda.Event()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model.launch_prior_chain()
+                done.record(side)
+            model.phi_pass()
+            torch.cuda.current_stream().wait_event(done)
+            split = model.launch_data_chain()[:4].cpu().numpy()
+            model._check_pd()
+            np.testing.assert_allclose(split, fused, rtol=1e-12)
+        # handle-internal ordering (asvgp_elbo_chain_sync): no caller-side event
+        A.set_band_algorithm(2)
+        fused = model.elbo_and_grad().cpu().numpy()
+        model._h.chain_sync(1)
         try:
-            model.launch_prior_chain()
-            r = model.launch_data_chain()[:4].cpu().numpy()
+            model._out.zero_()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model.launch_prior_chain()
+            model.phi_pass()
+            split2 = model.launch_data_chain()[:4].cpu().numpy()
+            torch.cuda.current_stream().wait_stream(side)
         finally:
-            A.set_band_algorithm(0)
-        np.testing.assert_allclose(r, fused, rtol=1e-6)
+            model._h.chain_sync(0)
+        np.testing.assert_allclose(split2, fused, rtol=1e-12)
+    finally:
+        A.set_band_algorithm(0)
+
+
+def test_two_models_step_concurrently_on_two_streams_and_threads(A):
+    """SURVEY 8 b3 / VERDICT r1 #6: library state lives in per-model handles, so two models with different theta, algorithms
+    and sizes may step from two host threads on two streams; each must get exactly what it gets alone."""
+    import threading
+    rng = np.random.default_rng(31)
+    specs = [(60000, 1024, 0.03, 0), (45001, 512, 0.08, 2)]
+    models, alone = [], []
+    for N, M, l, algo in specs:
+        x = rng.uniform(1e-9, 1 - 1e-9, N)
+        y = (np.sin(15 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+        m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.1, lengthscales=l), A.B4Spline(0, 1, M))
+        m.likelihood.variance.assign(0.02)
+        if algo:
+            m._h.set_band_algorithm(algo)
+        models.append(m)
+        alone.append(m.elbo_and_grad().cpu().numpy())
+    torch.cuda.synchronize()
+    got = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(40):
+                    models[i].phi_pass()
+                    r = models[i].elbo_and_grad(check_pd=False)
+                st.synchronize()
+                got[i] = r.cpu().numpy()
+        except Exception as exc:      # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        np.testing.assert_allclose(got[i], alone[i], rtol=1e-12)
 
 
 def test_kron_fit_improves_bound(A):
