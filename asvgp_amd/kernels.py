@@ -25,12 +25,25 @@ class Parameter:
         self.assign(value)
 
     def assign(self, value):
+        """Set the constrained value.  The value is kept EXACTLY (gpflow would return softplus(softplus_inv(value)), an ulp or
+        two away): with cond(Kuu) ~ 1e7 the fp64 rounding pattern of the Kuu band alone moves the bound at the 1e-9 level, so
+        parity against a CPU evaluation at theta needs the very same doubles."""
         value = float(value)
         assert value > self.lower
-        self.unconstrained = softplus_inv(value - self.lower)
+        self._u = softplus_inv(value - self.lower)
+        self._value = value
+
+    @property
+    def unconstrained(self):
+        return self._u
+
+    @unconstrained.setter
+    def unconstrained(self, u):
+        self._u = float(u)
+        self._value = softplus(self._u) + self.lower
 
     def numpy(self):
-        return softplus(self.unconstrained) + self.lower
+        return self._value
 
     __float__ = numpy
 
