@@ -444,7 +444,7 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
         A.set_band_algorithm(0)
     model._post = None
     r0 = model.elbo_and_grad().cpu().numpy()
-    np.testing.assert_allclose(r0, res[3][0], rtol=1e-13)      # auto == planned prior chain (the finalize sums with atomics)
+    np.testing.assert_allclose(r0, res[3][0], rtol=1e-9, atol=1e-9 * float(np.max(np.abs(r0))))   # auto == planned prior chain (the finalize sums with atomics: last bits vary)
     ob = O.Basis(order, 0, 1, M)
     Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
     oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, N, v, l, s)
