@@ -78,7 +78,7 @@ extern "C" int asvgp_destroy(asvgp_handle_t handle) {
 
 extern "C" int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo) {
   if (algo != 0 && algo != 1 && algo != 3 && algo != 5) {
-    set_error("set_phi_algorithm: 0 auto (= 5), 1 fp64 LDS-atomic band scatter, 3 fixed-point band scatter, 5 fixed-point centred-moment scatter");
+    set_error("set_phi_algorithm: 0 auto (5 where it applies, else 3), 1 fp64 LDS-atomic band scatter, 3 fixed-point band scatter, 5 fixed-point centred-moment scatter");
     return ASVGP_ERR_BAD_ARG;
   }
   as_handle(handle)->phi_algo = algo;

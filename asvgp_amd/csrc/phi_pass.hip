@@ -405,6 +405,10 @@ template <int K> struct MomCoef {
   static constexpr MomTab<K> tab{};
 };
 
+}  // namespace asvgp
+#include "phi_moments.hpp"
+namespace asvgp {
+
 
 // Sum the per-workgroup partials into the packed stats buffer (zeroed beforehand).
 // grid = (ceil((E+1)/256), gsplit); each thread sums its slice of workgroups, then one fp64 global atomic.
@@ -583,12 +587,69 @@ static int phi_max_cols(int K, long n_mesh, bool fx) {
   return (int)(avail / (8 * (K + 2 + (fx ? 1 : 0))));
 }
 
+// Centred-moment Phi pass (algorithm 5, phi_moments.hpp).  Returns 1 when it does not apply (D != 1, unaligned inputs, or the
+// plane split does not fit the LDS at this M) and the caller falls back to the band-scatter kernel.
+template <int K, int G>
+static int launch_phi_moments_g(Handle* h, const double* x, const double* y, long N, const double* mesh, long n_mesh, double delta,
+                                long M, double* stats, double* ws, hipStream_t st) {
+  const int ncells = (int)n_mesh - 1;
+  const size_t lds_bytes = mq_lds_bytes<K, G>(ncells, (int)n_mesh);
+  if (lds_bytes > PHI_LDS_BUDGET) return 1;
+  long max_wg = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
+  long R = max_wg / G;
+  if (R < 1) return 1;
+  const long need = (N + 2 * MQ_THREADS - 1) / (2 * MQ_THREADS);
+  if (R > need) R = need < 1 ? 1 : need;
+  if (R >= 8) R &= ~7L;                                   // whole XCD rounds: the roles of a range share an XCD
+  long ppr = (N + R - 1) / R;
+  ppr = ((ppr + 2 * MQ_THREADS - 1) / (2 * MQ_THREADS)) * (2 * MQ_THREADS);
+  if (ppr < 2 * MQ_THREADS) ppr = 2 * MQ_THREADS;
+  int s0 = 50;
+  { long c = 2; int lg = 1; while (c < ppr) { c <<= 1; ++lg; } if (62 - lg < s0) s0 = 62 - lg; }
+  const long E = (long)mq_planes<K>() * ncells;
+  MqArgs a;
+  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta;
+  a.partials = ws;
+  a.scal = a.partials + (size_t)PHI_MAX_BLOCKS * E;
+  a.ov = a.scal + 2 * PHI_MAX_BLOCKS;
+  a.tot = a.ov + (size_t)PHI_MAX_BLOCKS * (K + 1) * ncells;
+  a.tot_n = E;
+  a.ppr = ppr; a.n_ranges = (int)R; a.s0 = s0;
+  auto kern = phi_moment_kernel<K, G>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+  const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
+  if (prof) (void)hipEventRecord(h->prof_ev[h->prof_n][0], st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(R * G)), dim3(MQ_THREADS), lds_bytes, st, a);
+  if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
+  const int gsplit = R >= 64 ? 16 : (R >= 8 ? 4 : 1);
+  hipLaunchKernelGGL(phi_moment_reduce_kernel, dim3((unsigned)((E + 255) / 256), gsplit), dim3(256), 0, st, a.partials, (int)R, E, a.tot);
+  hipLaunchKernelGGL(phi_moment_convert_kernel<K>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, a.tot, ncells, M, a.scal, (int)R, stats);
+  int rc = check_launch("phi_accumulate_1d (moments)");
+  return rc;
+}
+
+template <int K>
+static int launch_phi_moments(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh, double delta,
+                              long M, double* stats, double* ws, hipStream_t st) {
+  if (D != 1 || N < 1 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return 1;
+  int rc = launch_phi_moments_g<K, 1>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
+  if (rc == 1) rc = launch_phi_moments_g<K, 2>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
+  if (rc == 1) rc = launch_phi_moments_g<K, 4>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
+  return rc;
+}
+
 // Band-scatter Phi pass (algorithms 1 and 3): the (k+1)(k+2)/2 + (k+1) products of every point go straight into the
 // workgroup's LDS band image.  Timing events (Handle::prof_*) are recorded on the launch stream right around the kernel.
 template <int K>
 static int launch_phi(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
   const int ncells = (int)n_mesh - 1;
+  if (h->phi_algo == 0 || h->phi_algo == 5) {
+    const int rc = launch_phi_moments<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
+    if (rc != 1) return rc;
+    if (h->phi_algo == 5) { set_error("phi algorithm 5 (centred moments) needs D == 1, 16-byte aligned x / y and M small enough for the LDS split"); return ASVGP_ERR_UNSUPPORTED; }
+  }
   const bool fx = (h->phi_algo != 1);
   int maxc = phi_max_cols(K, n_mesh, fx);
   if (maxc < 2 * K + 2) {
@@ -643,7 +704,10 @@ using namespace asvgp;
 extern "C" size_t asvgp_phi_workspace_bytes(int64_t M, int order, int64_t D) {
   (void)D;
   if (M <= 0 || order < 1 || order > ASVGP_MAX_ORDER) return 0;
-  return sizeof(double) * (size_t)PHI_MAX_BLOCKS * ((size_t)(order + 2) * (size_t)M + 1);
+  // band scatter: 256 partial band images; centred moments: 256 x (moment image + y-overflow planes + 2 scalars) + the totals
+  const size_t band = (size_t)PHI_MAX_BLOCKS * ((size_t)(order + 2) * (size_t)M + 1);
+  const size_t mom = (size_t)PHI_MAX_BLOCKS * ((size_t)(4 * order + 3) * (size_t)M + 2) + (size_t)(3 * order + 2) * (size_t)M;
+  return sizeof(double) * (band > mom ? band : mom);
 }
 
 extern "C" int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double* y, int64_t N, int64_t D, const double* mesh,

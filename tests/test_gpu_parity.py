@@ -474,9 +474,9 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
                                              (4, 1024, 100000, False), (4, 2048, 150001, True), (5, 200, 30000, False),
                                              (6, 90, 10000, True), (4, 4096, 60000, False), (3, 3000, 50000, True)])
 def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
-    """v1 (per-point fp64 LDS atomic scatter), v2 (counting sort + per-cell moments) and v3 (v1 with the band summed in
-    64-bit fixed point) give the same statistics; sorted (time-series) inputs exercise the wave-uniform paths, clustered
-    inputs the skew handling."""
+    """Algorithm 1 (per-point fp64 LDS atomic band scatter), 3 (the same in 64-bit fixed point) and 5 (fixed-point centred
+    moments per cell, planes split over 1 / 2 / 4 workgroup roles - the default where it applies) give the same statistics;
+    sorted (time-series) inputs exercise the wave-uniform run mode, repeated points the same-address paths."""
     rng = np.random.default_rng(M + N)
     x = rng.uniform(1e-9, 1 - 1e-9, N)
     if sort:
@@ -488,22 +488,30 @@ def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
     band, rhs, yy = O.sufficient_stats_direct(ob, x, y)
     got = {}
     try:
-        for algo in (1, 2, 3, 4):
+        for algo in (1, 3, 5):
             A.set_phi_algorithm(algo)
-            m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), bs)
+            try:
+                m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), bs)
+            except RuntimeError:
+                assert algo == 5 and M == 4096      # 13 planes over 4 roles + the 32 KB mesh table exceed the LDS: auto falls back to 3
+                continue
             got[algo] = m._stats.cpu().numpy().copy()
-            assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= 1e-12 * np.max(np.abs(band)), algo
             gotb = m.KufKfu.cpu().numpy()
-            assert (gotb[band == 0] == 0).all(), algo       # structural zeros (right padding) stay exact zeros
-            if algo != 3 and not (algo == 4 and order == 6):   # fixed point (3, and 4's k = 6 fallback) flushes entries below ~1e-15 of the diagonal's scale to zero
+            assert np.max(np.abs(gotb - band)) <= 1e-12 * np.max(np.abs(band)), algo
+            pad = np.zeros_like(band, dtype=bool)
+            for d in range(1, order + 1):
+                pad[d, M - d:] = True
+            assert (gotb[pad] == 0).all(), algo       # structural zeros (right padding) stay exact zeros
+            if algo == 1:
                 assert np.array_equal(gotb == 0, band == 0), algo
             np.testing.assert_allclose(m.Kuf_y.cpu().numpy(), rhs, rtol=0, atol=1e-12 * np.max(np.abs(rhs)))
             assert abs(m.tr_yTy.item() - yy) <= 1e-12 * yy
     finally:
         A.set_phi_algorithm(0)
-    assert np.max(np.abs(got[1] - got[2])) <= 1e-12 * np.max(np.abs(got[1]))
-    assert np.max(np.abs(got[1] - got[3])) <= 1e-12 * np.max(np.abs(got[1]))
-    assert np.max(np.abs(got[1] - got[4])) <= 1e-12 * np.max(np.abs(got[1]))
+    for algo in got:
+        assert np.max(np.abs(got[1] - got[algo])) <= 1e-12 * np.max(np.abs(got[1]))
+    m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), bs)          # auto
+    assert np.max(np.abs(m._stats.cpu().numpy() - got[1])) <= 1e-12 * np.max(np.abs(got[1]))
 
 
 # ------------------------------------------------------------------------------------------------ Kronecker 2-D
