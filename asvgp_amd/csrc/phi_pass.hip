@@ -588,54 +588,46 @@ static int phi_max_cols(int K, long n_mesh, bool fx) {
 }
 
 // Centred-moment Phi pass (algorithm 5, phi_moments.hpp).  Returns 1 when it does not apply (D != 1, unaligned inputs, or the
-// plane split does not fit the LDS at this M) and the caller falls back to the band-scatter kernel.
-template <int K, int G>
-static int launch_phi_moments_g(Handle* h, const double* x, const double* y, long N, const double* mesh, long n_mesh, double delta,
-                                long M, double* stats, double* ws, hipStream_t st) {
+// image does not fit the LDS at this M) and the caller falls back to the band-scatter kernel.
+template <int K, int CS>
+static int launch_phi_moments_cs(Handle* h, const double* x, const double* y, long N, const double* mesh, long n_mesh, double delta,
+                                 long M, double* stats, double* ws, hipStream_t st) {
   const int ncells = (int)n_mesh - 1;
-  const size_t lds_bytes = mq_lds_bytes<K, G>(ncells, (int)n_mesh);
-  if (lds_bytes > PHI_LDS_BUDGET) return 1;
-  long max_wg = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
-  long R = max_wg / G;
-  if (R < 1) return 1;
-  const long need = (N + 2 * MQ_THREADS - 1) / (2 * MQ_THREADS);
-  if (R > need) R = need < 1 ? 1 : need;
-  if (R >= 8) R &= ~7L;                                   // whole XCD rounds: the roles of a range share an XCD
-  long ppr = (N + R - 1) / R;
-  ppr = ((ppr + 2 * MQ_THREADS - 1) / (2 * MQ_THREADS)) * (2 * MQ_THREADS);
-  if (ppr < 2 * MQ_THREADS) ppr = 2 * MQ_THREADS;
-  int s0 = 50;
-  { long c = 2; int lg = 1; while (c < ppr) { c <<= 1; ++lg; } if (62 - lg < s0) s0 = 62 - lg; }
-  const long E = (long)mq_planes<K>() * ncells;
+  const size_t lds_bytes = mq_lds_bytes<K, CS>(M);
+  if (ncells > CS || lds_bytes > PHI_LDS_BUDGET) return 1;
+  long nblk = (N + 2 * MQ_THREADS - 1) / (2 * MQ_THREADS);
+  const long gmax = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
+  const int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
+  long ppb = (N + G - 1) / G;
+  ppb = ((ppb + 2 * MQ_THREADS - 1) / (2 * MQ_THREADS)) * (2 * MQ_THREADS);
+  int s0 = 50;   // 62 - ceil(log2(points per workgroup)), at most 50 (magic-constant conversion range)
+  { long c = 2; int lg = 1; while (c < ppb) { c <<= 1; ++lg; } if (62 - lg < s0) s0 = 62 - lg; }
   MqArgs a;
-  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta;
+  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M;
   a.partials = ws;
-  a.scal = a.partials + (size_t)PHI_MAX_BLOCKS * E;
-  a.ov = a.scal + 2 * PHI_MAX_BLOCKS;
-  a.tot = a.ov + (size_t)PHI_MAX_BLOCKS * (K + 1) * ncells;
-  a.tot_n = E;
-  a.ppr = ppr; a.n_ranges = (int)R; a.s0 = s0;
-  auto kern = phi_moment_kernel<K, G>;
+  a.ov = ws + (size_t)PHI_MAX_BLOCKS * ((size_t)(K + 2) * M + 1);
+  a.ppb = ppb; a.zero_ptr = stats; a.zero_n = (K + 2) * M + 1; a.s0 = s0;
+  { const char* ab = getenv("ASVGP_PHI_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+  auto kern = phi_moment_kernel<K, CS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
   const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
   if (prof) (void)hipEventRecord(h->prof_ev[h->prof_n][0], st);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(R * G)), dim3(MQ_THREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(MQ_THREADS), lds_bytes, st, a);
   if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
-  const int gsplit = R >= 64 ? 16 : (R >= 8 ? 4 : 1);
-  hipLaunchKernelGGL(phi_moment_reduce_kernel, dim3((unsigned)((E + 255) / 256), gsplit), dim3(256), 0, st, a.partials, (int)R, E, a.tot);
-  hipLaunchKernelGGL(phi_moment_convert_kernel<K>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, a.tot, ncells, M, a.scal, (int)R, stats);
-  int rc = check_launch("phi_accumulate_1d (moments)");
-  return rc;
+  const int E1 = (int)((K + 2) * M + 1);
+  const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
+  return check_launch("phi_accumulate_1d (moments)");
 }
 
 template <int K>
 static int launch_phi_moments(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh, double delta,
                               long M, double* stats, double* ws, hipStream_t st) {
   if (D != 1 || N < 1 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return 1;
-  int rc = launch_phi_moments_g<K, 1>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
-  if (rc == 1) rc = launch_phi_moments_g<K, 2>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
-  if (rc == 1) rc = launch_phi_moments_g<K, 4>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
+  int rc = launch_phi_moments_cs<K, 512>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);     // plane stride: smallest that holds the cells
+  if (rc == 1) rc = launch_phi_moments_cs<K, 1024>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
+  if (rc == 1) rc = launch_phi_moments_cs<K, 2048>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
   return rc;
 }
 
@@ -704,9 +696,9 @@ using namespace asvgp;
 extern "C" size_t asvgp_phi_workspace_bytes(int64_t M, int order, int64_t D) {
   (void)D;
   if (M <= 0 || order < 1 || order > ASVGP_MAX_ORDER) return 0;
-  // band scatter: 256 partial band images; centred moments: 256 x (moment image + y-overflow planes + 2 scalars) + the totals
+  // 256 partial [band | Phi y | y^T y] images; the centred-moment kernel adds a per-workgroup fp64 plane for out-of-scale y
   const size_t band = (size_t)PHI_MAX_BLOCKS * ((size_t)(order + 2) * (size_t)M + 1);
-  const size_t mom = (size_t)PHI_MAX_BLOCKS * ((size_t)(4 * order + 3) * (size_t)M + 2) + (size_t)(3 * order + 2) * (size_t)M;
+  const size_t mom = band + (size_t)PHI_MAX_BLOCKS * (size_t)M;   // + the per-workgroup fp64 plane for out-of-scale y
   return sizeof(double) * (band > mom ? band : mom);
 }
 

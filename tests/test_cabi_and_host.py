@@ -48,7 +48,7 @@ def test_host_side_argument_checks_fail_loudly(lib):
                                        ctypes.c_void_p(8), ctypes.c_void_p(8), 1 << 30, None) == -2     # order 7
     assert lib.asvgp_set_band_algorithm(None, 7) == -1 and lib.asvgp_set_phi_algorithm(None, 2) == -1
     assert lib.asvgp_destroy(None) == 0
-    assert lib.asvgp_phi_workspace_bytes(2048, 4, 1) == 8 * (256 * (19 * 2048 + 2) + 14 * 2048)
+    assert lib.asvgp_phi_workspace_bytes(2048, 4, 1) == 8 * 256 * (7 * 2048 + 1)
     assert lib.asvgp_elbo_workspace_bytes(2048, 4, 1) >= 8 * (9 * 5 * 2048 + 2 * 2048)
     with pytest.raises(_lib.AsvgpError):
         _lib.check(-2, "x")

@@ -475,7 +475,7 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
                                              (6, 90, 10000, True), (4, 4096, 60000, False), (3, 3000, 50000, True)])
 def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
     """Algorithm 1 (per-point fp64 LDS atomic band scatter), 3 (the same in 64-bit fixed point) and 5 (fixed-point centred
-    moments per cell, planes split over 1 / 2 / 4 workgroup roles - the default where it applies) give the same statistics;
+    moments per cell for Phi Phi^T + fixed-point scatter of Phi y - the default where the image fits the LDS) give the same statistics;
     sorted (time-series) inputs exercise the wave-uniform run mode, repeated points the same-address paths."""
     rng = np.random.default_rng(M + N)
     x = rng.uniform(1e-9, 1 - 1e-9, N)
@@ -493,7 +493,7 @@ def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
             try:
                 m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), bs)
             except RuntimeError:
-                assert algo == 5 and M == 4096      # 13 planes over 4 roles + the 32 KB mesh table exceed the LDS: auto falls back to 3
+                assert algo == 5 and M > 2100       # the moment image exceeds the LDS: auto falls back to 3
                 continue
             got[algo] = m._stats.cpu().numpy().copy()
             gotb = m.KufKfu.cpu().numpy()

@@ -12,7 +12,7 @@ for sub in "ab":
     acc = {}
     for f in glob.glob("$O/%s/*/*_counter_collection.csv" % sub):
         for r in csv.DictReader(open(f)):
-            if "phi_" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
+            if ("phi_accumulate" in r["Kernel_Name"] or "phi_moment_kernel" in r["Kernel_Name"]):
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print("%-24s %14.0f   (n=%d)" % (k, sum(v) / len(v), len(v)))
