@@ -26,6 +26,12 @@
 // (the float32 linspace of Python-float endpoints) take the table from global memory.
 // Sorted / time-series input: a wave whose whole batch sits in ONE cell sums its moments across the wave on the VALU (DPP) and
 // commits them from one lane (full double -> int64 conversion) instead of 64 same-address atomics per plane.
+// What bounds it (rocprofv3 PMC + compile-time ablations, profiles/r02_phi_*): 83 us = 8 (prologue / epilogue) + 75; with the
+// streaming loads switched off it still takes 82 us, with the atomics switched off 45 us - the memory stream (36 us at 4.4 TB/s)
+// is fully hidden, and what remains is 45-50 us of LDS-pipe time (13 cycles per random-address ds_add_u64, 64 % of them
+// bank-conflict cycles) plus 43 us of VALU time (168 instructions per point at ~4 cycles) that overlap only by a quarter.
+// A software-pipelined form (the next batch's cell search interleaved with the current batch's atomics in one fenced basic
+// block) and a half-iteration stagger of the second half of the waves were built and measured: no change (84 us), removed.
 // Epilogue: every workgroup turns its moments into band entries through the exact integer-ratio tables MomTab (centred
 // monomials: <= 2e-14 of the largest entry up to k = 6) and flushes [band | Phi y | y^T y] like the band-scatter kernel, so
 // phi_reduce_kernel sums the partials unchanged.
