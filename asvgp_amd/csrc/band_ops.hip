@@ -45,14 +45,17 @@ struct KuuCoefs { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS];
 // contraction, so the band is bit-identical to the numpy/TF evaluation order).
 __global__ void kuu_assemble_kernel(const double* __restrict__ S, KuuCoefs cf, long E, double* __restrict__ Kuu,
                                     double* __restrict__ dK) {
+  // (HIP's __dmul_rn / __dadd_rn are plain * and +: without the pragma the compiler contracts them into fma and the band is no
+  // longer the reference's rounding sequence - found in round 2 through a 1-ulp knot mismatch in the Phi kernel)
+#pragma clang fp contract(off)
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  double acc = __dmul_rn(cf.c[0], S[e]);
-  double dacc = __dmul_rn(cf.dc[0], S[e]);
+  double acc = cf.c[0] * S[e];
+  double dacc = cf.dc[0] * S[e];
   for (int t = 1; t < cf.n; ++t) {
     double s = S[(long)t * E + e];
-    acc = __dadd_rn(acc, __dmul_rn(cf.c[t], s));
-    dacc = __dadd_rn(dacc, __dmul_rn(cf.dc[t], s));
+    acc = acc + cf.c[t] * s;
+    dacc = dacc + cf.dc[t] * s;
   }
   Kuu[e] = acc;
   if (dK) dK[e] = dacc;

@@ -153,15 +153,21 @@ template <bool BIG> __device__ __forceinline__ void bcr_barrier() {
 struct BandSumP {
   const double* A; const double* Kuu; double inv_s;   // A * (1/s): within 1 ulp of the reference's A / s (gpr.py:72); 40 fp64
                                                       // divisions per node on the prepass / level-0 chain were ~4 % of the P chain
-  __device__ __forceinline__ double load(long off, bool ok) const { return ok ? __dadd_rn(__dmul_rn(A[off], inv_s), Kuu[off]) : 0.0; }
+  __device__ __forceinline__ double load(long off, bool ok) const {
+#pragma clang fp contract(off)
+    const double t = A[off] * inv_s;
+    return ok ? t + Kuu[off] : 0.0;
+  }
   __device__ __forceinline__ void load8(long off, double (&o)[8]) const {
+#pragma clang fp contract(off)
     const double2* p = reinterpret_cast<const double2*>(A + off);
     const double2* q2 = reinterpret_cast<const double2*>(Kuu + off);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double2 t = p[q], u = q2[q];
-      o[2 * q] = __dadd_rn(__dmul_rn(t.x, inv_s), u.x);
-      o[2 * q + 1] = __dadd_rn(__dmul_rn(t.y, inv_s), u.y);
+      const double a0 = t.x * inv_s, a1 = t.y * inv_s;   // (plain operators: they are under the pragma, inlined helpers are not)
+      o[2 * q] = a0 + u.x;
+      o[2 * q + 1] = a1 + u.y;
     }
   }
   __device__ __forceinline__ bool aligned16() const { return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Kuu)) & 15) == 0; }

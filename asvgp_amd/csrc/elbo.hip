@@ -75,18 +75,21 @@ struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]
 static __global__ void elbo_prepare_kernel(const double* __restrict__ S, KuuCoefs2 cf, long E, const double* __restrict__ A,
                                     double s, double* __restrict__ Kuu, double* __restrict__ dK,
                                     double* __restrict__ P) {
+  // (HIP's __dmul_rn / __dadd_rn are plain * and +: without the pragma the compiler contracts them into fma and the band is no
+  // longer the reference's rounding sequence - found in round 2 through a 1-ulp knot mismatch in the Phi kernel)
+#pragma clang fp contract(off)
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  double acc = __dmul_rn(cf.c[0], S[e]);
-  double dacc = __dmul_rn(cf.dc[0], S[e]);
+  double acc = cf.c[0] * S[e];
+  double dacc = cf.dc[0] * S[e];
   for (int t = 1; t < cf.n; ++t) {
     double sv = S[(long)t * E + e];
-    acc = __dadd_rn(acc, __dmul_rn(cf.c[t], sv));
-    dacc = __dadd_rn(dacc, __dmul_rn(cf.dc[t], sv));
+    acc = acc + cf.c[t] * sv;
+    dacc = dacc + cf.dc[t] * sv;
   }
   Kuu[e] = acc;
   if (dK) dK[e] = dacc;
-  if (P) P[e] = __dadd_rn(__ddiv_rn(A[e], s), acc);  // gpr.py:72  KufKfu / sigma2 + Kuu
+  if (P) P[e] = A[e] / s + acc;  // gpr.py:72  KufKfu / sigma2 + Kuu
 }
 
 template <int K, bool TANGENT, bool RHS>

@@ -4,6 +4,7 @@
 #include <time.h>
 
 #include <mutex>
+#include <vector>
 
 #include "handle.hpp"
 
@@ -48,6 +49,27 @@ double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_o
   *seq_out = seq;
   *slot_out = slot;
   return h->tab_host + (size_t)slot * h->slot_doubles;
+}
+
+bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hipStream_t st, double* step_out) {
+  for (int i = 0; i < h->n_mesh_seen; ++i)
+    if (h->mesh_seen[i].ptr == mesh_dev && h->mesh_seen[i].n == n_mesh) { *step_out = h->mesh_seen[i].step; return h->mesh_seen[i].regular != 0; }
+  std::vector<double> m((size_t)n_mesh);
+  bool regular = false;
+  double step = 0.0;
+  if (n_mesh >= 2 && hipMemcpyAsync(m.data(), mesh_dev, sizeof(double) * (size_t)n_mesh, hipMemcpyDeviceToHost, st) == hipSuccess &&
+      hipStreamSynchronize(st) == hipSuccess) {
+    const double m0 = m[0];
+    step = (m[n_mesh - 1] - m0) / (double)(n_mesh - 1);
+    regular = true;
+    for (long i = 0; i < n_mesh - 1 && regular; ++i) {
+      volatile double t = (double)i * step;        // two roundings, no contraction: what numpy.linspace does
+      regular = (m[i] == t + m0);
+    }
+  }
+  if (h->n_mesh_seen < 8) h->mesh_seen[h->n_mesh_seen++] = Handle::MeshSeen{mesh_dev, n_mesh, regular ? 1 : 0, step};
+  *step_out = step;
+  return regular;
 }
 
 }  // namespace asvgp

@@ -52,14 +52,21 @@ template <int K, int CS> __host__ inline size_t mq_lds_bytes(long M) { return mq
 struct MqArgs {
   const double* x; const double* y; long N;
   const double* mesh_g; int n_mesh; double inv_delta; int M;
+  double step;             // REG: (last knot - first knot) / (n_mesh - 1) as the HOST rounds it (numpy.linspace's step)
   double* partials;        // [workgroup][(K+2) M + 1] doubles: band | Phi y | y^T y  (the layout phi_reduce_kernel sums)
   double* ov;              // [workgroup][M] fp64 plane for out-of-scale y (written and read by that workgroup only)
   long ppb;                // points per workgroup (a multiple of 2 * MQ_THREADS)
   double* zero_ptr; long zero_n;   // packed stats buffer to zero (phi_reduce_kernel adds into it afterwards)
   int s0;
-  int ablate;              // diagnostic (ASVGP_PHI_ABLATE): 1 = no LDS atomics (loads + cell search + arithmetic only), 2 = loads only,
-                           // 3 = no streaming loads (atomics + arithmetic only), 4 = non-temporal streaming loads
 };
+
+// knot i of numpy.linspace: i * step rounded, THEN + start rounded.  (HIP's __dmul_rn / __dadd_rn are plain * and + and may be
+// contracted into an fma - one rounding, a different knot in ~40 % of the cases when start != 0; the pragma forbids it.)
+__device__ __forceinline__ double mq_linspace_knot(int i, double step, double m0) {
+#pragma clang fp contract(off)
+  const double t = (double)i * step;
+  return t + m0;
+}
 
 // Cell search (basis.py:58-59: idx = max(#{mesh < x} - 1, 0), a TABLE search, not arithmetic).
 // mq_guess: arithmetic guess; the two knots around it are fetched one pipeline stage ahead; mq_resolve fixes the guess
@@ -82,7 +89,7 @@ __device__ __forceinline__ int mq_resolve(double x, int g, double lo, double hi,
   return i;
 }
 
-template <int K, int CS>
+template <int K, int CS, bool REG>
 __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
   extern __shared__ double lds[];
   if (a.zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.zero_n; e += (long)gridDim.x * blockDim.x) a.zero_ptr[e] = 0.0;
@@ -106,26 +113,28 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
   const double inv_delta = a.inv_delta;
   const long beg = (long)blockIdx.x * a.ppb;
   long end = beg + a.ppb;
+  const bool full = end <= a.N;                            // workgroup-uniform: every batch of this workgroup is complete
   if (end > a.N) end = a.N;
-  const long n_it = a.ppb / (2 * MQ_THREADS);              // rows of 64 lanes x 2 points per wave
-  auto unit_of = [&](long it) __attribute__((always_inline)) -> long {                    // super-tiles: each wave streams MQ_CH contiguous rows
-    const long nfull = n_it / MQ_CH, rem = n_it - nfull * MQ_CH;
-    const long sup = it / MQ_CH, r = it - sup * MQ_CH;
+  const int n_it = (int)(a.ppb / (2 * MQ_THREADS));        // rows of 64 lanes x 2 points per wave
+  // super-tiles: each wave streams MQ_CH contiguous rows (sorted input then keeps a wave inside one cell for long)
+  const int nfull = n_it / MQ_CH, rem = n_it - nfull * MQ_CH;
+  auto unit_of = [&](int it) __attribute__((always_inline)) -> int {
+    const int sup = it / MQ_CH, r = it - sup * MQ_CH;
     return (sup < nfull) ? (sup * (MQ_THREADS / 64) + wv) * MQ_CH + r : nfull * (MQ_THREADS / 64) * MQ_CH + wv * rem + r;
   };
-  const double2* x2 = reinterpret_cast<const double2*>(a.x);
-  const double2* y2 = reinterpret_cast<const double2*>(a.y);
   const long ubeg = beg >> 1, uend = (end > beg) ? (end >> 1) : 0;   // pairs
+  const double2* x2 = reinterpret_cast<const double2*>(a.x) + ubeg;  // workgroup-uniform bases: per-lane offsets stay 32-bit
+  const double2* y2 = reinterpret_cast<const double2*>(a.y) + ubeg;
+  const int npair = (int)(uend > ubeg ? uend - ubeg : 0);
   // ---- y scale of this workgroup: 2^E >= 4 max |y| over a strided sample of its range (4 x 1024 pairs)
   int E;
   double y0;
   {
     double m = 0.0;
-    const long npairs = uend > ubeg ? uend - ubeg : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const long u = ubeg + (npairs * q) / 4 + tid;
-      if (u < uend) { const double2 v = y2[u]; const double t = fmax(fabs(v.x), fabs(v.y)); m = (t == t && t < 1e300) ? fmax(m, t) : m; }
+      const int u = (int)(((long)npair * q) / 4) + tid;
+      if (u < npair) { const double2 v = y2[u]; const double t = fmax(fabs(v.x), fabs(v.y)); m = (t == t && t < 1e300) ? fmax(m, t) : m; }
     }
     if (tid == 0 && (end & 1) && end > beg) { const double t = fabs(a.y[end - 1]); m = (t == t && t < 1e300) ? fmax(m, t) : m; }
 #pragma unroll
@@ -143,10 +152,29 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
   const int chiS = ((1075 - s0) << 20) | 0x80000;          // magic-constant high word for scale 2^s0; power p: - (p << 20)
   const int chiR = ((1075 - (s0 - E)) << 20) | 0x80000;
   const double m0 = mesh[0];
+  const double m_last = mesh[n_mesh - 1];
+  const double step = a.step;                              // numpy.linspace: delta / div, divided on the host
   double yy = 0.0;
   unsigned nbad = 0;
+  if (REG) {   // the host chose this instantiation from its copy of the mesh; a mesh that is NOT that linspace here is reported loudly
+    bool okm = true;
+    for (int i = tid; i < n_mesh - 1; i += MQ_THREADS) okm = okm && (mesh[i] == mq_linspace_knot(i, step, m0));
+    if (!okm) ++nbad;
+  }
+  auto knot = [&](int i) __attribute__((always_inline)) -> double { return (i == n_mesh - 1) ? m_last : mq_linspace_knot(i, step, m0); };
 
-  // one point (cell c, centred local coordinate s) -> S planes, count, Phi y.  ONE branch for the y scale.
+  // ---- general code for one point: exact table search (basis.py:58-59), every special case handled per lane
+  auto cell_of = [&](double x, double& u) __attribute__((always_inline)) -> int {
+    int i = mq_guess(x, m0, inv_delta, n_mesh);
+    if (REG) {
+      double lo = knot(i);
+      if (!(lo < x)) { while (i > 0 && !(knot(i) < x)) --i; lo = knot(i); }
+      else if (knot(i + 1) < x) { while (i < n_mesh - 2 && knot(i + 1) < x) ++i; lo = knot(i); }
+      u = lo;
+      return i;
+    }
+    return mq_resolve(x, i, mesh[i], mesh[i + 1], mesh, n_mesh, u);
+  };
   auto scatter = [&](int c, double s, double yv) __attribute__((always_inline)) {
     if (!(fabs(s) <= 0.50001)) { ++nbad; return; }         // outside the mesh (or NaN): reported, never accumulated
     yy = fma(yv, yv, yy);
@@ -167,97 +195,99 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
       for (int i = 0; i <= K; ++i) __hip_atomic_fetch_add(ovr + c + K - i, v[i] * yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-
-  // ---- is the mesh the fp64 linspace numpy makes (basis.py:17 with int endpoints: knot i = i * step + start, two roundings,
-  // last knot = stop)?  Then the knots are generated on the VALU, bit for bit the table's, and the cell search needs no memory
-  // at all.  Otherwise (the float32-linspace meshes of Python-float endpoints) the table is read from global memory.
-  const double m_last = mesh[n_mesh - 1];
-  const double step = (m_last - m0) / (double)(n_mesh - 1);
-  bool regular;
-  {
-    bool ok = true;
-    for (int i = tid; i < n_mesh - 1; i += MQ_THREADS) ok = ok && (mesh[i] == __dadd_rn(__dmul_rn((double)i, step), m0));
-    regular = __syncthreads_and(ok ? 1 : 0) != 0;
-  }
-  auto knot = [&](int i) __attribute__((always_inline)) -> double { return (i == n_mesh - 1) ? m_last : __dadd_rn(__dmul_rn((double)i, step), m0); };
-  auto cell_regular = [&](double x, double& u) __attribute__((always_inline)) -> int {
-    int i = mq_guess(x, m0, inv_delta, n_mesh);
-    double lo = knot(i);
-    if (!(lo < x)) {
-      while (i > 0 && !(knot(i) < x)) --i;
-      lo = knot(i);
-    } else if (knot(i + 1) < x) {
-      while (i < n_mesh - 2 && knot(i + 1) < x) ++i;
-      lo = knot(i);
+  // the whole wave in cell cw (sorted / time-series input): VALU wave sums (DPP), one lane commits
+  auto wave_cell = [&](int cw, double sa, double sb, double ya, double yb) __attribute__((always_inline)) {
+    yy = fma(ya, ya, fma(yb, yb, yy));
+    if (lane == 0) __hip_atomic_fetch_add(cnt + cw, 128u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    double pa = sa, pb = sb;
+#pragma unroll
+    for (int p = 1; p <= NS; ++p) {
+      const double t = wave_sum_dpp(pa + pb);
+      if (lane == 0) lds_add_u64(planes + (size_t)(p - 1) * CS + cw, (unsigned long long)__double2ll_rn(ldexp(t, s0 + p)));
+      pa *= sa; pb *= sb;
     }
-    u = lo;
-    return i;
+    double va[K + 1], vb[K + 1];
+    bspline_pieces<K>(sa + 0.5, va);
+    bspline_pieces<K>(sb + 0.5, vb);
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+      const double t = wave_sum_dpp(fma(va[i], ya, vb[i] * yb));
+      if (lane == 0) lds_add_u64(rhs + cw + K - i, (unsigned long long)__double2ll_rn(ldexp(t, s0 - E)));
+    }
   };
-  auto cell_table = [&](double x, double& u) __attribute__((always_inline)) -> int {
-    const int g = mq_guess(x, m0, inv_delta, n_mesh);
-    return mq_resolve(x, g, mesh[g], mesh[g + 1], mesh, n_mesh, u);
-  };
-  // ---- streaming loop.  One batch = a 16-B pair (x0, x1), (y0, y1) per lane.  Two batches are in flight per wave (ping-pong
-  // register sets A / B, the loop statically unrolled by two: the set just consumed is re-requested for batch it + 2, the other
-  // one - batch it + 1 - is never touched while its loads are outstanding, so no wait is forced on it).
-  // Every batch is classified: a wave whose 128 points all sit in ONE cell with every y inside the scale (sorted / time-series
-  // input) sums its moments across the wave on the VALU (DPP) and commits them from one lane - 14 single-lane atomics instead
-  // of 28 same-address wave-wide ones; any other batch scatters point by point.
-  if (uend > ubeg) {
-    double2 xA = make_double2(0.0, 0.0), yA = xA, xB = xA, yB = xA;
-    const long ulast = uend - 1;
-    auto fetch = [&](long it, double2& xo, double2& yo) __attribute__((always_inline)) {   // unconditional (clamped address, masked at use):
-      long u = ubeg + unit_of(it < n_it ? it : n_it - 1) * 64 + lane;                        // a branch around the loads costs the compiler its
-      u = u < ulast ? u : ulast;                                                             // count of what is in flight (it then waits for everything)
-      if (a.ablate == 3 && it > 1) return;               // diagnostic: no streaming loads (the first two batches are re-used)
-      if (a.ablate == 4) {                                 // diagnostic: non-temporal loads
-        typedef double nt_d2 __attribute__((ext_vector_type(2)));
-        const nt_d2 xv = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(x2 + u)), yv = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(y2 + u));
-        xo = make_double2(xv.x, xv.y); yo = make_double2(yv.x, yv.y);
-        return;
-      }
+
+  // ---- streaming loop.  One batch = a 16-B pair (x0, x1), (y0, y1) per lane; two batches in flight per wave (ping-pong
+  // register sets, the loop statically unrolled by two; loads unconditional with clamped offsets, so that no branch costs the
+  // compiler its count of what is in flight).  Every batch is classified by wave votes:
+  //   common - every lane holds two in-range, in-scale points whose guessed cell needs at most one correction step: a branch-free
+  //            block (26 ds_add_u64 + 2 ds_add_u32 per lane pair, no exec-mask traffic);
+  //   whole wave in ONE cell: wave_cell;   anything else (last partial batch, outliers, far-off guesses): the general code.
+  if (npair > 0) {
+    const int ulast = npair - 1;
+    double2 xA, yA, xB, yB;
+    auto fetch = [&](int it, double2& xo, double2& yo) __attribute__((always_inline)) {
+      int u = unit_of(it < n_it ? it : n_it - 1) * 64 + lane;
+      u = u < ulast ? u : ulast;
       xo = x2[u]; yo = y2[u];
     };
-    auto batch = [&](long it, double2& xbuf, double2& ybuf) __attribute__((always_inline)) {
-      const bool have = (ubeg + unit_of(it) * 64 + lane) < uend;
+    auto batch = [&](int it, double2& xbuf, double2& ybuf) __attribute__((always_inline)) {
       const double2 xc = xbuf, yc = ybuf;
       fetch(it + 2, xbuf, ybuf);
-      double u0, u1;
-      int c0, c1;
-      if (regular) { c0 = cell_regular(xc.x, u0); c1 = cell_regular(xc.y, u1); }
-      else { c0 = cell_table(xc.x, u0); c1 = cell_table(xc.y, u1); }
-      const double sa = (xc.x - u0) * inv_delta - 0.5, sb = (xc.y - u1) * inv_delta - 0.5;
-      const int cw = __builtin_amdgcn_readfirstlane(c0);
-      const bool same = have && c0 == cw && c1 == cw && fabs(sa) <= 0.50001 && fabs(sb) <= 0.50001 &&
-                        fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
-      if (a.ablate == 1 || a.ablate == 2) {                // diagnostic builds of the timing experiments only
-        yy += (a.ablate == 2) ? xc.x + xc.y + yc.x + yc.y : sa + sb + yc.x + yc.y + (double)(c0 + c1);
-      } else if (__all(same)) {                            // ---- the whole wave in cell cw
-        yy = fma(yc.x, yc.x, fma(yc.y, yc.y, yy));
-        if (lane == 0) __hip_atomic_fetch_add(cnt + cw, 128u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        double pa = sa, pb = sb;
+      bool fast = false;
+      int c0 = 0, c1 = 0;
+      double sa = 0.0, sb = 0.0;
+      if (REG && full) {                                   // (uniform) branch-free classification
+        const int g0 = mq_guess(xc.x, m0, inv_delta, n_mesh), g1 = mq_guess(xc.y, m0, inv_delta, n_mesh);
+        const double l0 = knot(g0), h0 = knot(g0 + 1), l1 = knot(g1), h1 = knot(g1 + 1);
+        c0 = g0 - ((!(l0 < xc.x) && g0 > 0) ? 1 : 0) + (((h0 < xc.x) && g0 < n_mesh - 2) ? 1 : 0);
+        c1 = g1 - ((!(l1 < xc.y) && g1 > 0) ? 1 : 0) + (((h1 < xc.y) && g1 < n_mesh - 2) ? 1 : 0);
+        const double u0 = knot(c0), u0n = knot(c0 + 1), u1 = knot(c1), u1n = knot(c1 + 1);
+        const bool v0 = (c0 == 0 || u0 < xc.x) && (c0 == n_mesh - 2 || !(u0n < xc.x));    // basis.py:58-59 holds for c0
+        const bool v1 = (c1 == 0 || u1 < xc.y) && (c1 == n_mesh - 2 || !(u1n < xc.y));
+        sa = (xc.x - u0) * inv_delta - 0.5;
+        sb = (xc.y - u1) * inv_delta - 0.5;
+        const bool good = v0 && v1 && fabs(sa) <= 0.50001 && fabs(sb) <= 0.50001 && fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
+        fast = __all(good);
+      }
+      if (fast) {
+        const int cw = __builtin_amdgcn_readfirstlane(c0);
+        if (__all(c0 == cw && c1 == cw)) {
+          wave_cell(cw, sa, sb, yc.x, yc.y);
+        } else {
+          yy = fma(yc.x, yc.x, fma(yc.y, yc.y, yy));
+          __hip_atomic_fetch_add(cnt + c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(cnt + c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          double pa = sa, pb = sb;
 #pragma unroll
-        for (int p = 1; p <= NS; ++p) {
-          const double t = wave_sum_dpp(pa + pb);
-          if (lane == 0) lds_add_u64(planes + (size_t)(p - 1) * CS + cw, (unsigned long long)__double2ll_rn(ldexp(t, s0 + p)));
-          pa *= sa; pb *= sb;
-        }
-        double va[K + 1], vb[K + 1];
-        bspline_pieces<K>(sa + 0.5, va);
-        bspline_pieces<K>(sb + 0.5, vb);
+          for (int p = 1; p <= NS; ++p) {
+            lds_add_u64(planes + (size_t)(p - 1) * CS + c0, fx_convert(pa, chiS - (p << 20)));
+            lds_add_u64(planes + (size_t)(p - 1) * CS + c1, fx_convert(pb, chiS - (p << 20)));
+            pa *= sa; pb *= sb;
+          }
+          double va[K + 1], vb[K + 1];
+          bspline_pieces<K>(sa + 0.5, va);
+          bspline_pieces<K>(sb + 0.5, vb);
 #pragma unroll
-        for (int i = 0; i <= K; ++i) {
-          const double t = wave_sum_dpp(fma(va[i], yc.x, vb[i] * yc.y));
-          if (lane == 0) lds_add_u64(rhs + cw + K - i, (unsigned long long)__double2ll_rn(ldexp(t, s0 - E)));
+          for (int i = 0; i <= K; ++i) {
+            lds_add_u64(rhs + c0 + K - i, fx_convert(va[i] * yc.x, chiR));
+            lds_add_u64(rhs + c1 + K - i, fx_convert(vb[i] * yc.y, chiR));
+          }
         }
-      } else if (have) {
-        scatter(c0, sa, yc.x);
-        scatter(c1, sb, yc.y);
+      } else {                                             // ---- general code
+        const bool have = (unit_of(it) * 64 + lane) < npair;
+        double u0, u1;
+        c0 = cell_of(xc.x, u0); c1 = cell_of(xc.y, u1);
+        sa = (xc.x - u0) * inv_delta - 0.5; sb = (xc.y - u1) * inv_delta - 0.5;
+        const int cw = __builtin_amdgcn_readfirstlane(c0);
+        const bool same = have && c0 == cw && c1 == cw && fabs(sa) <= 0.50001 && fabs(sb) <= 0.50001 &&
+                          fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
+        if (__all(same)) wave_cell(cw, sa, sb, yc.x, yc.y);
+        else if (have) { scatter(c0, sa, yc.x); scatter(c1, sb, yc.y); }
       }
     };
     fetch(0, xA, yA);
     fetch(1, xB, yB);
-    for (long it = 0; it < n_it; it += 2) {                // wave-convergent throughout (votes, DPP)
+    for (int it = 0; it < n_it; it += 2) {                 // wave-convergent throughout (votes, DPP)
       batch(it, xA, yA);
       if (it + 1 < n_it) batch(it + 1, xB, yB);
     }
@@ -265,7 +295,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
   if ((end & 1) && end > beg && tid == 0) {                // odd tail point (only the last workgroup with points can have one)
     double u;
     const double xv = a.x[end - 1];
-    const int c = cell_table(xv, u);
+    const int c = cell_of(xv, u);
     scatter(c, (xv - u) * inv_delta - 0.5, a.y[end - 1]);
   }
   double tot = block_sum(yy, scratch);                     // (contains the barrier that orders the LDS atomics before the read-out)

@@ -591,7 +591,7 @@ static int phi_max_cols(int K, long n_mesh, bool fx) {
 // image does not fit the LDS at this M) and the caller falls back to the band-scatter kernel.
 template <int K, int CS>
 static int launch_phi_moments_cs(Handle* h, const double* x, const double* y, long N, const double* mesh, long n_mesh, double delta,
-                                 long M, double* stats, double* ws, hipStream_t st) {
+                                 long M, double* stats, double* ws, hipStream_t st, bool regular, double step) {
   const int ncells = (int)n_mesh - 1;
   const size_t lds_bytes = mq_lds_bytes<K, CS>(M);
   if (ncells > CS || lds_bytes > PHI_LDS_BUDGET) return 1;
@@ -603,12 +603,11 @@ static int launch_phi_moments_cs(Handle* h, const double* x, const double* y, lo
   int s0 = 50;   // 62 - ceil(log2(points per workgroup)), at most 50 (magic-constant conversion range)
   { long c = 2; int lg = 1; while (c < ppb) { c <<= 1; ++lg; } if (62 - lg < s0) s0 = 62 - lg; }
   MqArgs a;
-  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M;
+  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M; a.step = step;
   a.partials = ws;
   a.ov = ws + (size_t)PHI_MAX_BLOCKS * ((size_t)(K + 2) * M + 1);
   a.ppb = ppb; a.zero_ptr = stats; a.zero_n = (K + 2) * M + 1; a.s0 = s0;
-  { const char* ab = getenv("ASVGP_PHI_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
-  auto kern = phi_moment_kernel<K, CS>;
+  auto kern = regular ? phi_moment_kernel<K, CS, true> : phi_moment_kernel<K, CS, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
   const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
@@ -625,9 +624,11 @@ template <int K>
 static int launch_phi_moments(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh, double delta,
                               long M, double* stats, double* ws, hipStream_t st) {
   if (D != 1 || N < 1 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return 1;
-  int rc = launch_phi_moments_cs<K, 512>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);     // plane stride: smallest that holds the cells
-  if (rc == 1) rc = launch_phi_moments_cs<K, 1024>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
-  if (rc == 1) rc = launch_phi_moments_cs<K, 2048>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st);
+  double step = 0.0;
+  const bool regular = handle_mesh_is_linspace(h, mesh, n_mesh, st, &step);
+  int rc = launch_phi_moments_cs<K, 512>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, regular, step);     // plane stride: smallest that holds the cells
+  if (rc == 1) rc = launch_phi_moments_cs<K, 1024>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, regular, step);
+  if (rc == 1) rc = launch_phi_moments_cs<K, 2048>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, regular, step);
   return rc;
 }
 
