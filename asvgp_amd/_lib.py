@@ -40,6 +40,7 @@ SIGNATURES = {
     "asvgp_prior_table_doubles": (_Z, [_P, _I, _L, _I]),
     "asvgp_prior_forward_host": (_I, [_P, _I, _L, _I, _P, _P, _P, _Z, _P]),
     "asvgp_elbo_grad_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_kuu_inverse_band_1d": (_I, [_P, _P, _I, _D, _D, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "asvgp_elbo_chain_sync": (_I, [_P, _I]),
     "asvgp_elbo_prior_chain_1d": (_I, [_P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _Z, _P]),
     "asvgp_elbo_data_chain_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),

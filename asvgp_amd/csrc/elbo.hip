@@ -64,6 +64,10 @@ template <int K> struct ElboLauncher {
   static int run(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long N, long M, long D,
                  double* out, int* info, void* ws, hipStream_t st, int part);
 };
+template <int K> struct KuuInvLauncher {   // band(Kuu^-1) and its d/d-lengthscale tangent for one 1-D Kuu (the Kronecker factors)
+  static int run(Handle* h, const double* S, int kind, double v, double l, long M, double* Kuu, double* dK, double* SK, double* dSK,
+                 double* logdet2, int* info, void* ws, hipStream_t st);
+};
 template <int K> struct PostLauncher {
   static int run(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
                  double* alpha, double* W, int* info, void* ws, hipStream_t st);
@@ -473,9 +477,73 @@ int PostLauncher<K>::run(Handle* h, const double* stats, const double* S, int ki
 }
 
 
+// ---- band(Kuu^-1) with its lengthscale tangent as an operator of its own (asvgp_kuu_inverse_band_1d): the planned chain when the
+// handle holds a plan, else the all-GPU Dual chain (block cyclic reduction when it fits the LDS, sequential sweeps otherwise)
+template <int K>
+__global__ __launch_bounds__(BCR_THREADS) void kuu_inverse_pre_kernel(const double* tab, int n_rec, const int* node_rec, int M, double* wsK,
+                                                                      double* SK, double* dSK, double* logdet2, int* info,
+                                                                      unsigned long long* done_flag, unsigned long long seq) {
+  extern __shared__ double lds[];
+  bcr_backward_pre<K>(tab, n_rec, node_rec, M, wsK, lds, BandOut<Dual>{SK, dSK}, logdet2, info, done_flag, seq);
+}
+template <int K>
+__global__ __launch_bounds__(64) void kuu_inverse_sweep_kernel(const double* Kuu, const double* dK, double* LK, double* dLK, double* SK,
+                                                               double* dSK, int M, int* info) {
+  cholesky_sweep<Dual, K, false>(BandPtr<Dual>{Kuu, dK}, BandOut<Dual>{LK, dLK}, M, nullptr, nullptr, info);
+  __syncthreads();
+  takahashi_sweep<Dual, K, false>(BandPtr<Dual>{LK, dLK}, BandOut<Dual>{SK, dSK}, M, nullptr, nullptr);
+}
+static __global__ void kuu_logdet_kernel(const double* __restrict__ LK, const double* __restrict__ dLK, long M, double* __restrict__ out) {
+  __shared__ double scratch[32];
+  double a = 0.0, b = 0.0;
+  for (long j = threadIdx.x; j < M; j += blockDim.x) { const double l = LK[j]; a += log(l * l); b += 2.0 * dLK[j] / l; }
+  a = block_sum(a, scratch);
+  b = block_sum(b, scratch + 16);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
+template <int K>
+int KuuInvLauncher<K>::run(Handle* h, const double* S, int kind, double v, double l, long M, double* Kuu, double* dK, double* SK,
+                           double* dSK, double* logdet2, int* info, void* ws, hipStream_t st) {
+  KuuCoefs2 cf;
+  for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
+  int rc = asvgp_matern_coeffs(kind, v, l, cf.c, cf.dc, &cf.n);
+  if (rc) return rc;
+  Ws w = carve(ws, M, K, 1);
+  const long E = (long)(K + 1) * M, nb = (M + K - 1) / K;
+  hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, (const double*)nullptr, 1.0, Kuu, dK,
+                     (double*)nullptr);
+  const bool have_plan = h->plan && prior_plan_M(h->plan) == M && prior_plan_k(h->plan) == K && prior_plan_terms(h->plan) == cf.n;
+  if (have_plan && h->band_algo != 1 && h->band_algo != 2) {
+    unsigned long long seq = 0;
+    int slot = 0;
+    double* tab = handle_table_acquire(h, &seq, &slot);
+    (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
+    const int n_rec = prior_plan_nrec(h->plan);
+    const size_t lds_bytes = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kuu_inverse_pre_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+    hipLaunchKernelGGL(kuu_inverse_pre_kernel<K>, dim3(1), dim3(BCR_THREADS), lds_bytes, st, h->tab_dev + (size_t)slot * h->slot_doubles, n_rec,
+                       h->node_rec_dev, (int)M, w.bcrK, SK, dSK, logdet2, info, h->done_dev + slot, seq);
+    return check_launch("kuu_inverse_band_1d (planned)");
+  }
+  const size_t ldsK = sizeof(double) * bcr_lds_doubles<Dual, K, 0>(nb);
+  if (ldsK <= 160 * 1024 - 256 && h->band_algo != 1) {
+    auto kern = elbo_bcr_prior_kernel<K, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsK);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(BCR_THREADS), ldsK, st, Kuu, dK, (int)M, w.bcrK, SK, dSK, logdet2, info, 0);
+    return check_launch("kuu_inverse_band_1d (BCR)");
+  }
+  hipLaunchKernelGGL(kuu_inverse_sweep_kernel<K>, dim3(1), dim3(64), 0, st, Kuu, dK, w.LK, w.dLK, SK, dSK, (int)M, info);
+  hipLaunchKernelGGL(kuu_logdet_kernel, dim3(1), dim3(256), 0, st, w.LK, w.dLK, M, logdet2);
+  return check_launch("kuu_inverse_band_1d (sweeps)");
+}
+
 // ASVGP_ELBO_PART: 1 = ELBO + gradient launcher (tangent chains), 2 = posterior launcher, unset = both
 #if !defined(ASVGP_ELBO_PART) || ASVGP_ELBO_PART == 1
 template struct ElboLauncher<ASVGP_ELBO_ONLY_K>;
+template struct KuuInvLauncher<ASVGP_ELBO_ONLY_K>;
 #endif
 #if !defined(ASVGP_ELBO_PART) || ASVGP_ELBO_PART == 2
 template struct PostLauncher<ASVGP_ELBO_ONLY_K>;
@@ -545,6 +613,23 @@ extern "C" int asvgp_elbo_data_chain_1d(asvgp_handle_t handle, const double* sta
 #define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 2);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
 #undef ELBO_CASE
+  return ASVGP_ERR_UNSUPPORTED;
+}
+
+extern "C" int asvgp_kuu_inverse_band_1d(asvgp_handle_t handle, const double* static_bands, int kind, double variance, double lengthscale,
+                                         int64_t M, int k, double* Kuu, double* dKuu_dl, double* S, double* dS_dl, double* logdet2, int* info,
+                                         void* workspace, size_t workspace_bytes, asvgp_stream_t stream) {
+  if (!static_bands || !Kuu || !dKuu_dl || !S || !dS_dl || !logdet2 || !info || M < 1 || !(variance > 0.0) || !(lengthscale > 0.0)) {
+    set_error("kuu_inverse_band_1d: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  if (k < 1 || k > ASVGP_MAX_ORDER) { set_error("kuu_inverse_band_1d: bandwidth %d outside 1..%d", k, (int)ASVGP_MAX_ORDER); return ASVGP_ERR_UNSUPPORTED; }
+  if (!workspace || workspace_bytes < asvgp_elbo_workspace_bytes(M, k, 1)) { set_error("kuu_inverse_band_1d: workspace too small"); return ASVGP_ERR_WORKSPACE; }
+  Handle* h = as_handle(handle);
+  hipStream_t st = as_stream(stream);
+#define KINV_CASE(KK) case KK: return KuuInvLauncher<KK>::run(h, static_bands, kind, variance, lengthscale, (long)M, Kuu, dKuu_dl, S, dS_dl, logdet2, info, workspace, st);
+  switch (k) { KINV_CASE(1) KINV_CASE(2) KINV_CASE(3) KINV_CASE(4) KINV_CASE(5) KINV_CASE(6) }
+#undef KINV_CASE
   return ASVGP_ERR_UNSUPPORTED;
 }
 

@@ -381,10 +381,16 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         b1, b2 = self.bases
         m1, m2, k = b1.m, b2.m, self.order
         s = float(self.likelihood.variance)
-        Ks = [f.make_Kuu(kern) for f, kern in zip(self.inducing_features, self.kernels)]
-        Ls = [banded.cholesky_band(K) for K in Ks]
-        Ss = [banded.inverse_from_cholesky_band(L) for L in Ls]
-        logdet_K = m2 * torch.log(Ls[0][0] ** 2).sum() + m1 * torch.log(Ls[1][0] ** 2).sum()
+        # per-dimension Kuu factors: band(K_i^-1), its exact lengthscale tangent and log|K_i| from ONE call each (gpr.py:286-291)
+        Ks, dKs, Ss, dSs, lds = [], [], [], [], []
+        for feat, kern in zip(self.inducing_features, self.kernels):
+            K, dK, S, dS, ld2, info = feat.inverse_band(kern)
+            Ks.append(K); dKs.append(dK); Ss.append(S); dSs.append(dS); lds.append(ld2)
+        for i, feat in enumerate(self.inducing_features):
+            col = int(feat._info[0].item())
+            if col:
+                raise NotPositiveDefiniteError("Kuu band of dimension %d not positive definite at column %d" % (i, col - 1))
+        logdet_K = m2 * lds[0][0] + m1 * lds[1][0]
         bw = k * m2 + k
         dev = self._stats.device
         Pb = torch.empty(self.Mtot * (bw + 1), dtype=torch.float64, device=dev)
@@ -405,7 +411,7 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
             check(lib.asvgp_blockband_backsolve(Pb.data_ptr(), self.Mtot, bw, alpha.data_ptr(), stream_ptr()),
                   "blockband_backsolve")
             alpha = alpha / s
-        return dict(Ks=Ks, Ls=Ls, Ss=Ss, logdet_K=logdet_K, logdet_P=logdet_P[0], trace=tr[0], c=c / s, Lb=Pb, bw=bw,
+        return dict(Ks=Ks, dKs=dKs, Ss=Ss, dSs=dSs, logdet_K=logdet_K, logdet_P=logdet_P[0], trace=tr[0], c=c / s, Lb=Pb, bw=bw,
                     alpha=alpha, s=s)
 
     def elbo(self):
@@ -478,14 +484,8 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         s, N = f["s"], float(self.num_data)
         vs = [float(k.variance) for k in self.kernels]
         ls = [float(k.lengthscales) for k in self.kernels]
-        dKs, Zs = [], []
-        for feat, kern, v, l in zip(self.inducing_features, self.kernels, vs, ls):
-            _, dK = feat.make_Kuu(kern, with_dl=True)
-            dKs.append(dK)
-            h = 1e-5 * l                                         # band of K^-1 dK K^-1 = -d band(K^-1) / dl, central difference on the 1-D factor
-            Sp = banded.inverse_from_cholesky_band(banded.cholesky_band(feat.make_Kuu(type(kern)(variance=v, lengthscales=l + h))))
-            Sm = banded.inverse_from_cholesky_band(banded.cholesky_band(feat.make_Kuu(type(kern)(variance=v, lengthscales=l - h))))
-            Zs.append((Sm - Sp) / (2 * h))
+        dKs = f["dKs"]
+        Zs = [-dS for dS in f["dSs"]]                           # band(K^-1 dK K^-1) = -d band(K^-1)/dl: the exact tangent of the 1-D chain
         out = torch.empty(11, dtype=torch.float64, device=self._stats.device)
         b1, b2 = self.bases
         check(lib.asvgp_kron_grad_terms(SigD.data_ptr(), SigS.data_ptr(), Bb, f["alpha"].data_ptr(),

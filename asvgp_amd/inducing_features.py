@@ -4,7 +4,7 @@ import ctypes
 import torch
 
 from . import kernels
-from ._lib import check, get_lib, stream_ptr
+from ._lib import Handle, check, get_lib, stream_ptr
 
 TERM_ORDER = ("A", "B", "C", "D", "BC", "BC_grad", "BC_ggrad", "BC_ggrad_none", "BC_none_ggrad")
 KIND_TERMS = {
@@ -45,6 +45,31 @@ class SplineFeatures1D:
         check(lib.asvgp_kuu_assemble(S.data_ptr(), n.value, c, dc, M, k, Kuu.data_ptr(),
                                      dK.data_ptr() if with_dl else None, stream_ptr()), "kuu_assemble")
         return (Kuu, dK) if with_dl else Kuu
+
+    def inverse_band(self, kernel):
+        """(Kuu, dKuu/dl, S, dS/dl, logdet2) with S = band(Kuu^-1) = inverse_from_cholesky_band(cholesky_band(Kuu)) (gpr.py:56-59),
+        its exact lengthscale tangent (forward mode through the factorisation: band(Kuu^-1 dKuu Kuu^-1) = -dS/dl) and
+        logdet2 = [log|Kuu|, d log|Kuu|/dl] on the device - asvgp_kuu_inverse_band_1d, with the handle's prior plan (forward pass
+        on the host in long double over the distinct nodes) when the bands have the Toeplitz structure."""
+        import numpy as np
+        lib = get_lib()
+        S = self.static_stack(kernel.kind)
+        k, M = self.basis.order, self.basis.m
+        if getattr(self, "_h", None) is None:
+            self._h = Handle()
+            self._h_kind = None
+            self._ws = torch.zeros(lib.asvgp_elbo_workspace_bytes(M, k, 1) // 8, dtype=torch.float64, device=S.device)
+            self._info = torch.zeros(2, dtype=torch.int32, device=S.device)
+        if self._h_kind != kernel.kind:
+            self._h.prior_plan(np.ascontiguousarray(S.cpu().numpy()), S.shape[0], M, k)
+            self._h_kind = kernel.kind
+        out = [torch.empty((k + 1, M), dtype=torch.float64, device=S.device) for _ in range(4)]
+        logdet2 = torch.empty(2, dtype=torch.float64, device=S.device)
+        check(lib.asvgp_kuu_inverse_band_1d(self._h.ptr, S.data_ptr(), kernel.kind, float(kernel.variance), float(kernel.lengthscales),
+                                            M, k, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                            logdet2.data_ptr(), self._info.data_ptr(), self._ws.data_ptr(), self._ws.numel() * 8,
+                                            stream_ptr()), "kuu_inverse_band_1d")
+        return out[0], out[1], out[2], out[3], logdet2, self._info
 
     def make_Kuf(self, X, sparse=True):
         """inducing_features.py:47-48 (the `sparse` argument is ignored there too)."""

@@ -160,6 +160,14 @@ int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double*
                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                        double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
+/* band(Kuu^-1) and its d/d-lengthscale tangent as an operator of its own: Kuu / dKuu_dl (assembled, inducing_features.py:12-44), S =
+ * inverse_from_cholesky_band(cholesky_band(Kuu)) (gpr.py:56-59) and dS / dl, logdet2 (device) = [log|Kuu|, d log|Kuu| / dl].
+ * What the Kronecker model needs of each 1-D factor (gpr.py:286-307); uses the handle's prior plan when there is one (host
+ * forward pass in long double), else the all-GPU chains.  workspace: asvgp_elbo_workspace_bytes(M, k, 1). */
+int asvgp_kuu_inverse_band_1d(asvgp_handle_t handle, const double* static_bands, int kind, double variance, double lengthscale,
+                              int64_t M, int k, double* Kuu, double* dKuu_dl, double* S, double* dS_dl, double* logdet2, int* info,
+                              void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+
 /* The same computation split for scheduling: the PRIOR chain touches only theta (Kuu, dKuu/dl, band(Kuu^-1) and its
  * tangent, log|Kuu|) and may be enqueued on another stream concurrently with the Phi pass; the DATA chain
  * (P = Kuu + A/s factor/solve/inverse + the finalize) needs `stats` and must be ordered after the prior chain of the same

@@ -710,6 +710,82 @@ def elbo_kron(bases, kinds, thetas, s, X, y):
     return float(elbo), dict(A=A, b=b, Kuu=Kuu, P=P)
 
 
+def elbo_grad_kron(bases, kinds, thetas, s, X, y):
+    """The bound of elbo_kron and its analytic gradient w.r.t. [v_1, l_1, ..., v_d, l_d, s] (dense; small grids only):
+    G = 1/2 (Kuu^-1 - P^-1 - alpha alpha^T - Kuu^-1 A Kuu^-1 / s) (SURVEY App. A-6 with Kuu = kron(K_i), gpr.py:282-308),
+    d/dl_i = <G, K_1 x .. dK_i/dl_i .. x K_d>, d/dv_i = <G, -Kuu / v_i> - N prod(v) / (2 s v_i), d/ds as in the 1-D case.
+    This is what TF autodiff returns for the reference's dense expression."""
+    e, parts = elbo_kron(bases, kinds, thetas, s, X, y)
+    A, b, Kuu, P = parts["A"], parts["b"], parts["Kuu"], parts["P"]
+    N = X.shape[0]
+    Kinv = np.linalg.inv(Kuu)
+    Pinv = np.linalg.inv(P)
+    alpha = Pinv @ b / s
+    G = 0.5 * (Kinv - Pinv - alpha @ alpha.T - Kinv @ A @ Kinv / s)
+    Ks, dKs = [], []
+    for bs, kd, (v, l) in zip(bases, kinds, thetas):
+        K, dK = make_Kuu(bs, kd, v, l, want_dl=True)
+        Ks.append(band_to_dense_sym(K))
+        dKs.append(band_to_dense_sym(dK))
+    vprod = float(np.prod([v for v, _ in thetas]))
+    g = []
+    for i, (v, l) in enumerate(thetas):
+        Kd = np.ones((1, 1))
+        for j in range(len(bases)):
+            Kd = np.kron(Kd, dKs[j] if j == i else Ks[j])
+        g.append(float(np.sum(G * (-Kuu / v))) - 0.5 * N * vprod / (v * s))
+        g.append(float(np.sum(G * Kd)))
+    trKA = float(np.trace(Kinv @ A))
+    yy = float(np.sum(y * y))
+    g.append(float(-0.5 * N / s + 0.5 * np.sum(Pinv * A) / s ** 2 + 0.5 * yy / s ** 2 + 0.5 * (alpha.T @ A @ alpha).item() / s ** 2
+                   - (b.T @ alpha).item() / s ** 2 + 0.5 * N * vprod / s ** 2 - 0.5 * trKA / s ** 2))
+    return e, np.array(g)
+
+
+def elbo_kron_banded(bases, kinds, thetas, s, X, y):
+    """The same bound (gpr.py:282-308) without ever forming a dense M_tot x M_tot matrix, for grids of the BASELINE size
+    (128 x 128): Kuf Kuf^T as a scipy sparse product, P = kron(K_1, K_2) + A / s as a LAPACK band (bandwidth k (m_2 + 1),
+    scipy.linalg.cholesky_banded), log|Kuu| = m_2 log|K_1| + m_1 log|K_2|, tr(Kuu^-1 A) = <K_1^-1 x K_2^-1, A> over the
+    non-zeros of A.  d = 2 only (utils.py:57 handles exactly that too)."""
+    import scipy.linalg as sla
+    assert len(bases) == 2 and y.shape[1] == 1
+    N = X.shape[0]
+    k = bases[0].order
+    m1, m2 = bases[0].m, bases[1].m
+    M = m1 * m2
+    Phis = [bs.evaluate_basis(X[:, i:i + 1]) for i, bs in enumerate(bases)]
+    Kuf = make_kvs_sparse(Phis).tocsr()
+    A = (Kuf @ Kuf.T).tocoo()
+    b = np.asarray(Kuf @ y).reshape(-1)
+    Kd = [band_to_dense_sym(make_Kuu(bs, kd, v, l)) for bs, kd, (v, l) in zip(bases, kinds, thetas)]
+    Kinv = [np.linalg.inv(K) for K in Kd]
+    logdet_K = m2 * np.linalg.slogdet(Kd[0])[1] + m1 * np.linalg.slogdet(Kd[1])[1]
+    i1, i2, j1, j2 = A.row // m2, A.row % m2, A.col // m2, A.col % m2
+    trKA = float(np.sum(A.data * Kinv[0][i1, j1] * Kinv[1][i2, j2]))
+    bw = k * (m2 + 1)
+    Pb = np.zeros((bw + 1, M))                              # LAPACK lower band: Pb[i - j, j] = P[i, j]
+    low = A.row >= A.col
+    np.add.at(Pb, (A.row[low] - A.col[low], A.col[low]), A.data[low] / s)
+    K1b, K2b = make_Kuu(bases[0], kinds[0], *thetas[0]), make_Kuu(bases[1], kinds[1], *thetas[1])
+    for d1 in range(k + 1):                                 # kron(K_1, K_2)[(a + d1) m2 + (c + d2), a m2 + c] = K_1[a + d1, a] K_2[c + d2, c]
+        for d2 in range(-k, k + 1):
+            if d1 == 0 and d2 < 0:
+                continue
+            a = np.arange(m1 - d1)
+            c = np.arange(max(0, -d2), min(m2, m2 - d2))
+            v2 = K2b[abs(d2), np.minimum(c, c + d2)]
+            col = (a[:, None] * m2 + c[None, :]).reshape(-1)
+            val = (K1b[d1, a][:, None] * v2[None, :]).reshape(-1)
+            Pb[d1 * m2 + d2, col] += val
+    Lb = sla.cholesky_banded(Pb, lower=True)
+    logdet_P = 2.0 * float(np.sum(np.log(Lb[0])))
+    c = sla.solve_banded((bw, 0), Lb, b) / s
+    vprod = float(np.prod([v for v, _ in thetas]))
+    elbo = (-0.5 * N * np.log(2 * np.pi * s) - 0.5 * logdet_P + 0.5 * logdet_K - 0.5 * float(np.sum(y * y)) / s
+            + 0.5 * float(np.sum(c * c)) - 0.5 * N * vprod / s + 0.5 * trKA / s)
+    return float(elbo)
+
+
 def predict_f_kron(bases, kinds, thetas, s, X, y, Xnew):
     """gpr.py:310-334: dense posterior (mean, var) of GPR_kron; var is tiled over D columns (gpr.py:331-332)."""
     _, parts = elbo_kron(bases, kinds, thetas, s, X, y)

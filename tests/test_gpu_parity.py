@@ -966,6 +966,20 @@ def test_kron_full_size_properties_config4_and_config5_shapes(A):
     m2_ = A.GPR_kron((X[perm].contiguous(), y[perm].contiguous()), model.kernels, bases)
     m2_.likelihood.variance.assign(0.01)
     assert abs(m2_.elbo().item() - e) <= 1e-9 * abs(e) + 5e-10 * (0.5 * N / 0.01)
+    # the bound itself against the CPU banded oracle at the full 128 x 128 basis (LAPACK band Cholesky, bandwidth 387): N = 200k
+    Ns = 200_000
+    ms = A.GPR_kron((X[:Ns], y[:Ns]), [A.Matern32(variance=1.0, lengthscales=0.2), A.Matern32(variance=1.0, lengthscales=0.2)], bases)
+    ms.likelihood.variance.assign(0.05)
+    ob = [O.Basis(3, 0, 1, 128), O.Basis(3, 0, 1, 128)]
+    Xh, yh = X[:Ns].cpu().numpy(), y[:Ns].cpu().numpy()
+    oe = O.elbo_kron_banded(ob, [1, 1], [(1.0, 0.2), (1.0, 0.2)], 0.05, Xh, yh)
+    es, gs = ms.elbo_and_grad()
+    assert abs(es - oe) <= elbo_tol(oe, Ns, 1.0, 0.05, float((y[:Ns] * y[:Ns]).sum().item())), (es, oe)
+    assert abs(ms.elbo().item() - oe) <= elbo_tol(oe, Ns, 1.0, 0.05, float((y[:Ns] * y[:Ns]).sum().item()))
+    hfd = 1e-5 * 0.05                                            # d / d sigma^2 by central differences of the banded oracle (the others: small-grid test)
+    fd_s = (O.elbo_kron_banded(ob, [1, 1], [(1.0, 0.2), (1.0, 0.2)], 0.05 + hfd, Xh, yh) -
+            O.elbo_kron_banded(ob, [1, 1], [(1.0, 0.2), (1.0, 0.2)], 0.05 - hfd, Xh, yh)) / (2 * hfd)
+    assert abs(gs[4] - fd_s) <= 1e-5 * abs(fd_s)
     # posterior at 2000 test points: mean close to the noise-free function, variance within (0, prior]
     Xs = torch.rand((2000, 2), dtype=torch.float64, device="cuda", generator=g) * 0.9 + 0.05
     mean, var = model.predict_f(Xs)
@@ -989,7 +1003,7 @@ def test_kron_full_size_properties_config4_and_config5_shapes(A):
 @pytest.mark.parametrize("order,m1,m2,N", [(3, 10, 11, 1500), (2, 30, 8, 2500), (4, 14, 13, 3000)])
 def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
     """Band-restricted inverse of P through dense super-blocks vs the dense inverse; analytic gradient of the bound
-    (TF autodiff in the reference, eNATL60.py:89) vs central differences of the dense oracle."""
+    (TF autodiff in the reference, eNATL60.py:89) vs the analytic dense gradient of the oracle, gate 1e-6."""
     rng = np.random.default_rng(m1 * 31 + m2)
     X = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(-0.999, 1.999, N)], axis=1)
     y = (np.sin(6 * X[:, :1]) * np.cos(2 * X[:, 1:]) + 0.1 * rng.normal(size=(N, 1)))
@@ -1023,17 +1037,8 @@ def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
     assert abs(e - oe) <= elbo_tol(oe, N, th[0][0] * th[1][0], s, yy, bcr=True)
     assert abs(e - model.elbo().item()) <= 1e-9 * abs(e)
 
-    def val(p):
-        return O.elbo_kron(obases, [1, 1], [(p[0], p[1]), (p[2], p[3])], p[4], X, y)[0]
-    p0 = np.array([th[0][0], th[0][1], th[1][0], th[1][1], s])
-    fd = np.zeros(5)
-    for i in range(5):
-        h = 1e-5 * p0[i]
-        pp, pm = p0.copy(), p0.copy()
-        pp[i] += h
-        pm[i] -= h
-        fd[i] = (val(pp) - val(pm)) / (2 * h)
-    np.testing.assert_allclose(g, fd, rtol=2e-5, atol=2e-5 * np.max(np.abs(fd)))
+    _, og = O.elbo_grad_kron(obases, [1, 1], th, s, X, y)     # the analytic dense gradient (what TF autodiff gives the reference)
+    np.testing.assert_allclose(g, og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
 
 
 @pytest.mark.parametrize("order,m1,m2,N", [(1, 7, 9, 3000), (2, 9, 8, 4001), (3, 12, 10, 20000), (4, 14, 15, 30000), (5, 16, 15, 8000),
