@@ -196,7 +196,7 @@ __device__ __forceinline__ T band_E(const Src& A, int M, int n, int r, int c) { 
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int B, int NRHS, typename Src = BandPtr<T>, bool BIG = false>
 __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rhs, int M, double* ws, double* lds, BandOut<T> S, double* x,
-                          double* logdet, int* info, double* stamps = nullptr) {
+                          double* logdet, int* info, double* stamps = nullptr, int rhs_stride = 1) {
   using N = Num<T>;
   using Lay = BcrLayout<B, NRHS>;
   const int tid = threadIdx.x;
@@ -276,7 +276,7 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
     constexpr int RMAX = (2 * NS * B + BCR_THREADS - 1) / BCR_THREADS;
     double rv[RMAX];
 #pragma unroll
-    for (int q = 0; q < RMAX; ++q) { const int r = tid + q * BCR_THREADS; rv[q] = (r < M) ? rhs[r] : 0.0; }
+    for (int q = 0; q < RMAX; ++q) { const int r = tid + q * BCR_THREADS; rv[q] = (r < M) ? rhs[(long)r * rhs_stride] : 0.0; }
 #pragma unroll
     for (int q = 0; q < RMAX; ++q) { const int r = tid + q * BCR_THREADS; if (r < nb * B) xs[r] = rv[q]; }
   }
@@ -813,7 +813,7 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
       for (int d = 1; d <= B; ++d)
         if (col + d >= M) S.store((long)d * M + col, N::zero());
   if (NRHS)
-    for (int r = tid; r < M; r += BCR_THREADS) x[r] = xs[r];
+    for (int r = tid; r < M; r += BCR_THREADS) x[(long)r * rhs_stride] = xs[r];
   // log|A| = 2 sum log diag(L_i) over all nodes, off the dependent chain (padding rows have L = 1)
   {
     constexpr int RMAX = (2 * NS * B + BCR_THREADS - 1) / BCR_THREADS;
@@ -851,6 +851,123 @@ __device__ __attribute__((always_inline)) void bcr_solve(Src A, const double* rh
       *info = (bmin == 0x7fffffff) ? 0 : bmin;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Further right-hand-side columns (y with D > 1 outputs, gpr.py:75,80-82: solve_triang_mat with an M x D rhs) from the factor
+// records bcr_solve<double, B, 1> left in `ws`: the same forward / backward substitution over the elimination tree, one thread
+// per (node, column) pair per level, columns d0 .. d0 + nd - 1 of the row-major (M, D) arrays rhs / x.
+// lds: nb * B * nd doubles (the survivor image of bcr_solve is dead by now).  Called by the whole workgroup.
+// ------------------------------------------------------------------------------------------------------------
+template <int B, bool BIG = false>
+__device__ __attribute__((noinline)) void bcr_solve_more(const double* rhs, double* x, int D, int d0, int nd, int M, double* ws, double* lds) {
+  using Lay = BcrLayout<B, 1>;
+  const int tid = threadIdx.x;
+  const int nb = (M + B - 1) / B;
+  constexpr int NN = 2 * bcr_ns<double, B, BIG>();
+  auto W = [&](int node, int f) -> double { return ws[(long)f * NN + node]; };
+  double* xs = lds;                                          // [row][nd]
+  for (int e = tid; e < nb * B * nd; e += BCR_THREADS) {
+    const int row = e / nd, d = e - row * nd;
+    xs[e] = (row < M) ? rhs[(long)row * D + d0 + d] : 0.0;
+  }
+  __syncthreads();
+  int levels = 0;
+  while ((1 << levels) < nb) ++levels;
+  for (int l = 0; l < levels; ++l) {                         // forward: z_i = L^-1 y_i, y_a -= U_a^T z_i | y_b -= U_b^T z_i
+    const int h = 1 << l;
+    const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
+    for (int w = tid; w < ne * nd; w += BCR_THREADS) {
+      const int m = w / nd, d = w - m * nd;
+      const int i = h + m * 2 * h, a = i - h;
+      double z[B];
+#pragma unroll
+      for (int r = 0; r < B; ++r) {
+        double t = xs[(i * B + r) * nd + d];
+#pragma unroll
+        for (int p = 0; p < r; ++p) t = fma(-W(i, Lay::W_L + r * B + p), z[p], t);
+        z[r] = t * W(i, Lay::W_I + r);
+      }
+#pragma unroll
+      for (int r = 0; r < B; ++r) {
+        xs[(i * B + r) * nd + d] = z[r];
+        double t = xs[(a * B + r) * nd + d];
+#pragma unroll
+        for (int p = 0; p < B; ++p) t = fma(-W(i, Lay::W_UA + p * B + r), z[p], t);
+        xs[(a * B + r) * nd + d] = t;
+      }
+    }
+    __syncthreads();
+    for (int w = tid; w < ne * nd; w += BCR_THREADS) {
+      const int m = w / nd, d = w - m * nd;
+      const int i = h + m * 2 * h, b = i + h;
+      if (b < nb) {
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+          double t = xs[(b * B + r) * nd + d];
+#pragma unroll
+          for (int p = 0; p < B; ++p) t = fma(-W(i, Lay::W_UB + p * B + r), xs[(i * B + p) * nd + d], t);
+          xs[(b * B + r) * nd + d] = t;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int d = tid; d < nd; d += BCR_THREADS) {              // root: x_0 = L^-T L^-1 y_0  (only L of the root record is stored)
+    double t[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+      double v = xs[r * nd + d];
+#pragma unroll
+      for (int p = 0; p < r; ++p) v = fma(-W(0, Lay::W_L + r * B + p), t[p], v);
+      t[r] = v / W(0, Lay::W_L + r * B + r);
+    }
+#pragma unroll
+    for (int r = B - 1; r >= 0; --r) {
+      double v = t[r];
+#pragma unroll
+      for (int p = r + 1; p < B; ++p) v = fma(-W(0, Lay::W_L + p * B + r), t[p], v);
+      t[r] = v / W(0, Lay::W_L + r * B + r);
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) xs[r * nd + d] = t[r];
+  }
+  __syncthreads();
+  for (int l = levels - 1; l >= 0; --l) {                    // backward: x_i = L^-T (z_i - U_a x_a - U_b x_b)
+    const int h = 1 << l;
+    const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
+    for (int w = tid; w < ne * nd; w += BCR_THREADS) {
+      const int m = w / nd, d = w - m * nd;
+      const int i = h + m * 2 * h, a = i - h, b = i + h;
+      const bool hasb = b < nb;
+      double t[B];
+#pragma unroll
+      for (int r = 0; r < B; ++r) {
+        double v = xs[(i * B + r) * nd + d];
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+          v = fma(-W(i, Lay::W_UA + r * B + p), xs[(a * B + p) * nd + d], v);
+          if (hasb) v = fma(-W(i, Lay::W_UB + r * B + p), xs[(b * B + p) * nd + d], v);
+        }
+        t[r] = v;
+      }
+#pragma unroll
+      for (int r = B - 1; r >= 0; --r) {
+        double v = t[r];
+#pragma unroll
+        for (int p = r + 1; p < B; ++p) v = fma(-W(i, Lay::W_L + p * B + r), t[p], v);
+        t[r] = v * W(i, Lay::W_I + r);
+      }
+#pragma unroll
+      for (int r = 0; r < B; ++r) xs[(i * B + r) * nd + d] = t[r];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < M * nd; e += BCR_THREADS) {
+    const int row = e / nd, d = e - row * nd;
+    x[(long)row * D + d0 + d] = xs[e];
+  }
+  __syncthreads();
 }
 
 }  // namespace asvgp

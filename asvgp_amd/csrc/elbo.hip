@@ -129,13 +129,24 @@ __global__ __launch_bounds__(64) void elbo_trsv_kernel(const double* L, int M, c
   (void)scale;
 }
 
+// columns 1 .. D-1 of a multi-output rhs, in chunks of as many columns as the (now free) LDS image holds
+template <int K, bool BIG>
+__device__ __forceinline__ void more_columns(const double* b, double* x, int D, int M, double* wsP, double* lds, int lds_doubles) {
+  if (D <= 1) return;
+  __syncthreads();
+  const int nb = (M + K - 1) / K;
+  int chunk = lds_doubles / (nb * K);
+  if (chunk < 1) chunk = 1;
+  for (int d0 = 1; d0 < D; d0 += chunk) bcr_solve_more<K, BIG>(b, x, D, d0, (D - d0 < chunk) ? D - d0 : chunk, M, wsP, lds);
+}
+
 // Both chains by block cyclic reduction, one 256-thread workgroup each (bcr.hpp).
 template <int K, bool TANGENT, bool BIG>
 __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu, const double* dK, const double* P,
                                                                const double* b, int M, double* wsK, double* wsP,
                                                                double* SK, double* dSK, double* SP, double* x,
                                                                double* logdets, int* info, int do_stamps,
-                                                               int first_chain, double /*unused*/) {
+                                                               int first_chain, int D, int lds_doubles) {
   extern __shared__ double lds[];
   double* st = do_stamps ? logdets + 8 : nullptr;  // diagnostic: 24 stamps per chain after the 4 log-det slots
   // do_stamps == 2 (diagnostic): run the solve twice and stamp the second, warm, pass (instruction cache / TLB effects)
@@ -144,7 +155,8 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_kernel(const double* Kuu
       if (TANGENT) bcr_solve<Dual, K, 0, BandPtr<Dual>, BIG>(BandPtr<Dual>{Kuu, dK}, nullptr, M, wsK, lds, BandOut<Dual>{SK, dSK}, nullptr, logdets, info, st);
       else bcr_solve<double, K, 0, BandPtr<double>, BIG>(BandPtr<double>{Kuu, nullptr}, nullptr, M, wsK, lds, BandOut<double>{SK, nullptr}, nullptr, logdets, info, st);
     } else {   // (the split data chain, P formed in the gathers, has its own kernel: elbo_bcr_data_kernel)
-      bcr_solve<double, K, 1, BandPtr<double>, BIG>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr);
+      bcr_solve<double, K, 1, BandPtr<double>, BIG>(BandPtr<double>{P, nullptr}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, st ? st + 24 : nullptr, D);
+      more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
     }
     __syncthreads();
   }
@@ -167,11 +179,12 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_prior_kernel(const doubl
 template <int K, bool BIG>
 __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_data_kernel(const double* Kuu, const double* A, const double* b, int M,
                                                                     double* wsP, double* SP, double* x, double* logdets,
-                                                                    int* info, int do_stamps, double s) {
+                                                                    int* info, int do_stamps, double s, int D, int lds_doubles) {
   extern __shared__ double lds[];
   double* st = do_stamps ? logdets + 8 : nullptr;
   bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1,
-                                         st ? st + 24 : nullptr);
+                                         st ? st + 24 : nullptr, D);
+  more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
 }
 
 // Planned prior chain (band algorithm 3): block 0 = the P chain (as elbo_bcr_data_kernel), block 1 = the backward pass of the
@@ -181,11 +194,12 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
                                                                   double* wsP, double* SP, double* x, double* logdets, int* info,
                                                                   double s, const double* tab, int n_rec, const int* node_rec,
                                                                   double* wsK, double* SK, double* dSK,
-                                                                  unsigned long long* done_flag, unsigned long long seq) {
+                                                                  unsigned long long* done_flag, unsigned long long seq, int D, int lds_doubles) {
   extern __shared__ double lds[];
-  if (blockIdx.x == 0)
-    bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, nullptr);
-  else
+  if (blockIdx.x == 0) {
+    bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, nullptr, D);
+    more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
+  } else
     bcr_backward_pre<K>(tab, n_rec, node_rec, M, wsK, lds, BandOut<Dual>{SK, dSK}, logdets, info, done_flag, seq);
 }
 
@@ -344,7 +358,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
   if (algo == 3 && !have_plan) { set_error("band algorithm 3 needs asvgp_prior_plan_1d for this (M, k, kernel)"); return ASVGP_ERR_BAD_ARG; }
   size_t ldsK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0>(nb) : bcr_lds_doubles<double, K, 0>(nb));
   size_t ldsP = sizeof(double) * bcr_lds_doubles<double, K, 1>(nb);
-  bool planned = (D == 1) && have_plan && (algo == 0 || algo == 3);
+  bool planned = have_plan && (algo == 0 || algo == 3);
   size_t lds_bytes = planned ? ldsP : (ldsK > ldsP ? ldsK : ldsP);
   bool fits = lds_bytes <= 160 * 1024 - 256;
   bool big = false;   // BIG layout (bcr.hpp): twice the nodes, couplings in an L2-resident plane - M up to 4096 at k = 4
@@ -355,7 +369,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     size_t bb = planned ? bP : (bK > bP ? bK : bP);
     if (bb <= 160 * 1024 - 256) { big = true; fits = true; lds_bytes = bb; }
   }
-  use_bcr = (D == 1) && (algo == 2 || algo == 3 || (algo == 0 && fits));
+  use_bcr = (algo == 2 || algo == 3 || (algo == 0 && fits));   // (D > 1: column 0 rides through the levels, the others replay the factors)
   planned = planned && use_bcr;
   if (part != 0 && (!use_bcr || planned)) {
     // split scheduling exists for the all-GPU BCR path only: the sweeps and the planned chain run as one unit in the data call
@@ -380,7 +394,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     hipLaunchKernelGGL(kern, dim3(2), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                        h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK,
-                       h->done_dev + slot, seq);
+                       h->done_dev + slot, seq, (int)D, (int)(lds_bytes / sizeof(double)));
     if (scale_alpha) {
       long n = M * D;
       hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
@@ -411,12 +425,12 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
       hipLaunchKernelGGL(kern, dim3(1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info,
-                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, s);
+                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, s, (int)D, (int)(lds_bytes / sizeof(double)));
     } else {
       auto kern = big ? elbo_bcr_kernel<K, TANGENT, HAS_BIG> : elbo_bcr_kernel<K, TANGENT, false>;
       hipLaunchKernelGGL(kern, dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
-                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, 0.0);
+                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, (int)D, (int)(lds_bytes / sizeof(double)));
     }
     if (part == 1) {
       if (h->sync_on) (void)hipEventRecord(h->evP, st);

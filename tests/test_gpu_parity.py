@@ -334,25 +334,36 @@ def test_elbo_synthetic_medium_vs_oracle(A):
         np.testing.assert_allclose(r[1:4], og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)), err_msg=str((kd, order)))
 
 
-def test_two_output_columns(A):
-    rng = np.random.default_rng(4)
-    N, M = 3000, 40
+@pytest.mark.parametrize("M,order,D,N", [(40, 3, 2, 3000), (1024, 4, 3, 30000), (2048, 4, 7, 20000), (257, 2, 2, 5000)])
+def test_multi_output_columns_on_every_band_algorithm(A, M, order, D, N):
+    """y with D > 1 columns (gpr.py:75,80-82: solve_triang_mat with an M x D rhs; the bound sums over the columns): the first
+    column rides through the cyclic-reduction levels, the others replay the stored factors (bcr_solve_more) - on the planned
+    chain (auto), the all-GPU chains (2) and the sequential sweeps (1)."""
+    rng = np.random.default_rng(4 + M)
     x = rng.uniform(0.01, 0.99, N)
-    y = np.stack([np.sin(9 * x), np.cos(5 * x)], 1) + 0.1 * rng.normal(size=(N, 2))
-    bs = A.B3Spline(0, 1, M)
-    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=0.9, lengthscales=0.2), bs)
+    y = np.stack([np.sin((5 + 2 * d) * x + d) for d in range(D)], 1) + 0.1 * rng.normal(size=(N, D))
+    bs = _mk_basis(A, order, 0, 1, M)
+    l = 0.2 if M < 100 else 0.02
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=0.9, lengthscales=l), bs)
     model.likelihood.variance.assign(0.05)
-    ob = O.Basis(3, 0, 1, M)
+    ob = O.Basis(order, 0, 1, M)
     Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
-    oe, og, _ = O.elbo_grad_1d(ob, 1, Ab, b, yy, N, 0.9, 0.2, 0.05)
-    r = model.elbo_and_grad().cpu().numpy()
-    assert abs(r[0] - oe) <= 1e-9 * abs(oe)
-    np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
+    oe, og, _ = O.elbo_grad_1d(ob, 1, Ab, b, yy, N, 0.9, l, 0.05)
     xs = rng.uniform(0.01, 0.99, 100)
-    om, ov = O.predict_f_1d(ob, 1, Ab, b, 0.9, 0.2, 0.05, xs)
-    mean, var = model.predict_f(xs.reshape(-1, 1))
-    np.testing.assert_allclose(mean, om, atol=1e-8)
-    np.testing.assert_allclose(var, ov, atol=1e-8)
+    om, ov = O.predict_f_1d_banded(ob, 1, Ab, b, 0.9, l, 0.05, xs)
+    try:
+        for algo in (0, 2, 1):
+            A.set_band_algorithm(algo)
+            model._post = None
+            r = model.elbo_and_grad().cpu().numpy()
+            assert abs(r[0] - oe) <= elbo_tol(oe, N, 0.9, 0.05, yy, bcr=(algo == 2)), (algo, r[0], oe)
+            np.testing.assert_allclose(r[1:4], og, rtol=1e-6, err_msg="algo %d" % algo)
+            mean, var = model.predict_f(xs.reshape(-1, 1))
+            assert mean.shape == (100, D)
+            np.testing.assert_allclose(mean, om, atol=1e-8)
+            np.testing.assert_allclose(var, ov, atol=1e-8)
+    finally:
+        A.set_band_algorithm(0)
 
 
 def test_notebook_golden_end_to_end(A, S):
