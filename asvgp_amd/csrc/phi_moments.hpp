@@ -24,8 +24,8 @@
 // memory access - a dependent ds_read would queue behind the 16 waves' outstanding LDS atomics, and a dependent global gather
 // adds a second memory round trip per batch (measured: 57 us with the atomics switched off against 35 us).  Other meshes
 // (the float32 linspace of Python-float endpoints) take the table from global memory.
-// Sorted / time-series input: a wave whose whole batch sits in ONE cell sums its moments across the wave on the VALU (DPP) and
-// commits them from one lane (full double -> int64 conversion) instead of 64 same-address atomics per plane.
+// Sorted / time-series input: a wave whose whole batch sits in ONE cell sums its moments per lane, across batches, and commits a
+// run when the cell changes (DPP wave reduction, one lane, full double -> int64 conversion) instead of 64 same-address atomics.
 // What bounds it (rocprofv3 PMC + compile-time ablations, profiles/r02_phi_*): 83 us = 8 (prologue / epilogue) + 75; with the
 // streaming loads switched off it still takes 82 us, with the atomics switched off 45 us - the memory stream (36 us at 4.4 TB/s)
 // is fully hidden, and what remains is 45-50 us of LDS-pipe time (13 cycles per random-address ds_add_u64, 64 % of them
@@ -195,25 +195,44 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
       for (int i = 0; i <= K; ++i) __hip_atomic_fetch_add(ovr + c + K - i, v[i] * yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-  // the whole wave in cell cw (sorted / time-series input): VALU wave sums (DPP), one lane commits
-  auto wave_cell = [&](int cw, double sa, double sb, double ya, double yb) __attribute__((always_inline)) {
-    yy = fma(ya, ya, fma(yb, yb, yy));
-    if (lane == 0) __hip_atomic_fetch_add(cnt + cw, 128u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    double pa = sa, pb = sb;
+  // the whole wave in ONE cell (sorted / time-series input: a wave stays in a cell for dozens of batches): the moments are summed
+  // per lane across batches and leave through ONE wave reduction (DPP, VALU only) + single-lane commits when the cell changes
+  double raS[NS], raR[K + 1];
+  int rcell = -1, rn = 0;                                    // wave-uniform: cell of the open run, batches in it
+#pragma unroll
+  for (int p = 0; p < NS; ++p) raS[p] = 0.0;
+#pragma unroll
+  for (int i = 0; i <= K; ++i) raR[i] = 0.0;
+  auto run_flush = [&]() __attribute__((always_inline)) {
+    if (rcell < 0) return;
+    if (lane == 0) __hip_atomic_fetch_add(cnt + rcell, 128u * (unsigned)rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int p = 1; p <= NS; ++p) {
-      const double t = wave_sum_dpp(pa + pb);
-      if (lane == 0) lds_add_u64(planes + (size_t)(p - 1) * CS + cw, (unsigned long long)__double2ll_rn(ldexp(t, s0 + p)));
-      pa *= sa; pb *= sb;
+      const double t = wave_sum_dpp(raS[p - 1]);
+      if (lane == 0) lds_add_u64(planes + (size_t)(p - 1) * CS + rcell, (unsigned long long)__double2ll_rn(ldexp(t, s0 + p)));
+      raS[p - 1] = 0.0;
     }
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+      const double t = wave_sum_dpp(raR[i]);
+      if (lane == 0) lds_add_u64(rhs + rcell + K - i, (unsigned long long)__double2ll_rn(ldexp(t, s0 - E)));
+      raR[i] = 0.0;
+    }
+    rcell = -1;
+    rn = 0;
+  };
+  auto wave_cell = [&](int cw, double sa, double sb, double ya, double yb) __attribute__((always_inline)) {
+    if (cw != rcell) { run_flush(); rcell = cw; }
+    ++rn;
+    yy = fma(ya, ya, fma(yb, yb, yy));
+    double pa = sa, pb = sb;
+#pragma unroll
+    for (int p = 1; p <= NS; ++p) { raS[p - 1] += pa + pb; pa *= sa; pb *= sb; }
     double va[K + 1], vb[K + 1];
     bspline_pieces<K>(sa + 0.5, va);
     bspline_pieces<K>(sb + 0.5, vb);
 #pragma unroll
-    for (int i = 0; i <= K; ++i) {
-      const double t = wave_sum_dpp(fma(va[i], ya, vb[i] * yb));
-      if (lane == 0) lds_add_u64(rhs + cw + K - i, (unsigned long long)__double2ll_rn(ldexp(t, s0 - E)));
-    }
+    for (int i = 0; i <= K; ++i) raR[i] += fma(va[i], ya, vb[i] * yb);
   };
 
   // ---- streaming loop.  One batch = a 16-B pair (x0, x1), (y0, y1) per lane; two batches in flight per wave (ping-pong
@@ -237,12 +256,12 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
       int c0 = 0, c1 = 0;
       double sa = 0.0, sb = 0.0;
       if (REG && full) {                                   // (uniform) branch-free classification
-        const int g0 = mq_guess(xc.x, m0, inv_delta, n_mesh), g1 = mq_guess(xc.y, m0, inv_delta, n_mesh);
-        const double l0 = knot(g0), h0 = knot(g0 + 1), l1 = knot(g1), h1 = knot(g1 + 1);
-        c0 = g0 - ((!(l0 < xc.x) && g0 > 0) ? 1 : 0) + (((h0 < xc.x) && g0 < n_mesh - 2) ? 1 : 0);
-        c1 = g1 - ((!(l1 < xc.y) && g1 > 0) ? 1 : 0) + (((h1 < xc.y) && g1 < n_mesh - 2) ? 1 : 0);
+        // the arithmetic guess IS the cell unless x sits within rounding of a knot: validated against the two knots around it
+        // (basis.py:58-59: mesh[c] < x <= mesh[c+1], open ends at the boundary cells); a miss anywhere in the wave -> general code
+        c0 = mq_guess(xc.x, m0, inv_delta, n_mesh);
+        c1 = mq_guess(xc.y, m0, inv_delta, n_mesh);
         const double u0 = knot(c0), u0n = knot(c0 + 1), u1 = knot(c1), u1n = knot(c1 + 1);
-        const bool v0 = (c0 == 0 || u0 < xc.x) && (c0 == n_mesh - 2 || !(u0n < xc.x));    // basis.py:58-59 holds for c0
+        const bool v0 = (c0 == 0 || u0 < xc.x) && (c0 == n_mesh - 2 || !(u0n < xc.x));
         const bool v1 = (c1 == 0 || u1 < xc.y) && (c1 == n_mesh - 2 || !(u1n < xc.y));
         sa = (xc.x - u0) * inv_delta - 0.5;
         sb = (xc.y - u1) * inv_delta - 0.5;
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
         if (__all(c0 == cw && c1 == cw)) {
           wave_cell(cw, sa, sb, yc.x, yc.y);
         } else {
+          run_flush();
           yy = fma(yc.x, yc.x, fma(yc.y, yc.y, yy));
           __hip_atomic_fetch_add(cnt + c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(cnt + c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -282,7 +302,10 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
         const bool same = have && c0 == cw && c1 == cw && fabs(sa) <= 0.50001 && fabs(sb) <= 0.50001 &&
                           fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
         if (__all(same)) wave_cell(cw, sa, sb, yc.x, yc.y);
-        else if (have) { scatter(c0, sa, yc.x); scatter(c1, sb, yc.y); }
+        else {
+          run_flush();
+          if (have) { scatter(c0, sa, yc.x); scatter(c1, sb, yc.y); }
+        }
       }
     };
     fetch(0, xA, yA);
@@ -291,6 +314,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
       batch(it, xA, yA);
       if (it + 1 < n_it) batch(it + 1, xB, yB);
     }
+    run_flush();
   }
   if ((end & 1) && end > beg && tid == 0) {                // odd tail point (only the last workgroup with points can have one)
     double u;

@@ -38,9 +38,10 @@ def synth(N, seed=1234):
 def measured_traffic(n_local):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B streaming reads at 64 B).  The PMC passes
-    cannot run inside this process; the committed summary profiles/r01_phi_traffic.json is used when it was taken on
-    the same per-rank workload, otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_phi_traffic.json")
+    cannot run inside this process; the committed summary profiles/r02_phi_traffic.json (same kernel, same per-rank workload,
+    taken with tools/collect_profiles.sh) is quoted when the workload matches, otherwise null.  It is a labelled constant from
+    the committed profile, not a measurement of this run."""
+    path = os.path.join(ROOT, "profiles", "r02_phi_traffic.json")
     try:
         d = json.load(open(path))
         if int(d["points_per_launch"]) == int(n_local):
@@ -298,8 +299,9 @@ def main():
                           "note": "planned prior chain: host forward pass under the Phi pass, Kuu backward pass beside the P chain"
                                   if not two_stream else "the theta-only prior chain (Kuu, tangent) runs on a second stream under the Phi pass"},
             "phi_pass_mpoints_per_s": n_local * world / (t_phi * 1e-6) / 1e6 if t_phi > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "phi_accumulate_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "phi_moment_kernel<4, 2048, true> (Phi pass, algorithm 5)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
+                         "traffic_source": "profiles/r02_phi_traffic.json (rocprofv3 PMC passes of the same kernel and workload; not re-measured in this run)",
                          "kernel_us": kern_us, "launches": launches.value,
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local},
             "elbo": float(out4[0]), "grad": [float(v) for v in out4[1:4]],

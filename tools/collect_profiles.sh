@@ -1,15 +1,18 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): kernel-trace stats of the bench command and the two separate PMC passes of the Phi kernel.
-# Outputs under gpurun_out/prof_final/ ; summarised into profiles/ by tools/summarise_profiles.py (run afterwards, on CPU).
+# Run on the GPU box (gpurun): kernel-trace stats of the bench command, the two separate HBM-traffic PMC passes and the SQ counter
+# passes of the Phi kernel.  Outputs under gpurun_out/prof_r02/ ; summarised into profiles/ by tools/summarise_profiles.py (run
+# afterwards, on CPU).  usage: bash tools/collect_profiles.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_final
+O=$R/gpurun_out/prof_r02
 rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err || exit 1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 tools/phi_pmc.py > $O/fetch.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 tools/phi_pmc.py > $O/write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -- python3 tools/phi_pmc.py > $O/sq.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --kernel-trace --output-format csv -d $O/sq2 -- python3 tools/phi_pmc.py > $O/sq2.log 2>&1 || exit 1
 timeout -k 10 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+timeout -k 10 300 python3 bench.py --sorted --no-cpu-baseline > $O/bench_sorted.json 2> $O/bench_sorted.err || exit 1
 find $O -name "*.csv" | head -30

@@ -1,9 +1,11 @@
-"""Summarise gpurun_out/prof_final (tools/collect_profiles.sh) into profiles/ (tracked)."""
+"""Summarise gpurun_out/prof_r02 (tools/collect_profiles.sh) into profiles/ (tracked).  usage: python tools/summarise_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_final")
+src = os.path.join(ROOT, "gpurun_out", "prof_r02")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+KERNEL = "phi_moment_kernel"
+
 
 def newest(pattern):
     """gpurun merges new files into gpurun_out/ without deleting older runs: keep only the most recent match."""
@@ -11,22 +13,23 @@ def newest(pattern):
     return fs[-1:]
 
 
-def counters(sub, kernel="phi_accumulate_kernel"):
+def counters(sub):
     out = {}
     for f in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
-            if kernel in row["Kernel_Name"]:
+            if KERNEL in row["Kernel_Name"]:
                 out.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
 ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, tag + "_bench.json"))
+shutil.copy(os.path.join(src, "bench_sorted.json"), os.path.join(dst, tag + "_bench_sorted.json"))
 fetch, nf = counters("fetch")
 write, nw = counters("write")
-name = None
+name, avg_ns = None, 0.0
 for row in csv.DictReader(open(ks)):
-    if "phi_accumulate_kernel" in row["Name"]:
+    if KERNEL in row["Name"]:
         name, avg_ns = row["Name"].split("(")[0].replace("void asvgp::", ""), float(row["AverageNs"])
 traffic = {
     "kernel": name, "points_per_launch": 10_000_000,
@@ -38,10 +41,10 @@ traffic = {
     "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 tools/phi_pmc.py "
                "(tools/collect_profiles.sh; launches averaged: %d / %d)" % (nf["FETCH_SIZE"], nw["WRITE_SIZE"]),
 }
-json.dump(traffic, open(os.path.join(dst, "r01_phi_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, tag + "_phi_traffic.json"), "w"), indent=1)
 sq, _ = counters("sq")
-p = os.path.join(dst, "r01_phi_pmc_counters.json")
-old = json.load(open(p)) if os.path.exists(p) else {}
-old[name + " (fixed-point band, final)"] = sq
-json.dump(old, open(p, "w"), indent=1)
+sq2, _ = counters("sq2")
+sq.update(sq2)
+json.dump({name: sq, "note": "rocprofv3 --pmc, two passes of 8 SQ counters each, averaged over the launches of tools/phi_pmc.py (chip totals)"},
+          open(os.path.join(dst, tag + "_phi_pmc_counters.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)); print(sq)
