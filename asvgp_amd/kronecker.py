@@ -63,12 +63,3 @@ def make_kvs_two_sparse(A, B):
     M1 = sparse_repeats(A, B.shape[0]).to_dense()
     M2 = sparse_tile(B, A.shape[0]).to_dense()
     return (M1 * M2).to_sparse_csr()
-
-
-def kron_log_determinant(Kuu, M, d):
-    """kronecker.py:35-40: log|K_1 (x) ... (x) K_d| = sum_i (M^d / M) log|K_i| with equal sizes M (the reference
-    multiplies by the whole list N instead of its element n - unused there; the intended formula is implemented)."""
-    from . import banded
-    L = [banded.cholesky_band(kuu) for kuu in Kuu]
-    logdets = [torch.log(l[0, :] ** 2).sum() for l in L]
-    return sum((float(M) ** d / float(M)) * ld for ld in logdets)

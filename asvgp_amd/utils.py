@@ -38,23 +38,11 @@ def band_to_dense_sym(K_lower):
     return banded.unpack_banded_matrix_to_dense(symmetrise_banded(K_lower), k, k)
 
 
-def band_to_tfband(K_lower):
-    """utils.py:35-37: lower band -> the upper band reversed along the diagonal axis (tf.linalg band layout)."""
-    lower_bandwidth = K_lower.shape[0] - 1
-    return torch.flip(banded.transpose_band(K_lower, lower_bandwidth, 0), dims=[0])
-
-
 def _kron_dense(mats):
     out = mats[0]
     for m in mats[1:]:
         out = torch.kron(out, m)
     return out
-
-
-def band_to_kron_band(K_sparse, mat_bandwidth):
-    """utils.py:39-43 (dense Kronecker product of the unpacked LOWER bands, repacked with the given bandwidth)."""
-    K_dense = [banded.unpack_banded_matrix_to_dense(k, mat_bandwidth, 0) for k in K_sparse]
-    return banded.pack_dense_matrix_to_banded(_kron_dense(K_dense), mat_bandwidth, 0)
 
 
 def bands_to_kron_cholesky(K_sparse, mat_bandwidth):

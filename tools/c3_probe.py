@@ -1,18 +1,31 @@
-"""BASELINE config 3 shape on one rank: N/8 = 1.25M points, M = 4096, Matern-5/2, B4Spline: Phi pass and ELBO+grad timings."""
+"""BASELINE config 3 (N = 10M, M = 4096, Matern-5/2, B4Spline): timings per band algorithm and parity of the statistics, the
+bound and the gradient against the oracle (fp64 reference order and long double).  usage: python tools/c3_probe.py [N]
+(N = 1_250_000 is one rank's share of the 8-GPU run)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A
-N, M = 1_250_000, 4096
-g = torch.Generator(device="cuda").manual_seed(1)
-x = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * (1 - 2e-9) + 1e-9
-y = torch.sin(20 * x) + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
-model = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern52(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
-model.likelihood.variance.assign(0.01)
+from oracle import asvgp_oracle as O
+N, M = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 4096
+v, l, s = 1.0, 0.05, 0.01
+rng = np.random.default_rng(1)
+x = rng.uniform(1e-9, 1 - 1e-9, N); y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+model = A.GPR_1d((torch.from_numpy(x).cuda().reshape(-1, 1), torch.from_numpy(y).cuda().reshape(-1, 1)), A.Matern52(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
+model.likelihood.variance.assign(s)
 def t(f, n=10):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-print("phi pass  %.1f us" % t(model.phi_pass))
-for algo in (0, 1):
+print("phi pass  %.1f us" % t(model.phi_pass), flush=True)
+ob = O.Basis(4, 0, 1, M)
+Ab, b, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+ref = np.concatenate([Ab.reshape(-1), b.reshape(-1), [yy]])
+print("statistics: max |diff| / max |ref| = %.2e" % (np.max(np.abs(model._stats.cpu().numpy() - ref)) / np.max(np.abs(ref))), flush=True)
+oe, og, _ = O.elbo_grad_1d(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
+ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
+print("oracle fp64 %.6f  long double %.6f  (|diff| %.3g)" % (oe, ee, abs(oe - ee)))
+for algo in (0, 1, 2, 3):
     A.set_band_algorithm(algo)
-    print("algo", algo, "elbo+grad %.1f us" % t(lambda: model.elbo_and_grad(check_pd=False)), model.elbo_and_grad().cpu().numpy()[:4])
+    r = model.elbo_and_grad().cpu().numpy()
+    print("band algorithm %d: elbo+grad %.1f us | ELBO - long double %+.3e | gradient rel %.2e" % (
+        algo, t(lambda: model.elbo_and_grad(check_pd=False)), r[0] - ee, np.max(np.abs(r[1:4] - ge) / np.abs(ge))), flush=True)
+A.set_band_algorithm(0)

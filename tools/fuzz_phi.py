@@ -1,5 +1,5 @@
 """Randomised parity sweep of the Phi pass against the oracle (not a unit test: run on the GPU box, prints failures).
-usage: python tools/fuzz_phi.py [n_cases] [seed]"""
+usage: python tools/fuzz_phi.py [n_cases] [seed] [n_big]      n_big: additional cases at N = 10M (headline size), M in {512..4096}"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A
@@ -7,11 +7,14 @@ from oracle import asvgp_oracle as O
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 min_m = {1: 4, 2: 7, 3: 9, 4: 12, 5: 13, 6: 15}
+n_big = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 fails = 0
-for case in range(n_cases):
+for case in range(n_cases + n_big):
     order = int(rng.integers(1, 7))
     M = int(rng.integers(min_m[order], 40)) if rng.random() < 0.5 else int(rng.integers(40, 5000))
     N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 2047, 2048, 2049, 4097])) if rng.random() < 0.3 else int(rng.integers(1, 300000))
+    if case >= n_cases:
+        order, M, N = int(rng.choice([3, 4, 4, 5])), int(rng.choice([512, 1000, 2048, 2048, 4096])), 10_000_000
     a, b = (0, 1) if rng.random() < 0.7 else (-3.5, 10.5)
     dist = rng.choice(["uniform", "sorted", "clustered", "repeats", "two_cells"])
     lo, hi = a + 1e-9 * (b - a), b - 1e-9 * (b - a)
@@ -23,7 +26,7 @@ for case in range(n_cases):
     yscale = 10.0 ** rng.integers(-8, 9)
     y = yscale * rng.standard_normal((N, 1))
     if rng.random() < 0.3 and N > 10: y[rng.integers(0, N, 3)] *= 1e6
-    algo = int(rng.choice([0, 1, 2, 3, 4]))
+    algo = int(rng.choice([0, 1, 3, 5]))      # auto | fp64 scatter | fixed-point band scatter | fixed-point moments
     A.set_phi_algorithm(algo)
     try:
         bs = getattr(A, "B%dSpline" % order)(a, b, M)

@@ -12,7 +12,7 @@ def t(f, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 for name, xs in (("unsorted", x), ("sorted", np.sort(x)), ("clustered", xc)):
     xd = torch.from_numpy(xs).cuda().reshape(-1, 1); yd = torch.from_numpy(y).cuda().reshape(-1, 1)
-    for algo in (2, 3, 4):
+    for algo in (1, 3, 5):
         A.set_phi_algorithm(algo)
         m = A.GPR_1d((xd, yd), A.Matern32(), A.B4Spline(0, 1, M))
         print("%-10s algo %d  %.1f us" % (name, algo, t(m.phi_pass)), flush=True)
