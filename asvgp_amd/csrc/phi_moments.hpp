@@ -60,6 +60,11 @@ struct MqArgs {
   int s0;
 };
 
+// |s| = |t - 1/2| bound of an accepted point.  Exactly 1/2 on an exact linspace; the float32-linspace meshes of basis.py:17 wobble by
+// ulp32(|knot|) / delta (3e-4 of a cell at [-3.5, 10.5], M = 5000), and the reference extrapolates its pieces there just the same.
+// The fixed-point headroom (scale 2^(s0 + p) for s^p, s0 = 62 - ceil(log2(points per workgroup))) needs (2 |s|)^(2K) < 2.
+#define MQ_SMAX 0.52
+
 // knot i of numpy.linspace: i * step rounded, THEN + start rounded.  (HIP's __dmul_rn / __dadd_rn are plain * and + and may be
 // contracted into an fma - one rounding, a different knot in ~40 % of the cases when start != 0; the pragma forbids it.)
 __device__ __forceinline__ double mq_linspace_knot(int i, double step, double m0) {
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
     return mq_resolve(x, i, mesh[i], mesh[i + 1], mesh, n_mesh, u);
   };
   auto scatter = [&](int c, double s, double yv) __attribute__((always_inline)) {
-    if (!(fabs(s) <= 0.50001)) { ++nbad; return; }         // outside the mesh (or NaN): reported, never accumulated
+    if (!(fabs(s) <= MQ_SMAX)) { ++nbad; return; }           // outside the mesh (or NaN): reported, never accumulated
     yy = fma(yv, yv, yy);
     double pw = s;
     __hip_atomic_fetch_add(cnt + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
         const bool v1 = (c1 == 0 || u1 < xc.y) && (c1 == n_mesh - 2 || !(u1n < xc.y));
         sa = (xc.x - u0) * inv_delta - 0.5;
         sb = (xc.y - u1) * inv_delta - 0.5;
-        const bool good = v0 && v1 && fabs(sa) <= 0.50001 && fabs(sb) <= 0.50001 && fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
+        const bool good = v0 && v1 && fabs(sa) <= MQ_SMAX && fabs(sb) <= MQ_SMAX && fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
         fast = __all(good);
       }
       if (fast) {
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
         c0 = cell_of(xc.x, u0); c1 = cell_of(xc.y, u1);
         sa = (xc.x - u0) * inv_delta - 0.5; sb = (xc.y - u1) * inv_delta - 0.5;
         const int cw = __builtin_amdgcn_readfirstlane(c0);
-        const bool same = have && c0 == cw && c1 == cw && fabs(sa) <= 0.50001 && fabs(sb) <= 0.50001 &&
+        const bool same = have && c0 == cw && c1 == cw && fabs(sa) <= MQ_SMAX && fabs(sb) <= MQ_SMAX &&
                           fabs(yc.x) <= y0 && fabs(yc.y) <= y0;
         if (__all(same)) wave_cell(cw, sa, sb, yc.x, yc.y);
         else {

@@ -525,6 +525,35 @@ def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
     assert np.max(np.abs(m._stats.cpu().numpy() - got[1])) <= 1e-12 * np.max(np.abs(got[1]))
 
 
+@pytest.mark.parametrize("order,M,N,dist", [(3, 1442, 45014, "ends"), (2, 1642, 242047, "clustered"), (4, 2048, 100000, "uniform")])
+def test_phi_pass_on_float32_linspace_mesh_cells_that_are_not_exactly_delta_wide(A, order, M, N, dist):
+    """basis.py:17 builds the knots of (-3.5, 10.5) in float32 (tf.linspace of Python floats): the cells are up to ulp32(10.5)/delta
+    = 1e-4 wider than delta, so t = (x - knot)/delta reaches 1.0001 and the reference simply evaluates its pieces there.  (Found
+    by tools/fuzz_phi.py: the moment kernel's first 'outside the mesh' test was |t - 1/2| <= 0.50001 and reported such points.)"""
+    rng = np.random.default_rng(order * M)
+    a, b = -3.5, 10.5
+    lo, hi = a + 1e-9 * (b - a), b - 1e-9 * (b - a)
+    if dist == "ends":
+        x = rng.choice([lo, a + 0.3 * (b - a), hi], N)
+    elif dist == "clustered":
+        x = np.clip(a + (b - a) * (0.5 + 0.03 * rng.standard_normal(N)), lo, hi)
+    else:
+        x = rng.uniform(lo, hi, N)
+    y = 100.0 * rng.standard_normal((N, 1))
+    ob = O.Basis(order, a, b, M)
+    band, rhs, yy = O.sufficient_stats_direct(ob, x, y)
+    try:
+        for algo in (0, 3, 5):
+            A.set_phi_algorithm(algo)
+            m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), _mk_basis(A, order, a, b, M))
+            tol = 1e-12 + 4e-16 * N          # (the oracle's sequential sums lose ~N eps on heavily repeated x)
+            assert np.max(np.abs(m.KufKfu.cpu().numpy() - band)) <= tol * np.max(np.abs(band)), algo
+            assert np.max(np.abs(m.Kuf_y.cpu().numpy() - rhs)) <= tol * np.max(np.abs(rhs)), algo
+            assert abs(m.tr_yTy.item() - yy) <= tol * yy, algo
+    finally:
+        A.set_phi_algorithm(0)
+
+
 # ------------------------------------------------------------------------------------------------ Kronecker 2-D
 def _blockband_to_dense(blk, k, m1, m2):
     """unpack the lower block band [off][col] into a dense symmetric (m1*m2)^2 matrix (test helper)."""

@@ -42,6 +42,8 @@ for case in range(n_cases + n_big):
         tol = 1e-12 + 4e-16 * N      # (the oracle's own sequential fp64 sums lose ~N eps on heavily repeated x)
         ok = eb <= tol and er <= tol and ey <= tol and zero_ok
     except Exception as e:  # noqa
+        if algo == 5 and "ASVGP_ERR_UNSUPPORTED" in repr(e):
+            continue                  # forced moments beyond their LDS image / alignment (auto falls back to 3): not a parity case
         ok, eb, er, ey = False, -1, -1, -1
         print("EXC", repr(e)[:200])
     if not ok:
