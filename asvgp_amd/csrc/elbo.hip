@@ -187,22 +187,6 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_bcr_data_kernel(const double
   more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
 }
 
-// Planned prior chain (band algorithm 3): block 0 = the P chain (as elbo_bcr_data_kernel), block 1 = the backward pass of the
-// Kuu chain from the host's factor table.  ONE launch for both chains: neither reads the other's output.
-template <int K, bool BIG>
-__global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* Kuu, const double* A, const double* b, int M,
-                                                                  double* wsP, double* SP, double* x, double* logdets, int* info,
-                                                                  double s, const double* tab, int n_rec, const int* node_rec,
-                                                                  double* wsK, double* SK, double* dSK,
-                                                                  unsigned long long* done_flag, unsigned long long seq, int D, int lds_doubles) {
-  extern __shared__ double lds[];
-  if (blockIdx.x == 0) {
-    bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, nullptr, D);
-    more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
-  } else
-    bcr_backward_pre<K>(tab, n_rec, node_rec, M, wsK, lds, BandOut<Dual>{SK, dSK}, logdets, info, done_flag, seq);
-}
-
 // sym-band quadratic form helper: x^T sym(S) x over columns handled by this thread
 // (branch-free: out-of-range neighbours are clamped and their band entry is a structural zero of the right-padded band)
 template <int KT>
@@ -220,19 +204,18 @@ __device__ __forceinline__ double quad_col(const double* S, long M, long j, cons
 
 struct ElboScalars { double v, l, s, N; };
 
+// The 14 band traces / quadratic forms of the bound and its gradient over `nblk` cooperating workgroups (this one is `bid`);
+// partial sums meet in `gacc` through device-scope atomics, the last workgroup to arrive writes the result and re-arms gacc /
+// ticket (and `rearm`, the chain-arrival counter of the fused launch) for the next call.  `part`: 16 * 14 doubles of LDS.
 template <int KT>
-__global__ __launch_bounds__(256) void elbo_finalize_kernel(
-    const double* __restrict__ stats, const double* __restrict__ Kuu, const double* __restrict__ dK,
+__device__ __forceinline__ void elbo_finalize_body(
+    int bid, int nblk, double* part_lds, const double* __restrict__ stats, const double* __restrict__ Kuu, const double* __restrict__ dK,
     const double* __restrict__ LK, const double* __restrict__ LP, const double* __restrict__ SK,
     const double* __restrict__ dSK, const double* __restrict__ SP, const double* __restrict__ c,
-    const double* __restrict__ alpha, const double* __restrict__ logdets, long M, int k_rt, long D, ElboScalars th,
-    double alpha_scale, double* __restrict__ gacc, unsigned* __restrict__ ticket, double* __restrict__ out) {
-  // grid of FIN_BLOCKS workgroups (a single one is limited by one CU's L1 bandwidth: ~740 KB of bands at M = 2048);
-  // partial sums meet in `gacc` through device-scope atomics, the last workgroup to arrive writes the result and
-  // re-arms gacc / ticket for the next call.
-  __shared__ double scratch[16];
+    const double* __restrict__ alpha, const double* __restrict__ logdets, long M, long D, ElboScalars th,
+    double alpha_scale, double* __restrict__ gacc, unsigned* __restrict__ ticket, unsigned* __restrict__ rearm, double* __restrict__ out) {
+  // (a single workgroup is limited by one CU's L1 bandwidth: ~740 KB of bands at M = 2048)
   constexpr int k = KT;   // compile-time bandwidth: the per-column loops unroll and their loads issue together
-  (void)k_rt;
   const double* A = stats;
   const double* b = stats + (long)(k + 1) * M;
   const double yy = stats[(long)(k + 1) * M + M * D];
@@ -240,7 +223,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (long)gridDim.x * blockDim.x) {
+  for (long j = (long)bid * blockDim.x + threadIdx.x; j < M; j += (long)nblk * blockDim.x) {
     if (!logdets) {
       double lk = LK[j], lp = LP[j];
       acc[LOGK] += log(lk * lk);  // gpr.py:57  log(square(L[0,:]))
@@ -271,7 +254,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
     }
   }
   // one shuffle tree per accumulator, ONE barrier pair for all of them
-  __shared__ double part[16][NACC];
+  double (*part)[NACC] = reinterpret_cast<double (*)[NACC]>(part_lds);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
@@ -284,15 +267,15 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
 #pragma unroll
     for (int i = 0; i < NACC; ++i) tot[i] = wave_sum_dpp(lane < nw ? part[lane][i] : 0.0);
   }
-  (void)scratch;
-  __shared__ int is_last;
+  int* is_last_p = reinterpret_cast<int*>(part_lds + 16 * NACC);
+#define is_last (*is_last_p)
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
       if (tot[i] != 0.0) __hip_atomic_fetch_add(gacc + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == gridDim.x - 1);
+    is_last = (t == (unsigned)nblk - 1);
   }
   __syncthreads();
   if (!is_last) return;
@@ -303,6 +286,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
 #pragma unroll
     for (int i = 0; i < NACC; ++i) __hip_atomic_store(gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rearm) __hip_atomic_store(rearm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double v = th.v, s = th.s, N = th.N, Dd = (double)D;
     // `alpha` may still be the unscaled solve x = P^-1 b (BCR path): alpha = x * alpha_scale; quadratic forms scale^2
     tot[AKA] *= alpha_scale * alpha_scale; tot[ADKA] *= alpha_scale * alpha_scale; tot[AAA] *= alpha_scale * alpha_scale;
@@ -329,6 +313,94 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
     out[0] = elbo; out[1] = d_v; out[2] = d_l; out[3] = d_s;
     out[4] = tot[LOGK]; out[5] = tot[LOGP]; out[6] = tot[TRKA]; out[7] = tot[CC];
   }
+#undef is_last
+}
+
+constexpr int FIN_LDS_DOUBLES = 16 * 14 + 2;
+
+template <int KT>
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(
+    const double* __restrict__ stats, const double* __restrict__ Kuu, const double* __restrict__ dK,
+    const double* __restrict__ LK, const double* __restrict__ LP, const double* __restrict__ SK,
+    const double* __restrict__ dSK, const double* __restrict__ SP, const double* __restrict__ c,
+    const double* __restrict__ alpha, const double* __restrict__ logdets, long M, int k_rt, long D, ElboScalars th,
+    double alpha_scale, double* __restrict__ gacc, unsigned* __restrict__ ticket, double* __restrict__ out) {
+  __shared__ double part[FIN_LDS_DOUBLES];
+  (void)k_rt;
+  elbo_finalize_body<KT>((int)blockIdx.x, (int)gridDim.x, part, stats, Kuu, dK, LK, LP, SK, dSK, SP, c, alpha, logdets, M, D, th, alpha_scale,
+                         gacc, ticket, nullptr, out);
+}
+
+// Fused launch of the planned path (band algorithms 0 / 3): ONE kernel per ELBO + gradient evaluation.
+//   workgroup 0            the P chain (as elbo_bcr_data_kernel): P = A/s + Kuu formed in its gathers
+//   workgroup 1            the backward pass of the Kuu chain from the host's factor table (neither chain reads the other's output)
+//   workgroups 2 .. 2+H-1  helpers: first assemble Kuu and dKuu/dl (theta-only, one load round trip spread over H workgroups - a
+//                          prepare kernel in front of the launch cost 5.5 us of critical path, the same loop inside workgroup 0 13 us),
+//                          then (ELBO call) sleep on the chains' arrival counter and run the finalize reductions.
+// Waits: workgroup 0 waits for the helpers' assembly (which depends on nothing), the helpers wait for the two chains: no cycle.
+// The helpers need no LDS and are dispatched after workgroups 0 and 1.
+struct FusedFin {
+  const double* stats; ElboScalars th; double alpha_scale; double* gacc; unsigned* ticket; unsigned* arrived; unsigned* assembled; double* out;
+  long D; int n_helpers; int finalize;
+};
+__device__ __forceinline__ void assemble_band_slice(const double* __restrict__ S, const double* __restrict__ coef, const double* __restrict__ dcoef, int n_terms,
+                                                    long E, long e, double* __restrict__ Kuu, double* __restrict__ dK) {
+#pragma clang fp contract(off)
+  double sv[ASVGP_MAX_KUU_TERMS];
+#pragma unroll
+  for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) sv[t] = (t < n_terms) ? S[(long)t * E + e] : 0.0;
+  double acc = coef[0] * sv[0], dacc = dcoef[0] * sv[0];
+#pragma unroll
+  for (int t = 1; t < ASVGP_MAX_KUU_TERMS; ++t)
+    if (t < n_terms) { acc = acc + coef[t] * sv[t]; dacc = dacc + dcoef[t] * sv[t]; }   // inducing_features.py:12-44 rounding sequence
+  Kuu[e] = acc;
+  if (dK) dK[e] = dacc;
+}
+template <int K, bool BIG>
+__global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* S_static, KuuCoefs2 cf, double* Kuu, double* dK, const double* A, const double* b, int M,
+                                                                  double* wsP, double* SP, double* x, double* logdets, int* info,
+                                                                  double s, const double* tab, int n_rec, const int* node_rec,
+                                                                  double* wsK, double* SK, double* dSK,
+                                                                  unsigned long long* done_flag, unsigned long long seq, int D, int lds_doubles, FusedFin fin) {
+  extern __shared__ double lds[];
+  const long E = (long)(K + 1) * M;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) __builtin_amdgcn_s_sleep(2);
+      __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (nobody else reads it)
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, nullptr, D);
+    more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
+  } else if (blockIdx.x == 1) {
+    bcr_backward_pre<K>(tab, n_rec, node_rec, M, wsK, lds, BandOut<Dual>{SK, dSK}, logdets, info, done_flag, seq);
+  } else {
+    for (long e = (long)(blockIdx.x - 2) * blockDim.x + threadIdx.x; e < E; e += (long)fin.n_helpers * blockDim.x)
+      assemble_band_slice(S_static, cf.c, cf.dc, cf.n, E, e, Kuu, dK);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(fin.assembled, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (!fin.finalize) return;
+  if (blockIdx.x < 2) {                                       // chains: publish the bands, count the arrival
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(fin.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (threadIdx.x == 0)
+    while (__hip_atomic_load(fin.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2u) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // (Kuu / dK slices of the OTHER helpers: each helper's release precedes its chain-arrival wait only in program order of that helper;
+  //  the chains arrive tens of microseconds after every helper has published, and workgroup 0 has acquired all of them before it arrives)
+  elbo_finalize_body<K>((int)blockIdx.x - 2, fin.n_helpers, lds, fin.stats, Kuu, dK, nullptr, nullptr, SK, dSK, SP, nullptr, x, logdets, (long)M, fin.D,
+                        fin.th, fin.alpha_scale, fin.gacc, fin.ticket, fin.arrived, fin.out);
 }
 
 static __global__ void scale_sub_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
@@ -343,7 +415,7 @@ static __global__ void scale_kernel(double* __restrict__ x, double f, long n) {
 
 template <int K, bool TANGENT>
 static int run_chains(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
-                      Ws w, int* info, hipStream_t st, bool& use_bcr, int part = 0, bool scale_alpha = true) {
+                      Ws w, int* info, hipStream_t st, bool& use_bcr, int part = 0, bool scale_alpha = true, FusedFin* fin = nullptr) {
   KuuCoefs2 cf;
   for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
   int rc = asvgp_matern_coeffs(kind, v, l, cf.c, cf.dc, &cf.n);
@@ -378,10 +450,8 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
   }
   if (planned) {
     // ---- host: forward pass of the Kuu chain for this theta (prior_plan.cpp, ~20 us) into the next slot of the pinned ring.
-    // Kuu / dKuu (finalize traces, P = A/s + Kuu in the P chain's gathers) are assembled by the prepare kernel meanwhile.
+    // Kuu / dKuu (finalize traces, P = A/s + Kuu in the P chain's gathers) are assembled by the chain workgroups themselves.
     if (!fits) { set_error("BCR needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
-    hipLaunchKernelGGL(elbo_prepare_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, S, cf, E, A, s, w.Kuu,
-                       TANGENT ? w.dK : (double*)nullptr, (double*)nullptr);
     unsigned long long seq = 0;
     int slot = 0;
     double* tab = handle_table_acquire(h, &seq, &slot);
@@ -392,9 +462,14 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     auto kern = big ? elbo_chains_kernel<K, HAS_BIG> : elbo_chains_kernel<K, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-    hipLaunchKernelGGL(kern, dim3(2), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
+    FusedFin ff{};
+    if (fin) { ff = *fin; ff.finalize = 1; fin->finalize = -1; }   // (-1: tells the caller that the finalize rode along)
+    ff.n_helpers = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
+    ff.assembled = reinterpret_cast<unsigned*>(w.fin + 20);
+    hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BCR_THREADS), lds_bytes, st, S, cf, w.Kuu, TANGENT ? w.dK : (double*)nullptr, A, b,
+                       (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                        h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK,
-                       h->done_dev + slot, seq, (int)D, (int)(lds_bytes / sizeof(double)));
+                       h->done_dev + slot, seq, (int)D, (int)(lds_bytes / sizeof(double)), ff);
     if (scale_alpha) {
       long n = M * D;
       hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);
@@ -463,11 +538,14 @@ int ElboLauncher<K>::run(Handle* h, const double* stats, const double* S, int ki
   {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
-    int rc = run_chains<K, true>(h, stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false);
-    if (rc || (part == 1)) return rc;
-    if (h->sync_on && part == 2 && bcr && h->evP) (void)hipStreamWaitEvent(st, h->evP, 0);
     ElboScalars th{v, l, s, (double)N};
     const int fin_blocks = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
+    static_assert(BCR_THREADS == 256, "the fused finalize shares the chain kernel's workgroup size");
+    FusedFin ff{stats, th, 1.0 / s, w.fin, reinterpret_cast<unsigned*>(w.fin + 16), reinterpret_cast<unsigned*>(w.fin + 18), nullptr, out, D, 0, 0};
+    int rc = run_chains<K, true>(h, stats, S, kind, v, l, s, M, D, w, info, st, bcr, part, false, part == 1 ? nullptr : &ff);
+    if (rc || (part == 1)) return rc;
+    if (ff.finalize < 0) return check_launch("elbo_grad_1d (fused)");
+    if (h->sync_on && part == 2 && bcr && h->evP) (void)hipStreamWaitEvent(st, h->evP, 0);
     hipLaunchKernelGGL(elbo_finalize_kernel<K>, dim3(fin_blocks), dim3(256), 0, st, stats, w.Kuu, w.dK, w.LK, w.LP, w.SK,
                        w.dSK, w.SP, w.c, w.alpha, bcr ? w.logdets : (const double*)nullptr, M, K, D, th,
                        bcr ? 1.0 / s : 1.0, w.fin, reinterpret_cast<unsigned*>(w.fin + 16), out);

@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3), help="0 auto (planned prior chain), 1 sequential sweeps, "
                     "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
+    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3, 4), help="steps in flight: 1 = one step at a time on one stream; "
+                    "L >= 2 = the Phi pass of step i+1 (N-side stream) runs under the band chains of step i (M-side stream), L sets of buffers")
+    ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the pipelined schedule (the chain workgroups need free CUs)")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
     ap.add_argument("--kernel-events", type=int, default=10, help="HIP events around every n-th Phi kernel launch")
     ap.add_argument("--phase-events", type=int, default=25, help="record per-phase events on every n-th step (0 = never)")
@@ -204,32 +207,41 @@ def main():
             e3.record()
             marks.append((e0, e1, e2, e3))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if not os.environ.get("ASVGP_BENCH_NOPROF"):
-        lib.asvgp_profile_enable(hdl.ptr, args.kernel_events)   # HIP events around every n-th Phi kernel launch of the timed region
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        step(record=(args.phase_events > 0 and it % args.phase_events == 0))
-        if args.sync_each_step:
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms_sum, launches = ctypes.c_double(0), ctypes.c_int64(0)
-    lib.asvgp_profile_read(hdl.ptr, ctypes.byref(ms_sum), ctypes.byref(launches))
-    lib.asvgp_profile_enable(hdl.ptr, 0)
+    def measure(step_fn, h):
+        """W untimed + exactly K timed steps between barrier + synchronize pairs; HIP events around every n-th Phi launch of handle h."""
+        for _ in range(args.warmup):
+            step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if not os.environ.get("ASVGP_BENCH_NOPROF"):
+            lib.asvgp_profile_enable(h.ptr, args.kernel_events)
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            step_fn(record=(args.phase_events > 0 and it % args.phase_events == 0))
+            if args.sync_each_step:
+                torch.cuda.synchronize()
+        t_enqueue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if os.environ.get("ASVGP_BENCH_VERBOSE"):
+            print("host enqueue %.1f us/step, total %.1f us/step" % (t_enqueue / args.steps * 1e6, dt / args.steps * 1e6), file=sys.stderr)
+        ms_sum, launches = ctypes.c_double(0), ctypes.c_int64(0)
+        lib.asvgp_profile_read(h.ptr, ctypes.byref(ms_sum), ctypes.byref(launches))
+        lib.asvgp_profile_enable(h.ptr, 0)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, ms_sum.value / max(launches.value, 1) * 1e3, launches.value
+
+    # ---- schedule A: one step at a time on one stream (the latency of an ELBO + gradient evaluation from raw data)
+    dt, kern_us, n_launches = measure(step, hdl)
     model._check_pd()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
     if marks:
         t_phi = np.mean([a.elapsed_time(b) for a, b, _, _ in marks]) * 1e3
         t_comm = np.mean([b.elapsed_time(c) for _, b, c, _ in marks]) * 1e3
@@ -237,6 +249,51 @@ def main():
     else:
         t_phi = t_comm = t_band = 0.0
     out4 = model._out.cpu().numpy()
+
+    # ---- schedule B (default, --in-flight L >= 2): L steps in flight.  The Phi pass needs no theta, so in a training loop over
+    # successive batches the N-side work of step i+1 (Phi pass, reduce, all-reduce: one stream) runs under the M-side work of
+    # step i (band chains + finalize: two workgroups + helpers, second stream).  Every step is still a complete ELBO + gradient
+    # evaluation from the raw points into its own statistics / workspace / output buffers (L models over the same x, y); the only
+    # cross-stream dependency is "statistics of step i complete" (one event); a lane is reused once the host has seen its previous
+    # step finish.  The Phi grid leaves CUs free for the chain workgroups (--phi-workgroups).
+    pipe = None
+    if args.in_flight >= 2 and not two_stream:
+        lanes = []
+        for _ in range(args.in_flight):
+            mm = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
+            mm.likelihood.variance.assign(theta[2])
+            mm.num_data = N
+            if args.band_algo:
+                mm._h.set_band_algorithm(args.band_algo)
+            mm._h.set_phi_workgroups(args.phi_workgroups)
+            lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False])
+        s_phi, s_chain = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+        turn = [0]
+
+        def step_pipelined(record=False):
+            lane = lanes[turn[0] % len(lanes)]
+            mm, ev_stats, ev_done, used = lane
+            turn[0] += 1
+            if used:
+                ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
+            with torch.cuda.stream(s_phi):
+                mm.phi_pass(allreduce=False)
+                if world > 1:
+                    dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
+                ev_stats.record(s_phi)
+            with torch.cuda.stream(s_chain):
+                s_chain.wait_event(ev_stats)
+                mm._launch_elbo()
+                ev_done.record(s_chain)
+            lane[3] = True
+
+        dt_p, kern_us_p, n_launches_p = measure(step_pipelined, lanes[0][0]._h)
+        outs = [ln[0]._out.cpu().numpy() for ln in lanes]
+        for ln in lanes:
+            ln[0]._check_pd()
+        pipe = {"dt": dt_p, "kern_us": kern_us_p, "launches": n_launches_p,
+                "max_rel_diff_vs_serial": float(max(np.max(np.abs(o[:4] - out4[:4]) / np.abs(out4[:4])) for o in outs))}
+        del lanes
 
     # Extra, N > 1 only: the same step with the BASELINE N on EVERY rank (weak scaling).  `value` above stays the strong-scaling
     # figure the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
@@ -276,13 +333,24 @@ def main():
             weak = {"error": repr(exc)[:200]}
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        kern_us = ms_sum.value / max(launches.value, 1) * 1e3
         n_local = hi - lo
-        achieved = BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        ser_ms = dt / args.steps * 1e3
+        serial = {"ms_per_step": ser_ms, "value": N / (dt / args.steps) / 1e6, "unit": "Mpoints/s", "phi_kernel_us": kern_us,
+                  "roofline_frac": (BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else 0.0,
+                  "schedule": "one step at a time on one stream: Phi pass -> reduce -> [all-reduce] -> band chains + finalize (one launch)"}
+        if pipe is not None:      # the headline schedule; the one-at-a-time figures ride along as `one_step_at_a_time`
+            dt_v, kern_v, launches_v = pipe["dt"], pipe["kern_us"], pipe["launches"]
+            schedule = ("%d steps in flight: N-side stream (Phi pass, reduce, all-reduce of step i+1) under the M-side stream (band chains + "
+                        "finalize of step i); every step is a complete evaluation from the raw points into its own buffers; Phi grid %d workgroups"
+                        % (args.in_flight, args.phi_workgroups))
+        else:
+            dt_v, kern_v, launches_v = dt, kern_us, n_launches
+            schedule = serial["schedule"]
+        ms_per_step = dt_v / args.steps * 1e3
+        achieved = BYTES_PER_POINT * n_local / (kern_v * 1e-6) / 1e9 if kern_v > 0 else 0.0
         line = {
             "metric": "Mpoints/s per ELBO+grad step, N=10M 1D Matern-3/2 M=2048",
-            "value": N / (dt / args.steps) / 1e6,
+            "value": N / (dt_v / args.steps) / 1e6,
             "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -294,18 +362,23 @@ def main():
             "config": {"workload": "1D synthetic N=%d (U(0,1) i.i.d. %s), Matern-%d/2, B4Spline(0,1,M=%d) band k=4, theta=(1,0.05,0.01)"
                                    % (N, "sorted" if args.sorted else "unsorted", args.matern // 10, M),
                        "parallelism": "dp%d (contiguous N-shards, one all-reduce of the %d-double band buffer)" % (world, stats.numel()),
-                       "points_per_rank": n_local},
+                       "points_per_rank": n_local, "schedule": schedule},
+            "one_step_at_a_time": serial,
             "phases_us": {"phi_pass": t_phi, "band_allreduce": t_comm, "data_chain_after_stats": t_band,
-                          "note": "planned prior chain: host forward pass under the Phi pass, Kuu backward pass beside the P chain"
+                          "note": "measured in the one-step-at-a-time schedule; planned prior chain: host forward pass under the Phi pass, "
+                                  "P chain + Kuu backward pass + finalize in ONE launch"
                                   if not two_stream else "the theta-only prior chain (Kuu, tangent) runs on a second stream under the Phi pass"},
             "phi_pass_mpoints_per_s": n_local * world / (t_phi * 1e-6) / 1e6 if t_phi > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "phi_moment_kernel<4, 2048, true> (Phi pass, algorithm 5)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
                          "traffic_source": "profiles/r02_phi_traffic.json (rocprofv3 PMC passes of the same kernel and workload; not re-measured in this run)",
-                         "kernel_us": kern_us, "launches": launches.value,
-                         "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local},
+                         "kernel_us": kern_v, "launches": launches_v,
+                         "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local,
+                         "note": "HIP events around every %d-th launch of the kernel inside the timed region of the schedule `value` is quoted on" % args.kernel_events},
             "elbo": float(out4[0]), "grad": [float(v) for v in out4[1:4]],
         }
+        if pipe is not None:
+            line["pipelined_max_rel_diff_vs_one_at_a_time"] = pipe["max_rel_diff_vs_serial"]
         if weak is not None:
             line["weak_scaling_extra"] = weak
         if not args.no_cpu_baseline and world == 1:
