@@ -361,6 +361,395 @@ __global__ __launch_bounds__(256) void bb_update_kernel(double* __restrict__ Pb,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent band Cholesky (ONE launch; the launch-per-panel form above is the fallback for bw > 416).
+// Left-looking over block columns of NB = 32: workgroup g owns block columns g, g + G, ...  For column c it keeps the whole panel
+// (rows j0 .. j0+31+bw, 32 columns) in MFMA accumulators - 27 row tiles of 16 at bw = 387, 7 per wave, 112 VGPRs - applies the
+// updates of the <= 13 finished block columns p that reach it (v_mfma_f64_16x16x4: C -= L[rows, p] L[c rows, p]^T, operands loaded
+// straight from the band in the instruction's lane map, band mask applied on the load), then factors the 32 x 32 diagonal block with
+// one wavefront (rows in registers, v_readlane broadcasts), inverts it (one column per lane), forms the rows below as
+// Pan * Linv^T on the matrix cores again, writes the block column and publishes `done = c + 1` (release).  A consumer acquires
+// `done >= p + 1` before it reads block column p.  Columns finish in increasing order (c needs c-1), so one monotonic counter is
+// the whole protocol, and the lowest unfinished column never waits on anything unfinished: progress needs only that its owner
+// is resident (G <= 16 workgroups).  The right-hand side rides along deterministically: t = b - sum_p L[c rows, p] y_p from the
+// same B operands, y = Ldiag^-1 t by the factoring wavefront.
+// ---------------------------------------------------------------------------------------------------------
+typedef double bb_d4 __attribute__((ext_vector_type(4)));
+__device__ unsigned long long bbp_stamps[32];   // diagnostic: s_memtime stamps of block column ASVGP_BB_STAMP_COL (tools/bbp_stamps.py)
+#define BBP_STAMP(k) do { if (stamp_col == c && tid == 0) bbp_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int BBP_THREADS = 256;
+__host__ __device__ inline int bbp_row_tiles(int bw) { return (BB_NB + bw + 15) / 16; }               // 16-row tiles of a panel
+__host__ __device__ inline int bbp_rs(int bw) { return bbp_row_tiles(bw) * 16 + 1; }                  // LDS column stride (odd: bank spread)
+__host__ inline size_t bbp_lds_bytes(int bw) { return sizeof(double) * ((size_t)BB_NB * bbp_rs(bw) + 2 * BB_NB * (BB_NB + 1) + 2 * BB_NB + 16 * 17 + 8); }
+
+// 1/sqrt(x) and sqrt(x) in fp64 from v_rsq_f64 + two Newton steps (+ one correction of the root): ~16 VALU instructions instead of
+// the ~80 of sqrt() followed by a division; relative error of both results <= 2e-16 (not correctly rounded: the factor is compared
+// against a CPU band Cholesky at 1e-9 - 1e-12, never bit for bit).  Non-positive / NaN input gives NaN (reported through `info`).
+__device__ __forceinline__ void bb_rsqrt(double x, double& inv, double& root) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  double g = x * y;
+  g = fma(fma(-g, g, x), 0.5 * y, g);
+  inv = y;
+  root = g;
+}
+
+// one update C -= L[rows, p] L[c rows, p]^T on the NT row tiles rt = R0 + ST * t of the calling wave
+template <int NT, int ST, bool FAST, bool RHS_ROW>
+__device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, double& tacc1, const double* __restrict__ Pb,
+                                           const double* __restrict__ rhs, long M, int bw, long LD, long j0, long p0, int nbk, int R16,
+                                           int R0, int ln, int lg) {
+  // element (r, p0 + q) of the band sits at Pp[q * (LD - 1) + r]
+  const double* __restrict__ Pp = Pb + p0 * (LD - 1);
+  const int dj = (int)(j0 - p0);                      // 32 .. 32 * PMAX
+  double breg[2][8];
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    const int q = 4 * s8 + lg;
+    const double* __restrict__ bq = Pp + (long)q * (LD - 1) + j0 + ln;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int n = 16 * ct + ln;
+      const bool ok = n < nbk && dj + n - q <= bw;
+      const double v = FAST ? bq[16 * ct] : ((ok) ? bq[16 * ct] : 0.0);
+      breg[ct][s8] = ok ? v : 0.0;
+    }
+  }
+  if (RHS_ROW && rhs) {
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const double yv = rhs[p0 + 4 * s8 + lg];
+      tacc0 = fma(breg[0][s8], yv, tacc0);
+      tacc1 = fma(breg[1][s8], yv, tacc1);
+    }
+  }
+  // A operands in groups of up to 4 row tiles: the group's 32 loads are in flight before its first MFMA waits (with a branch per
+  // tile the loads of tile t+1 were issued after the MFMAs of tile t; all tiles at once spill)
+  const long r_last = p0 + BB_NB - 1 + bw;            // last row of block column p
+  constexpr int GT = (NT < 4) ? NT : ((NT % 3 == 0) ? 3 : 4);
+#pragma unroll
+  for (int g0 = 0; g0 < NT; g0 += GT) {
+    double areg[GT][8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int q = 4 * s8 + lg;
+      const double* __restrict__ aq = Pp + (long)q * (LD - 1) + j0 + 16 * R0 + ln;
+#pragma unroll
+      for (int u = 0; u < GT; ++u) {
+        const int t = g0 + u;
+        if (t < NT) {
+          const int rl = 16 * (R0 + ST * t) + ln;     // row inside the panel window
+          const bool ok = (FAST || j0 + rl < M) && dj + rl - q <= bw;
+          const double v = FAST ? aq[16 * ST * t] : (ok ? aq[16 * ST * t] : 0.0);
+          areg[u][s8] = ok ? -v : 0.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GT; ++u) {
+      const int t = g0 + u;
+      if (t < NT) {
+        const int rt = R0 + ST * t;
+        const long rbase = j0 + 16 * rt;
+        if (rt < R16 && rbase <= r_last && rbase < M) {    // wave-uniform: tiles past the end of block column p get no MFMAs
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[u][s8], breg[0][s8], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[u][s8], breg[1][s8], acc[t][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
+// wait until block column p is finished (workgroup-wide; `seen` is workgroup-uniform)
+__device__ __forceinline__ void bbp_wait(unsigned& seen, int p, unsigned* __restrict__ done, unsigned* seen_sh, int tid) {
+  if (seen >= (unsigned)(p + 1)) return;
+  if (tid == 0) {
+    unsigned v;
+    while ((v = __hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)(p + 1)) __builtin_amdgcn_s_sleep(2);
+    *seen_sh = v;
+  }
+  __syncthreads();
+  seen = *seen_sh;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();                                    // (seen_sh is rewritten by the next wait)
+}
+
+// The rows of one wave's tiles: panel window (LDS) <-> accumulators in the MFMA C layout (col = lane & 15, row = (lane >> 4) + 4 i)
+template <int NT, int ST>
+__device__ __forceinline__ void bbp_acc_load(bb_d4 (&acc)[NT][2], const double* Pan, int RS, int R16, int R0, int ln, int lg) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int rt = (R0 + ST * t < R16) ? R0 + ST * t : 0;      // (tiles past the window: any valid address, never stored back)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t][ct][i] = Pan[(size_t)(16 * ct + ln) * RS + 16 * rt + lg + 4 * i];
+  }
+}
+template <int NT, int ST>
+__device__ __forceinline__ void bbp_acc_store(const bb_d4 (&acc)[NT][2], double* Pan, int RS, int R16, int R0, int ln, int lg) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int rt = R0 + ST * t;
+    if (rt < R16) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Pan[(size_t)(16 * ct + ln) * RS + 16 * rt + lg + 4 * i] = acc[t][ct][i];
+    }
+  }
+}
+
+// Work split inside the workgroup (4 waves): wave 0 owns the two row tiles of the DIAGONAL block, waves 1..3 the tiles below it
+// (rt = 1 + w, 4 + w, ...: NTW each).  After the update by block column c-1 - the one a column has to wait for - wave 0 goes
+// straight to the factorisation of the diagonal block while the others are still on the matrix cores.
+template <int NTW>
+__global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double* __restrict__ Pb, long M, int bw, long LD,
+                                                                         double* __restrict__ rhs, int* __restrict__ info,
+                                                                         unsigned* __restrict__ done, int nbc, int stamp_col) {
+  extern __shared__ double lds[];
+  const int R16 = bbp_row_tiles(bw), RS = bbp_rs(bw);
+  double* Pan = lds;                                  // [32 cols][RS rows]
+  double* Ld = Pan + (size_t)BB_NB * RS;              // [32][33] diagonal factor
+  double* Li = Ld + BB_NB * (BB_NB + 1);              // [32][33] its inverse
+  double* ys = Li + BB_NB * (BB_NB + 1);              // [32] t = b - sum L y of this block / then y
+  double* Tt = ys + 2 * BB_NB;                        // [16][17] product staging of the block inverse
+  unsigned* seen_sh = reinterpret_cast<unsigned*>(Tt + 16 * 17);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lg = lane >> 4;
+  const int PMAX = (BB_NB - 1 + bw) / BB_NB;          // block columns to the left that reach a panel
+  const int R0 = 1 + wv;                              // first row tile of waves 1..3 (stride 3)
+  unsigned seen = 0;                                  // block columns known to be finished (workgroup-uniform)
+  for (int c = blockIdx.x; c < nbc; c += gridDim.x) {
+    const long j0 = (long)c * BB_NB;
+    const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
+    const bool interior = j0 + 16 * R16 <= M;         // every row of the window exists: unmasked operand loads (value-masked)
+    BBP_STAMP(0);
+    // ---- panel of P: band -> LDS window (row-contiguous = coalesced; zeros outside the band, identity on the padding columns of a
+    // short last block) -> accumulators in the MFMA C layout.  (Masked loads straight into the C layout needed 112 live exec masks
+    // per lane: 700 spilled SGPRs and 200 spilled VGPRs.)
+    const int RW = 16 * R16;
+    for (int col = wv; col < BB_NB; col += 4) {       // one column per wave and pass, lanes along the rows
+      const double* __restrict__ src = Pb + (j0 + col) * LD - col;      // element (j0 + rl, j0 + col) at src[rl]
+#pragma unroll 4
+      for (int rl = lane; rl < RW; rl += 64) {
+        const int d = rl - col;
+        double v = (col >= nbk && rl == col) ? 1.0 : 0.0;
+        if (col < nbk && j0 + rl < M && d >= 0 && d <= bw) v = src[rl];
+        Pan[(size_t)col * RS + rl] = v;
+      }
+    }
+    __syncthreads();
+    bb_d4 acc[NTW][2];                                // waves 1..3: NTW tiles; wave 0: the diagonal block in the first two
+    bb_d4 (&accd)[2][2] = reinterpret_cast<bb_d4 (&)[2][2]>(acc);
+    if (wv == 0) bbp_acc_load<2, 1>(accd, Pan, RS, R16, 0, ln, lg);
+    else bbp_acc_load<NTW, 3>(acc, Pan, RS, R16, R0, ln, lg);
+    __syncthreads();                                  // (the window is rewritten after the updates)
+    double tacc0 = 0.0, tacc1 = 0.0;
+    BBP_STAMP(1);
+    // ---- updates from the finished block columns that reach this one
+    for (int p = (c > PMAX) ? c - PMAX : 0; p < c; ++p) {
+      bbp_wait(seen, p, done, seen_sh, tid);
+      if (p == c - 1) BBP_STAMP(2);
+      const long p0 = (long)p * BB_NB;
+      if (wv == 0) {
+        if (interior) bbp_update<2, 1, true, true>(accd, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, 0, ln, lg);
+        else bbp_update<2, 1, false, true>(accd, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, 0, ln, lg);
+      } else {
+        if (interior) bbp_update<NTW, 3, true, false>(acc, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, R0, ln, lg);
+        else bbp_update<NTW, 3, false, false>(acc, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, R0, ln, lg);
+      }
+    }
+    BBP_STAMP(3);
+    if (wv == 0) {
+      // ---- diagonal block (one wavefront; single-wave code issues one VALU instruction per >= 4 cycles, so the instruction count
+      // is the cost - the plain 32-step form with sqrt and division was 25 K cycles, its column-per-lane inverse another 16 K):
+      //   1. columns 0..15 eliminated on all 32 rows (lane r = row r, v_readlane broadcasts, reciprocal square root by Newton
+      //      steps on v_rsq_f64): L11 and L21 at once, the rhs block rides along;
+      //   2. D22 -= L21 L21^T: one 16x16x16 product on the matrix cores;   3. columns 16..31 on rows 16..31;
+      //   4. L11^-1 and L22^-1 together (lanes 0..15 / 16..31, one column each, right-looking: independent FMAs);
+      //   5. the off-diagonal block of the inverse, -L22^-1 (L21 L11^-1): two more small MFMA products through the LDS.
+      bbp_acc_store<2, 1>(accd, Pan, RS, R16, 0, ln, lg);
+      {
+        double t0 = tacc0, t1 = tacc1;                // t of this block: lane r (< 32) ends up with its row's sum
+        t0 += __shfl_xor(t0, 16, 64); t0 += __shfl_xor(t0, 32, 64);
+        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+        if (lane < BB_NB) {
+          const double bsum = (lane < 16) ? t0 : t1;
+          ys[lane] = (rhs && lane < nbk) ? rhs[j0 + lane] - bsum : 0.0;
+        }
+      }
+      int r = lane & 31;
+      asm volatile("" : "+v"(r));   // opaque per block column: the lane predicates (r == j, r >= cc) below are otherwise hoisted out
+                                    // of the column loop as loop invariants - 700 spilled SGPRs, reloaded through v_readlane
+      double t = ys[r];
+      int bad = 0;
+      double a[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) a[cc] = (cc <= r) ? Pan[(size_t)cc * RS + r] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double piv = readlane_f64(a[j], j);
+        if (!(piv > 0.0) && !bad) bad = j + 1;
+        double inv, ljj;
+        bb_rsqrt(piv, inv, ljj);
+        a[j] = (r == j) ? ljj : a[j] * inv;              // (rows above j hold zeros in column j)
+        const double yj = readlane_f64(t, j) * inv;       // forward substitution rides along
+        t = (r == j) ? yj : fma(-a[j], yj, t);
+#pragma unroll
+        for (int cc = j + 1; cc < 16; ++cc) {
+          const double lcj = readlane_f64(a[j], cc);
+          a[cc] = (r >= cc) ? fma(-a[j], lcj, a[cc]) : a[cc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < BB_NB) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) Ld[r * (BB_NB + 1) + cc] = (cc <= r) ? a[cc] : 0.0;
+      }
+      {   // D22 (C layout of the 16 x 16 tile) -= L21 L21^T
+        bb_d4 c22;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c22[i] = Pan[(size_t)(16 + ln) * RS + 16 + lg + 4 * i];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double av = Ld[(16 + ln) * (BB_NB + 1) + 4 * s4 + lg];      // A[m][k] = L21[m][k] = B[k][n = m]
+          c22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, av, c22, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Pan[(size_t)(16 + ln) * RS + 16 + lg + 4 * i] = c22[i];
+      }
+      double b2[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) b2[cc] = (r >= 16 && 16 + cc <= r) ? Pan[(size_t)(16 + cc) * RS + r] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double piv = readlane_f64(b2[j], 16 + j);
+        if (!(piv > 0.0) && !bad) bad = 16 + j + 1;
+        double inv, ljj;
+        bb_rsqrt(piv, inv, ljj);
+        b2[j] = (r == 16 + j) ? ljj : b2[j] * inv;
+        const double yj = readlane_f64(t, 16 + j) * inv;
+        t = (r == 16 + j) ? yj : ((r > 16 + j) ? fma(-b2[j], yj, t) : t);
+#pragma unroll
+        for (int cc = j + 1; cc < 16; ++cc) {
+          const double lcj = readlane_f64(b2[j], 16 + cc);
+          b2[cc] = (r >= 16 + cc) ? fma(-b2[j], lcj, b2[cc]) : b2[cc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < BB_NB) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) Ld[r * (BB_NB + 1) + 16 + cc] = (r >= 16 && 16 + cc <= r) ? b2[cc] : 0.0;
+        if (rhs && r < nbk) rhs[j0 + r] = t;
+      }
+      if (lane == 0 && bad) atomicCAS(info, 0, (int)(j0 + bad));
+      BBP_STAMP(5);
+      {   // inverses of the two 16 x 16 triangles: lane (16 h + j) solves L_hh x = e_j
+        int jj = lane & 15, o = lane & 16;
+        asm volatile("" : "+v"(jj));
+        double x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = (q == jj) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          x[q] = x[q] / Ld[(o + q) * (BB_NB + 1) + o + q];
+#pragma unroll
+          for (int rr = q + 1; rr < 16; ++rr) x[rr] = fma(-Ld[(o + rr) * (BB_NB + 1) + o + q], x[q], x[rr]);
+        }
+        if (lane < BB_NB) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) Li[(o + rr) * (BB_NB + 1) + o + jj] = x[rr];
+          if (o == 0) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) Li[rr * (BB_NB + 1) + 16 + jj] = 0.0;      // upper-right block of the inverse
+          }
+        }
+      }
+      {   // lower-left block: -L22^-1 (L21 L11^-1)
+        bb_d4 T = {0.0, 0.0, 0.0, 0.0}, U = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          T = __builtin_amdgcn_mfma_f64_16x16x4f64(Ld[(16 + ln) * (BB_NB + 1) + 4 * s4 + lg], Li[(4 * s4 + lg) * (BB_NB + 1) + ln], T, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Tt[(lg + 4 * i) * 17 + ln] = T[i];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          U = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 + ln) * (BB_NB + 1) + 16 + 4 * s4 + lg], Tt[(4 * s4 + lg) * 17 + ln], U, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Li[(16 + lg + 4 * i) * (BB_NB + 1) + ln] = -U[i];
+      }
+      // the diagonal block itself back to the band
+      for (int idx = lane; idx < BB_NB * BB_NB; idx += 64) {
+        const int rr = idx % BB_NB, cc = idx / BB_NB;
+        if (rr >= cc && rr < nbk && cc < nbk && rr - cc <= bw) Pb[(j0 + cc) * LD + (rr - cc)] = Ld[rr * (BB_NB + 1) + cc];
+      }
+    } else {
+      bbp_acc_store<NTW, 3>(acc, Pan, RS, R16, R0, ln, lg);      // (the A operands of the solve are read back in another lane map)
+    }
+    __syncthreads();
+    BBP_STAMP(6);
+    // ---- rows below the diagonal block (waves 1..3): X = Pan Linv^T on the matrix cores, stored straight from the C layout
+    // (16 lanes = 16 columns of the band per row: scattered 32-byte pieces, but fire-and-forget; a second pass through the LDS
+    // for row-contiguous stores cost a barrier and 13 K cycles of write-completion wait on the critical path)
+    if (wv != 0) {
+      double bl[2][8];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) bl[ct][s8] = Li[(16 * ct + ln) * (BB_NB + 1) + 4 * s8 + lg];    // B[k][n] = Linv[n][k]
+      double* __restrict__ xb[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) xb[ct] = Pb + (j0 + 16 * ct + ln) * (LD - 1) + j0 + 16 * R0 + lg;
+      constexpr int GS = 3;
+#pragma unroll
+      for (int g0 = 0; g0 < NTW; g0 += GS) {
+        double av[GS][8];                             // a group's A operands first (LDS latency once per group)
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+          const int rt = (g0 + u < NTW && R0 + 3 * (g0 + u) < R16) ? R0 + 3 * (g0 + u) : 2;
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) av[u][s8] = Pan[(size_t)(4 * s8 + lg) * RS + 16 * rt + ln];
+        }
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+          const int rt = R0 + 3 * (g0 + u);
+          if (g0 + u < NTW && rt < R16 && j0 + 16 * rt < M) {
+            bb_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+              x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][s8], bl[0][s8], x0, 0, 0, 0);
+              x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][s8], bl[1][s8], x1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int col = 16 * ct + ln, rl = 16 * rt + lg + 4 * i;
+                // element (j0 + rl, j0 + col) = xb[ct][16 * 3 * (g0 + u) + 4 i]: two base pointers per lane, immediate offsets
+                if (col < nbk && j0 + rl < M && rl - col <= bw) xb[ct][48 * (g0 + u) + 4 * i] = (ct == 0) ? x0[i] : x1[i];
+              }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    BBP_STAMP(8);
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_store(done, (unsigned)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    BBP_STAMP(9);
+    if (seen < (unsigned)c) seen = (unsigned)c;       // (c - 1 was acquired above; our own column needs no acquire)
+  }
+}
+
 // backward substitution x = L^-T c for one block column (called for j0 descending): one workgroup.
 __global__ __launch_bounds__(1024) void bb_backsolve_kernel(const double* __restrict__ Pb, long M, int bw, long LD, long j0,
                                                             double* __restrict__ x) {
@@ -663,6 +1052,30 @@ extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, doubl
   const long LD = bw + 1;
   hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
   if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  const int R16 = bbp_row_tiles((int)bw);
+  static const bool persistent_off = getenv("ASVGP_BB_PERSISTENT") && atoi(getenv("ASVGP_BB_PERSISTENT")) == 0;   // (diagnostic: the per-panel launches)
+  if (R16 <= 29 && !persistent_off) {
+    // one launch: dataflow over block columns.  The arrival counter lives in a stream-ordered allocation (re-entrant across streams).
+    unsigned* done = nullptr;
+    e = hipMallocAsync(reinterpret_cast<void**>(&done), 64, st);
+    if (e != hipSuccess) { set_error("hipMallocAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+    (void)hipMemsetAsync(done, 0, 64, st);
+    const int nbc = (int)((M + BB_NB - 1) / BB_NB);
+    const int G = nbc < 16 ? nbc : 16;
+    const size_t lds_bytes = bbp_lds_bytes((int)bw);
+    const int ntw = (R16 - 2 + 2) / 3;                  // row tiles below the diagonal block per wave (waves 1..3)
+    static const int stamp_col = getenv("ASVGP_BB_STAMP_COL") ? atoi(getenv("ASVGP_BB_STAMP_COL")) : -1;
+#define BBP_LAUNCH(NTW)                                                                                                              \
+    {                                                                                                                                \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chol_persistent_kernel<NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds_bytes);                                                                                       \
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); (void)hipFreeAsync(done, st); return ASVGP_ERR_LDS_CAPACITY; } \
+      hipLaunchKernelGGL(bb_chol_persistent_kernel<NTW>, dim3(G), dim3(BBP_THREADS), lds_bytes, st, Pb, (long)M, (int)bw, LD, rhs, info, done, nbc, stamp_col); \
+    }
+    if (ntw <= 3) BBP_LAUNCH(3) else if (ntw <= 6) BBP_LAUNCH(6) else BBP_LAUNCH(9)
+#undef BBP_LAUNCH
+    (void)hipFreeAsync(done, st);
+  } else
   for (long j0 = 0; j0 < M; j0 += BB_NB) {
     hipLaunchKernelGGL(bb_panel_kernel, dim3(1), dim3(512), 0, st, Pb, (long)M, (int)bw, LD, j0, rhs, info);
     long nbk = (M - j0 < BB_NB) ? (M - j0) : BB_NB;
@@ -680,6 +1093,10 @@ extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, doubl
     hipLaunchKernelGGL(bb_logdet_kernel, dim3(16), dim3(1024), 0, st, Pb, (long)M, LD, logdet);
   }
   return check_launch("blockband_cholesky");
+}
+
+extern "C" int asvgp_debug_bbp_stamps(unsigned long long* out32) {   // diagnostic (not in the public header)
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(bbp_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? ASVGP_OK : ASVGP_ERR_HIP;
 }
 
 extern "C" int asvgp_blockband_backsolve(const double* Lb, int64_t M, int64_t bw, double* x, asvgp_stream_t stream) {
