@@ -7,7 +7,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in `_host`; the caller owns every buffer
- *     (e.g. torch tensors' data_ptr()); the library allocates nothing outside an asvgp_handle_t (asvgp_create / _destroy).
+ *     (e.g. torch tensors' data_ptr()); the library allocates nothing outside an asvgp_handle_t (asvgp_create / _destroy),
+ *     except one 64-byte stream-ordered scratch (hipMallocAsync / hipFreeAsync) inside asvgp_blockband_cholesky.
  *   - state lives in the handle: algorithm choices, the Phi-pass workgroup count, chain-ordering events, the kernel-timing
  *     ring and the prior-chain plan.  Entry points that take a handle are re-entrant ACROSS handles (one handle per model /
  *     stream / host thread); a NULL handle means the process-wide default handle (single-threaded convenience).
@@ -222,7 +223,9 @@ int asvgp_kron_assemble(const double* K1, const double* K2, const double* S1, co
                         int64_t m1, int64_t m2, double noise_variance, double* Pb, double* trace_out,
                         asvgp_stream_t stream);
 /* in-place blocked band Cholesky (gpr.py:293 tf.linalg.cholesky(P)); rhs (may be NULL, length M) is overwritten with
- * L^-1 rhs (gpr.py:295 triangular_solve); logdet (may be NULL) = 2 sum log diag L; info = first bad column + 1. */
+ * L^-1 rhs (gpr.py:295 triangular_solve); logdet (may be NULL) = 2 sum log diag L; info = first bad column + 1.
+ * bw <= 432: ONE persistent launch (16 workgroups, left-looking dataflow over block columns of 32 through an arrival counter in a
+ * 64-byte stream-ordered allocation; fp64 MFMA updates); wider bands: one panel + one update launch per block column. */
 int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, double* rhs, double* logdet, int* info,
                              asvgp_stream_t stream);
 /* x <- L^-T x */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): kernel-trace stats of the bench command, the two separate HBM-traffic PMC passes and the SQ counter
-# passes of the Phi kernel.  Outputs under gpurun_out/prof_r02/ ; summarised into profiles/ by tools/summarise_profiles.py (run
-# afterwards, on CPU).  usage: bash tools/collect_profiles.sh
+# passes of the Phi kernel, kernel-trace stats of the Kronecker and the posterior probes.  Outputs under gpurun_out/prof_r02/ ;
+# summarised into profiles/ by tools/summarise_profiles.py (run afterwards, on CPU).  usage: bash tools/collect_profiles.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -13,6 +13,9 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 tools/phi_pmc.py > $O/write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -- python3 tools/phi_pmc.py > $O/sq.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --kernel-trace --output-format csv -d $O/sq2 -- python3 tools/phi_pmc.py > $O/sq2.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kron -- python3 tools/kron_probe.py > $O/kron.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/predict -- python3 tools/predict_probe.py > $O/predict.log 2>&1 || exit 1
 timeout -k 10 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --sorted --no-cpu-baseline > $O/bench_sorted.json 2> $O/bench_sorted.err || exit 1
-find $O -name "*.csv" | head -30
+timeout -k 10 300 python3 bench.py --in-flight 1 --no-cpu-baseline > $O/bench_one_at_a_time.json 2> $O/bench_one.err || exit 1
+find $O -name "*.csv" | head -40

@@ -25,6 +25,28 @@ ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, tag + "_bench.json"))
 shutil.copy(os.path.join(src, "bench_sorted.json"), os.path.join(dst, tag + "_bench_sorted.json"))
+if os.path.exists(os.path.join(src, "bench_one_at_a_time.json")):
+    shutil.copy(os.path.join(src, "bench_one_at_a_time.json"), os.path.join(dst, tag + "_bench_one_at_a_time.json"))
+for sub in ("kron", "predict"):          # kernel-trace stats of tools/kron_probe.py / tools/predict_probe.py + the probes' own output
+    fs = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    if fs:
+        shutil.copy(fs[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, sub)))
+        log = [ln for ln in open(os.path.join(src, sub + ".log")).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2")]
+        open(os.path.join(dst, "%s_%s_probe.txt" % (tag, sub)), "w").write("\n".join(log[-12:]) + "\n")
+# the bench runs BOTH schedules in one process: split the Phi kernel's launches by grid size (256 workgroups = one step at a time,
+# fewer = steps in flight) so that each average can be held against the matching figure of the bench line
+kt = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+if kt:
+    by_grid = {}
+    for row in csv.DictReader(open(kt[0])):
+        if KERNEL in row["Kernel_Name"]:
+            wgs = int(row["Grid_Size_X"]) // max(int(row["Workgroup_Size_X"]), 1)
+            by_grid.setdefault(wgs, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    json.dump({"kernel": KERNEL, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline",
+               "launches_by_workgroups": {str(k): {"launches": len(v), "average_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+                                          for k, v in sorted(by_grid.items())},
+               "note": "256 workgroups = one-step-at-a-time schedule (and warm-up / construction), 240 = steps-in-flight schedule"},
+              open(os.path.join(dst, tag + "_phi_kernel_by_schedule.json"), "w"), indent=1)
 fetch, nf = counters("fetch")
 write, nw = counters("write")
 name, avg_ns = None, 0.0
