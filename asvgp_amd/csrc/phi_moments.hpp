@@ -252,7 +252,12 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
     auto fetch = [&](int it, double2& xo, double2& yo) __attribute__((always_inline)) {
       int u = unit_of(it < n_it ? it : n_it - 1) * 64 + lane;
       u = u < ulast ? u : ulast;
-      xo = x2[u]; yo = y2[u];
+      // streaming loads marked non-temporal: x, y are read exactly once, and in the steps-in-flight schedule the band chains of the
+      // previous step run beside this kernel out of an L2-resident workspace that the 160 MB stream would otherwise evict
+      typedef double mq_nt2 __attribute__((ext_vector_type(2)));
+      const mq_nt2 xv = __builtin_nontemporal_load(reinterpret_cast<const mq_nt2*>(x2 + u));
+      const mq_nt2 yv = __builtin_nontemporal_load(reinterpret_cast<const mq_nt2*>(y2 + u));
+      xo = make_double2(xv.x, xv.y); yo = make_double2(yv.x, yv.y);
     };
     auto batch = [&](int it, double2& xbuf, double2& ybuf) __attribute__((always_inline)) {
       const double2 xc = xbuf, yc = ybuf;
