@@ -797,6 +797,62 @@ __global__ __launch_bounds__(1024) void bb_backsolve_kernel(const double* __rest
   }
 }
 
+// the whole backward substitution in ONE launch: the block columns are strictly sequential (x of block j0 needs every x below it), so
+// one 1024-thread workgroup walks them with a barrier per step instead of 512 launches of the kernel above (19 us each, 10 ms at
+// 128 x 128).  x written in earlier steps is read with device-scope loads (bypassing this CU's L1, which may hold the old line).
+__global__ __launch_bounds__(1024) void bb_backsolve_persistent_kernel(const double* __restrict__ Pb, long M, int bw, long LD,
+                                                                       double* __restrict__ x) {
+  __shared__ double Ls[BB_NB][BB_NB + 1];
+  __shared__ double ts[BB_NB];
+  const int tid = threadIdx.x;
+  const int c = tid / 32, part = tid % 32;            // 32 columns x 32 row-lanes (a half wave per column)
+  for (long j0 = ((M - 1) / BB_NB) * BB_NB; j0 >= 0; j0 -= BB_NB) {
+    const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
+    for (int idx = tid; idx < BB_NB * BB_NB; idx += blockDim.x) {
+      int r = idx / BB_NB, cc = idx % BB_NB;
+      double v = (r == cc) ? 1.0 : 0.0;
+      if (r >= cc && r < nbk && cc < nbk) v = (r - cc <= bw) ? Pb[(j0 + cc) * LD + (r - cc)] : 0.0;
+      Ls[r][cc] = v;
+    }
+    const long r_lo = j0 + nbk;
+    long r_hi = j0 + nbk - 1 + bw;
+    if (r_hi > M - 1) r_hi = M - 1;
+    double acc = 0.0;
+    if (c < nbk) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four independent load / FMA streams
+      long r = r_lo + part;
+      for (; r + 96 <= r_hi; r += 128) {
+        const long d = r - (j0 + c);
+        const double p0 = (d <= bw) ? Pb[(j0 + c) * LD + d] : 0.0, p1 = (d + 32 <= bw) ? Pb[(j0 + c) * LD + d + 32] : 0.0;
+        const double p2 = (d + 64 <= bw) ? Pb[(j0 + c) * LD + d + 64] : 0.0, p3 = (d + 96 <= bw) ? Pb[(j0 + c) * LD + d + 96] : 0.0;
+        a0 = fma(p0, __hip_atomic_load(x + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a0);
+        a1 = fma(p1, __hip_atomic_load(x + r + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1);
+        a2 = fma(p2, __hip_atomic_load(x + r + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a2);
+        a3 = fma(p3, __hip_atomic_load(x + r + 96, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a3);
+      }
+      for (; r <= r_hi; r += 32) {
+        const long d = r - (j0 + c);
+        if (d <= bw) a0 = fma(Pb[(j0 + c) * LD + d], __hip_atomic_load(x + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a0);
+      }
+      acc = (a0 + a1) + (a2 + a3);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (part == 0) ts[c] = (c < nbk) ? __hip_atomic_load(x + j0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - acc : 0.0;
+    __syncthreads();
+    if (tid < 64) {                                   // the 32 x 32 triangle: one wavefront, lane = row, columns descending
+      const int r = tid & 31;
+      double t = ts[r];
+      for (int cc = nbk - 1; cc >= 0; --cc) {
+        const double xc = readlane_f64(t, cc) / Ls[cc][cc];      // (t of row cc is final when its turn comes)
+        t = (r == cc) ? xc : ((r < cc) ? fma(-Ls[cc][r], xc, t) : t);
+      }
+      if (tid < nbk) __hip_atomic_store(x + j0 + r, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+
 // sum of 2 log diag over the band factor
 __global__ __launch_bounds__(1024) void bb_logdet_kernel(const double* __restrict__ Pb, long M, long LD, double* __restrict__ out) {
   __shared__ double scratch[16];
@@ -1103,6 +1159,11 @@ extern "C" int asvgp_blockband_backsolve(const double* Lb, int64_t M, int64_t bw
   if (!Lb || !x || M < 1 || bw < 0) { set_error("blockband_backsolve: bad argument"); return ASVGP_ERR_BAD_ARG; }
   hipStream_t st = as_stream(stream);
   const long LD = bw + 1;
+  static const bool persistent_off = getenv("ASVGP_BB_PERSISTENT") && atoi(getenv("ASVGP_BB_PERSISTENT")) == 0;   // (diagnostic: one launch per block column)
+  if (!persistent_off) {
+    hipLaunchKernelGGL(bb_backsolve_persistent_kernel, dim3(1), dim3(1024), 0, st, Lb, (long)M, (int)bw, LD, x);
+    return check_launch("blockband_backsolve");
+  }
   for (long j0 = ((M - 1) / BB_NB) * BB_NB; j0 >= 0; j0 -= BB_NB)
     hipLaunchKernelGGL(bb_backsolve_kernel, dim3(1), dim3(1024), 0, st, Lb, (long)M, (int)bw, LD, j0, x);
   return check_launch("blockband_backsolve");

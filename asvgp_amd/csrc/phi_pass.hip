@@ -165,12 +165,18 @@ template <int NP> struct Batch {
 };
 template <int NP>
 __device__ __forceinline__ void classify(Batch<NP>& B, bool valid, const double* mesh, int n_mesh, double m0, double inv_delta,
-                                         int cell0, int cell1) {
+                                         int cell0, int cell1, double& yy) {
   bool all_in = true;
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
     B.idx[q] = valid ? neighbour_index(B.x[q], mesh, n_mesh, m0, inv_delta) : -1;
-    B.in[q] = valid && B.idx[q] >= cell0 && B.idx[q] < cell1;
+    // a point outside the mesh (cell coordinate beyond [0, 1] by more than the 2 % that float32-linspace meshes wobble) or NaN would
+    // leave the fixed-point products' compile-time bounds and wrap the int64 image: it is not accumulated and reported loudly
+    // (NaN y^T y), like the moment kernel does - the models check (a, b) first, a direct C-ABI caller gets this
+    const double tq = valid ? (B.x[q] - mesh[B.idx[q] < 0 ? 0 : B.idx[q]]) * inv_delta : 0.5;
+    const bool inside = tq >= -0.02 && tq <= 1.02;
+    yy = inside ? yy : __builtin_nan("");
+    B.in[q] = valid && inside && B.idx[q] >= cell0 && B.idx[q] < cell1;
     all_in = all_in && B.in[q];
   }
   B.idx0 = __builtin_amdgcn_readfirstlane(B.idx[0]);
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
     B.x[0] = xa.x; B.y[0] = ya.x;
     if (VEC) { B.x[NP - 1] = xa.y; B.y[NP - 1] = ya.y; }
     fetch(it + 1);
-    classify<NP>(B, have, mesh, n_mesh, m0, inv_delta, cell0, cell1);
+    classify<NP>(B, have, mesh, n_mesh, m0, inv_delta, cell0, cell1, yy);
   };
   // Two loops so that the run accumulator (40 VGPRs) is live only while a wave actually is inside a run: scatter mode is the
   // steady state of unsorted input, run mode of sorted / time-series input; every batch is classified, so a wrong mode
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
       Batch<1> T1;
       T1.x[0] = (tid == 0) ? x[end - 1] : 0.0;
       T1.y[0] = (tid == 0) ? y[end - 1] : 0.0;
-      classify<1>(T1, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1);
+      classify<1>(T1, tid == 0, mesh, n_mesh, m0, inv_delta, cell0, cell1, yy);
       scatter_batch<K, 1, FX>(T1, mesh, inv_delta, cell0, ncols, do_band, band, rhs, yy, fx);
     }
   }

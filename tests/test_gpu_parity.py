@@ -967,6 +967,26 @@ def test_phi_fixed_point_scale_fallback(A):
     assert torch.isnan(m.Kuf_y).any() and torch.isnan(m.tr_yTy)      # a NaN observation is not silently dropped
 
 
+@pytest.mark.parametrize("algo", [1, 3, 5])
+@pytest.mark.parametrize("bad", [1.5, -0.25, float("nan")])
+def test_point_outside_the_mesh_is_reported_not_wrapped(A, algo, bad):
+    """C-ABI level (the model classes refuse such X first, gpr.py:25-26): an x outside (a, b), or NaN, must not wrap the
+    fixed-point image into finite garbage - every Phi algorithm reports it as NaN y^T y."""
+    rng = np.random.default_rng(5)
+    N, M = 50_000, 256
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = rng.normal(size=N)
+    try:
+        A.set_phi_algorithm(algo)
+        m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern12(), A.B4Spline(0, 1, M))
+        assert torch.isfinite(m.tr_yTy)
+        m.X[N // 3] = bad                            # behind the constructor's check
+        m.phi_pass()
+        assert torch.isnan(m.tr_yTy)
+    finally:
+        A.set_phi_algorithm(0)
+
+
 def test_kron_full_size_properties_config4_and_config5_shapes(A):
     """BASELINE config 4 (N=1M, 128x128, k=3) and the eNATL60 stand-in shape (B4Spline(-80,-25,100) x B4Spline(15,55,100),
     eNATL60.py:84) at full basis size: size-independent properties instead of an O(M_tot^3) oracle."""
