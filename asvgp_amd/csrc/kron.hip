@@ -369,8 +369,9 @@ __global__ __launch_bounds__(256) void bb_update_kernel(double* __restrict__ Pb,
 // straight from the band in the instruction's lane map, band mask applied on the load), then factors the 32 x 32 diagonal block with
 // one wavefront (rows in registers, v_readlane broadcasts), inverts it (one column per lane), forms the rows below as
 // Pan * Linv^T on the matrix cores again, writes the block column and publishes `done = c + 1` (release).  A consumer acquires
-// `done >= p + 1` before it reads block column p.  Columns finish in increasing order (c needs c-1), so one monotonic counter is
-// the whole protocol, and the lowest unfinished column never waits on anything unfinished: progress needs only that its owner
+// `done >= p + 1` before it reads block column p.  Columns finish in increasing order (c needs c-1), so monotonic counters are
+// the whole protocol (a second one, `early`, lets the next diagonal block start before the column is completely stored - see
+// the kernel), and the lowest unfinished column never waits on anything unfinished: progress needs only that its owner
 // is resident (G <= 16 workgroups).  The right-hand side rides along deterministically: t = b - sum_p L[c rows, p] y_p from the
 // same B operands, y = Ldiag^-1 t by the factoring wavefront.
 // ---------------------------------------------------------------------------------------------------------
@@ -467,18 +468,14 @@ __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, d
   }
 }
 
-// wait until block column p is finished (workgroup-wide; `seen` is workgroup-uniform)
-__device__ __forceinline__ void bbp_wait(unsigned& seen, int p, unsigned* __restrict__ done, unsigned* seen_sh, int tid) {
-  if (seen >= (unsigned)(p + 1)) return;
-  if (tid == 0) {
-    unsigned v;
-    while ((v = __hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)(p + 1)) __builtin_amdgcn_s_sleep(2);
-    *seen_sh = v;
-  }
-  __syncthreads();
-  seen = *seen_sh;
+// wait (this wavefront only) until counter[0] >= target; `seen` is the wave's last observed value
+__device__ __forceinline__ void bbp_wait(unsigned& seen, unsigned target, const unsigned* __restrict__ counter, int lane) {
+  if (seen >= target) return;
+  unsigned v = 0;
+  if (lane == 0)
+    while ((v = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) __builtin_amdgcn_s_sleep(2);
+  seen = __builtin_amdgcn_readfirstlane(v);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();                                    // (seen_sh is rewritten by the next wait)
 }
 
 // The rows of one wave's tiles: panel window (LDS) <-> accumulators in the MFMA C layout (col = lane & 15, row = (lane >> 4) + 4 i)
@@ -521,11 +518,15 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
   double* Li = Ld + BB_NB * (BB_NB + 1);              // [32][33] its inverse
   double* ys = Li + BB_NB * (BB_NB + 1);              // [32] t = b - sum L y of this block / then y
   double* Tt = ys + 2 * BB_NB;                        // [16][17] product staging of the block inverse
-  unsigned* seen_sh = reinterpret_cast<unsigned*>(Tt + 16 * 17);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lg = lane >> 4;
   const int PMAX = (BB_NB - 1 + bw) / BB_NB;          // block columns to the left that reach a panel
   const int R0 = 1 + wv;                              // first row tile of waves 1..3 (stride 3)
-  unsigned seen = 0;                                  // block columns known to be finished (workgroup-uniform)
+  // done[0]: block columns completely finished.  done[16]: "early" arrivals, two per block column - the first row tile of wave 1
+  // (rt = 2) and of wave 2 (rt = 3), i.e. rows j0+32 .. j0+63: all that the DIAGONAL block of the next column needs of this one.
+  // Wave 0 of column c therefore starts its last update, the factorisation and the inverse as soon as column c-1 has published
+  // those two tiles, while column c-1 is still solving and storing its other 23 tiles (which waves 1..3 of column c wait for).
+  unsigned* early = done + 16;
+  unsigned seen = 0, seen_early = 0;                  // per wavefront
   for (int c = blockIdx.x; c < nbc; c += gridDim.x) {
     const long j0 = (long)c * BB_NB;
     const int nbk = (int)((M - j0 < BB_NB) ? (M - j0) : BB_NB);
@@ -548,14 +549,19 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
     __syncthreads();
     bb_d4 acc[NTW][2];                                // waves 1..3: NTW tiles; wave 0: the diagonal block in the first two
     bb_d4 (&accd)[2][2] = reinterpret_cast<bb_d4 (&)[2][2]>(acc);
-    if (wv == 0) bbp_acc_load<2, 1>(accd, Pan, RS, R16, 0, ln, lg);
-    else bbp_acc_load<NTW, 3>(acc, Pan, RS, R16, R0, ln, lg);
+    {
+      int lno = ln, lgo = lg;
+      asm volatile("" : "+v"(lno), "+v"(lgo));
+      if (wv == 0) bbp_acc_load<2, 1>(accd, Pan, RS, R16, 0, lno, lgo);
+      else bbp_acc_load<NTW, 3>(acc, Pan, RS, R16, R0, lno, lgo);
+    }
     __syncthreads();                                  // (the window is rewritten after the updates)
     double tacc0 = 0.0, tacc1 = 0.0;
     BBP_STAMP(1);
     // ---- updates from the finished block columns that reach this one
     for (int p = (c > PMAX) ? c - PMAX : 0; p < c; ++p) {
-      bbp_wait(seen, p, done, seen_sh, tid);
+      if (wv == 0 && p == c - 1) bbp_wait(seen_early, 2u * (unsigned)c, early, lane);
+      else bbp_wait(seen, (unsigned)(p + 1), done, lane);
       if (p == c - 1) BBP_STAMP(2);
       const long p0 = (long)p * BB_NB;
       if (wv == 0) {
@@ -691,7 +697,9 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
         if (rr >= cc && rr < nbk && cc < nbk && rr - cc <= bw) Pb[(j0 + cc) * LD + (rr - cc)] = Ld[rr * (BB_NB + 1) + cc];
       }
     } else {
-      bbp_acc_store<NTW, 3>(acc, Pan, RS, R16, R0, ln, lg);      // (the A operands of the solve are read back in another lane map)
+      int lno = ln, lgo = lg;
+      asm volatile("" : "+v"(lno), "+v"(lgo));
+      bbp_acc_store<NTW, 3>(acc, Pan, RS, R16, R0, lno, lgo);    // (the A operands of the solve are read back in another lane map)
     }
     __syncthreads();
     BBP_STAMP(6);
@@ -699,6 +707,9 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
     // (16 lanes = 16 columns of the band per row: scattered 32-byte pieces, but fire-and-forget; a second pass through the LDS
     // for row-contiguous stores cost a barrier and 13 K cycles of write-completion wait on the critical path)
     if (wv != 0) {
+      int ln = lane & 15, lg = lane >> 4;             // re-derived per block column and made opaque: the LDS / band addresses below are
+      asm volatile("" : "+v"(ln), "+v"(lg));          // loop invariants otherwise, get hoisted out of the column loop, spilled, and come back
+                                                      // through scratch loads each followed by s_waitcnt vmcnt(0) (43 K cycles for this phase)
       double bl[2][8];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -736,6 +747,10 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
                 if (col < nbk && j0 + rl < M && rl - col <= bw) xb[ct][48 * (g0 + u) + 4 * i] = (ct == 0) ? x0[i] : x1[i];
               }
           }
+          if (g0 + u == 0 && wv <= 2) {               // rows j0+32 .. j0+63 are in the band (or do not exist): early arrival
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_fetch_add(early, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -746,7 +761,6 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       __hip_atomic_store(done, (unsigned)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     BBP_STAMP(9);
-    if (seen < (unsigned)c) seen = (unsigned)c;       // (c - 1 was acquired above; our own column needs no acquire)
   }
 }
 
@@ -1113,9 +1127,9 @@ extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, doubl
   if (R16 <= 29 && !persistent_off) {
     // one launch: dataflow over block columns.  The arrival counter lives in a stream-ordered allocation (re-entrant across streams).
     unsigned* done = nullptr;
-    e = hipMallocAsync(reinterpret_cast<void**>(&done), 64, st);
+    e = hipMallocAsync(reinterpret_cast<void**>(&done), 128, st);
     if (e != hipSuccess) { set_error("hipMallocAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
-    (void)hipMemsetAsync(done, 0, 64, st);
+    (void)hipMemsetAsync(done, 0, 128, st);
     const int nbc = (int)((M + BB_NB - 1) / BB_NB);
     const int G = nbc < 16 ? nbc : 16;
     const size_t lds_bytes = bbp_lds_bytes((int)bw);
