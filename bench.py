@@ -256,44 +256,52 @@ def main():
     # evaluation from the raw points into its own statistics / workspace / output buffers (L models over the same x, y); the only
     # cross-stream dependency is "statistics of step i complete" (one event); a lane is reused once the host has seen its previous
     # step finish.  The Phi grid leaves CUs free for the chain workgroups (--phi-workgroups).
-    pipe = None
+    pipe, pipe_error = None, None
     if args.in_flight >= 2 and not two_stream:
-        lanes = []
-        for _ in range(args.in_flight):
-            mm = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
-            mm.likelihood.variance.assign(theta[2])
-            mm.num_data = N
-            if args.band_algo:
-                mm._h.set_band_algorithm(args.band_algo)
-            mm._h.set_phi_workgroups(args.phi_workgroups)
-            lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False])
-        s_phi, s_chain = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
-        turn = [0]
+        try:
+            lanes = []
+            for _ in range(args.in_flight):
+                mm = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
+                mm.likelihood.variance.assign(theta[2])
+                mm.num_data = N
+                if args.band_algo:
+                    mm._h.set_band_algorithm(args.band_algo)
+                mm._h.set_phi_workgroups(args.phi_workgroups)
+                lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False])
+            s_phi, s_chain = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+            turn = [0]
 
-        def step_pipelined(record=False):
-            lane = lanes[turn[0] % len(lanes)]
-            mm, ev_stats, ev_done, used = lane
-            turn[0] += 1
-            if used:
-                ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
-            with torch.cuda.stream(s_phi):
-                mm.phi_pass(allreduce=False)
-                if world > 1:
-                    dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
-                ev_stats.record(s_phi)
-            with torch.cuda.stream(s_chain):
-                s_chain.wait_event(ev_stats)
-                mm._launch_elbo()
-                ev_done.record(s_chain)
-            lane[3] = True
+            def step_pipelined(record=False):
+                lane = lanes[turn[0] % len(lanes)]
+                mm, ev_stats, ev_done, used = lane
+                turn[0] += 1
+                if used:
+                    ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
+                with torch.cuda.stream(s_phi):
+                    mm.phi_pass(allreduce=False)
+                    if world > 1:
+                        dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
+                    ev_stats.record(s_phi)
+                with torch.cuda.stream(s_chain):
+                    s_chain.wait_event(ev_stats)
+                    mm._launch_elbo()
+                    ev_done.record(s_chain)
+                lane[3] = True
 
-        dt_p, kern_us_p, n_launches_p = measure(step_pipelined, lanes[0][0]._h)
-        outs = [ln[0]._out.cpu().numpy() for ln in lanes]
-        for ln in lanes:
-            ln[0]._check_pd()
-        pipe = {"dt": dt_p, "kern_us": kern_us_p, "launches": n_launches_p,
-                "max_rel_diff_vs_serial": float(max(np.max(np.abs(o[:4] - out4[:4]) / np.abs(out4[:4])) for o in outs))}
-        del lanes
+            dt_p, kern_us_p, n_launches_p = measure(step_pipelined, lanes[0][0]._h)
+            outs = [ln[0]._out.cpu().numpy() for ln in lanes]
+            for ln in lanes:
+                ln[0]._check_pd()
+            pipe = {"dt": dt_p, "kern_us": kern_us_p, "launches": n_launches_p,
+                    "max_rel_diff_vs_serial": float(max(np.max(np.abs(o[:4] - out4[:4]) / np.abs(out4[:4])) for o in outs))}
+            del lanes
+
+        except Exception as exc:   # the contract line must come out: fall back to the one-at-a-time figures and say why
+            pipe, pipe_error = None, repr(exc)[:300]
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
 
     # Extra, N > 1 only: the same step with the BASELINE N on EVERY rank (weak scaling).  `value` above stays the strong-scaling
     # figure the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
@@ -379,6 +387,8 @@ def main():
         }
         if pipe is not None:
             line["pipelined_max_rel_diff_vs_one_at_a_time"] = pipe["max_rel_diff_vs_serial"]
+        if pipe_error is not None:
+            line["in_flight_schedule_error"] = pipe_error
         if weak is not None:
             line["weak_scaling_extra"] = weak
         if not args.no_cpu_baseline and world == 1:

@@ -710,6 +710,52 @@ def elbo_kron(bases, kinds, thetas, s, X, y):
     return float(elbo), dict(A=A, b=b, Kuu=Kuu, P=P)
 
 
+def _chol_extended(Ain):
+    """Dense Cholesky in np.longdouble (80-bit on x86): the yardstick for ill-conditioned Kronecker cases, small grids only."""
+    A = np.array(Ain, dtype=np.longdouble)
+    n = A.shape[0]
+    L = np.zeros_like(A)
+    for j in range(n):
+        d = A[j, j] - np.dot(L[j, :j], L[j, :j])
+        L[j, j] = np.sqrt(d)
+        if j + 1 < n:
+            L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    return L
+
+
+def _solve_lower_extended(L, B):
+    X = np.array(B, dtype=np.longdouble)
+    for j in range(L.shape[0]):
+        X[j] = (X[j] - L[j, :j] @ X[:j]) / L[j, j]
+    return X
+
+
+def elbo_kron_extended(bases, kinds, thetas, s, X, y):
+    """elbo_kron (gpr.py:260-308) with the two dense factorisations, the solves and the sums in np.longdouble; the inputs (Phi,
+    Kuu factors) are the same fp64 numbers.  D = 1."""
+    N = X.shape[0]
+    Phis = [bs.evaluate_basis(X[:, i:i + 1]) for i, bs in enumerate(bases)]
+    Kuf = make_kvs_sparse(Phis)
+    A = (Kuf @ Kuf.T).toarray()
+    b = np.asarray(Kuf @ y)
+    Ks = [band_to_dense_sym(make_Kuu(bs, kd, v, l)) for bs, kd, (v, l) in zip(bases, kinds, thetas)]
+    Kuu = np.array(Ks[0], dtype=np.longdouble)
+    for K in Ks[1:]:
+        Kuu = np.kron(Kuu, np.array(K, dtype=np.longdouble))
+    ld = np.longdouble
+    LK = _chol_extended(Kuu)
+    P = np.array(A, dtype=ld) / ld(s) + Kuu
+    LP = _chol_extended(P)
+    c = _solve_lower_extended(LP, b) / ld(s)
+    W = _solve_lower_extended(LK, A)                     # tr(Kuu^-1 A) = tr(LK^-1 A LK^-T) = sum over columns of |LK^-1 A^(1/2)|: use LK^-1 A LK^-T
+    W = _solve_lower_extended(LK, W.T)
+    tr = np.trace(W)
+    vprod = ld(np.prod([v for v, _ in thetas]))
+    elbo = (-ld(0.5) * N * np.log(2 * ld(np.pi) * ld(s)) - np.sum(np.log(np.diag(LP))) + np.sum(np.log(np.diag(LK)))
+            - ld(0.5) * np.sum(np.array(y, dtype=ld) ** 2) / ld(s) + ld(0.5) * np.sum(c * c) - ld(0.5) * N * vprod / ld(s) + ld(0.5) * tr / ld(s))
+    return float(elbo)
+
+
 def elbo_grad_kron(bases, kinds, thetas, s, X, y):
     """The bound of elbo_kron and its analytic gradient w.r.t. [v_1, l_1, ..., v_d, l_d, s] (dense; small grids only):
     G = 1/2 (Kuu^-1 - P^-1 - alpha alpha^T - Kuu^-1 A Kuu^-1 / s) (SURVEY App. A-6 with Kuu = kron(K_i), gpr.py:282-308),

@@ -1241,6 +1241,30 @@ def test_headline_config_parity_n10m(A):
     assert abs(ms.elbo_and_grad().cpu().numpy()[0] - ee) <= gate
 
 
+def test_config3_n10m_m4096_matern52_single_gpu(A):
+    """BASELINE config 3 (N = 10M, M = 4096, Matern-5/2, B4) on ONE GPU: the statistics of all 10M points (band-scatter kernel in
+    two column chunks - the moment image does not fit M = 4096) to 1e-12, bound and gradient against the oracle and its long-double
+    evaluation with the headline gate.  BASELINE names no theta; lengthscale 0.005 (20 cells, cond(Kuu) ~ 1e9) - at the north
+    star's 0.05 cond(Kuu) ~ 1e17 and even the oracle's fp64 and long-double values differ by 6e3."""
+    N, M = 10_000_000, 4096
+    v, l, s = 1.0, 0.005, 0.01
+    rng = np.random.default_rng(1)
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+    model = A.GPR_1d((dev(x).reshape(-1, 1), dev(y).reshape(-1, 1)), A.Matern52(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(s)
+    ob = O.Basis(4, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+    ref = np.concatenate([Ab.reshape(-1), b.reshape(-1), [yy]])
+    assert np.max(np.abs(model._stats.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    r = model.elbo_and_grad().cpu().numpy()
+    oe, og, _ = O.elbo_grad_1d(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
+    ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
+    gate = 1e-9 * abs(ee) + 5 * abs(oe - ee)
+    assert abs(r[0] - ee) <= gate, (r[0], ee, oe, gate)
+    np.testing.assert_allclose(r[1:4], ge, rtol=5e-6)       # (1.6e-6 for every elimination order, the sequential one included: cond 1e9)
+
+
 def test_bench_self_launch_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` with no torchrun environment must launch its own workers (the driver's SCALE command);
     rehearsed with gloo and both ranks on the one GPU of the test box."""
