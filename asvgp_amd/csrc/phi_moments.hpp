@@ -360,7 +360,7 @@ __global__ __launch_bounds__(MQ_THREADS) void phi_moment_kernel(MqArgs a) {
       }
     }
 #pragma unroll
-    for (int d = 0; d <= K; ++d) out[(size_t)d * M + j] = (j + d < M) ? band[d] : 0.0;
+    for (int d = 0; d <= K; ++d) __builtin_nontemporal_store((j + d < M) ? band[d] : 0.0, out + (size_t)d * M + j);   // written once, read once by the reduce
     out[(size_t)(K + 1) * M + j] = ldexp((double)(long long)rhs[j], -(s0 - E)) +
                                    __hip_atomic_load(ovr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

@@ -430,10 +430,10 @@ __global__ __launch_bounds__(256) void phi_reduce_kernel(const double* __restric
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int g = g0;
   for (; g + 3 < g1; g += 4) {
-    s0 += partials[(size_t)g * E1 + e];
-    s1 += partials[(size_t)(g + 1) * E1 + e];
-    s2 += partials[(size_t)(g + 2) * E1 + e];
-    s3 += partials[(size_t)(g + 3) * E1 + e];
+    s0 += __builtin_nontemporal_load(partials + (size_t)g * E1 + e);       // (read once: keep the 29 MB out of the L2's LRU order)
+    s1 += __builtin_nontemporal_load(partials + (size_t)(g + 1) * E1 + e);
+    s2 += __builtin_nontemporal_load(partials + (size_t)(g + 2) * E1 + e);
+    s3 += __builtin_nontemporal_load(partials + (size_t)(g + 3) * E1 + e);
   }
   for (; g < g1; ++g) s0 += partials[(size_t)g * E1 + e];
   double s = (s0 + s1) + (s2 + s3);

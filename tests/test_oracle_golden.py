@@ -274,3 +274,17 @@ def test_additive_oracle_reduces_to_1d_model():
     m1, v1 = O.predict_f_1d(bs, 1, Ab, b, v, l, s, xs)
     np.testing.assert_allclose(ma, m1, atol=1e-9)
     np.testing.assert_allclose(va, v1, atol=1e-9)
+
+
+def test_kron_long_double_yardstick_agrees_with_fp64_dense_bound_when_well_conditioned():
+    """oracle.elbo_kron_extended (dense factorisations in np.longdouble) is the yardstick the GPU Kronecker path is held against
+    where Kuu = K1 (x) K2 is too ill-conditioned for the fp64 dense oracle; on a well-conditioned grid the two must agree."""
+    rng = np.random.default_rng(0)
+    N = 400
+    X = rng.uniform(0.01, 0.99, (N, 2))
+    y = np.sin(5 * X[:, :1]) + 0.1 * rng.standard_normal((N, 1))
+    bs = [O.Basis(3, 0, 1, 10), O.Basis(3, 0, 1, 11)]
+    th = [(1.0, 0.3), (0.8, 0.4)]
+    e64 = O.elbo_kron(bs, [1, 2], th, 0.05, X, y)[0]
+    e80 = O.elbo_kron_extended(bs, [1, 2], th, 0.05, X, y)
+    assert abs(e64 - e80) <= 1e-9 * abs(e80)
