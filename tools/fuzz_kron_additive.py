@@ -33,11 +33,7 @@ for case in range(n_cases):
             oe, parts = O.elbo_kron(obases, kds, th, s, X, y)
             e, g = model.elbo_and_grad()
             om, ov = O.predict_f_kron(obases, kds, th, s, X, y, Xs)
-            def val(p): return O.elbo_kron(obases, kds, [(p[0], p[1]), (p[2], p[3])], p[4], X, y)[0]
-            p0 = np.array([th[0][0], th[0][1], th[1][0], th[1][1], s]); fd = np.zeros(5)
-            for i in range(5):
-                h = 1e-5 * p0[i]; pp, pm = p0.copy(), p0.copy(); pp[i] += h; pm[i] -= h
-                fd[i] = (val(pp) - val(pm)) / (2 * h)
+            fd = O.elbo_grad_kron(obases, kds, th, s, X, y)[1]      # the dense analytic gradient (differences of the bound lose ~1e-4 here)
             eg = np.max(np.abs(g - fd) / (np.abs(fd) + np.max(np.abs(fd))))
             vs = th[0][0] * th[1][0]
             xe = O.elbo_kron_extended(obases, kds, th, s, X, y)       # the dense bound in long double: how far is the fp64 oracle itself?
