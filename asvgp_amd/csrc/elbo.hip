@@ -366,7 +366,11 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
   const long E = (long)(K + 1) * M;
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
-      while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) __builtin_amdgcn_s_sleep(2);
+      long spins = 0;                                 // bounded: helpers that never became resident must not hang the device
+      while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1L << 25)) { atomicExch(info + 1, -1); break; }       // reported like a failed factorisation (negative: gave up waiting)
+      }
       __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (nobody else reads it)
     }
     __syncthreads();
@@ -393,8 +397,13 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
     }
     return;
   }
-  if (threadIdx.x == 0)
-    while (__hip_atomic_load(fin.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2u) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    long spins = 0;                                   // bounded like the wait above; the bound is minutes of chain time
+    while (__hip_atomic_load(fin.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1L << 25)) { atomicExch(info + 1, -1); break; }
+    }
+  }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // (Kuu / dK slices of the OTHER helpers: each helper's release precedes its chain-arrival wait only in program order of that helper;

@@ -468,14 +468,29 @@ __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, d
   }
 }
 
-// wait (this wavefront only) until counter[0] >= target; `seen` is the wave's last observed value
-__device__ __forceinline__ void bbp_wait(unsigned& seen, unsigned target, const unsigned* __restrict__ counter, int lane) {
-  if (seen >= target) return;
+// wait (this wavefront only) until counter[0] >= target; `seen` is the wave's last observed value.  The spin is bounded: a
+// wavefront that has polled for seconds (the owner of the awaited column never became resident, or died) raises the abort word,
+// which every other waiter sees, and the kernel drains with `info` = -1 instead of hanging the device.
+__device__ __forceinline__ bool bbp_wait(unsigned& seen, unsigned target, const unsigned* __restrict__ counter, unsigned* __restrict__ abort_word,
+                                         int lane) {
+  if (seen >= target) return true;
   unsigned v = 0;
-  if (lane == 0)
-    while ((v = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) __builtin_amdgcn_s_sleep(2);
+  int ok = 1;
+  if (lane == 0) {
+    long spins = 0;
+    while ((v = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 1023) == 0 && (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1L << 25))) {
+        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+  }
+  ok = __builtin_amdgcn_readfirstlane(ok);
   seen = __builtin_amdgcn_readfirstlane(v);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok != 0;
 }
 
 // The rows of one wave's tiles: panel window (LDS) <-> accumulators in the MFMA C layout (col = lane & 15, row = (lane >> 4) + 4 i)
@@ -557,11 +572,13 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
     }
     __syncthreads();                                  // (the window is rewritten after the updates)
     double tacc0 = 0.0, tacc1 = 0.0;
+    bool gave_up = false;
     BBP_STAMP(1);
     // ---- updates from the finished block columns that reach this one
     for (int p = (c > PMAX) ? c - PMAX : 0; p < c; ++p) {
-      if (wv == 0 && p == c - 1) bbp_wait(seen_early, 2u * (unsigned)c, early, lane);
-      else bbp_wait(seen, (unsigned)(p + 1), done, lane);
+      const bool arrived = (wv == 0 && p == c - 1) ? bbp_wait(seen_early, 2u * (unsigned)c, early, done + 24, lane)
+                                                   : bbp_wait(seen, (unsigned)(p + 1), done, done + 24, lane);
+      if (!arrived) gave_up = true;                   // (wave-uniform; the column is finished with whatever is there and flagged)
       if (p == c - 1) BBP_STAMP(2);
       const long p0 = (long)p * BB_NB;
       if (wv == 0) {
@@ -573,6 +590,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       }
     }
     BBP_STAMP(3);
+    if (gave_up && lane == 0) atomicExch(info, -1);   // a waited-for block column never arrived (see bbp_wait): results are invalid
     if (wv == 0) {
       // ---- diagonal block (one wavefront; single-wave code issues one VALU instruction per >= 4 cycles, so the instruction count
       // is the cost - the plain 32-step form with sqrt and division was 25 K cycles, its column-per-lane inverse another 16 K):

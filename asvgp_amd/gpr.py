@@ -185,6 +185,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
 
     def _check_pd(self):
         info = self._info.tolist()
+        if info[0] < 0 or info[1] < 0:
+            raise AsvgpError("the ELBO launch gave up waiting for its helper workgroups (they never became resident): results discarded")
         if info[0]:
             raise NotPositiveDefiniteError("Kuu band not positive definite at column %d" % (info[0] - 1))
         if info[1]:
@@ -403,6 +405,8 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         check(lib.asvgp_blockband_cholesky(Pb.data_ptr(), self.Mtot, bw, c.data_ptr(), logdet_P.data_ptr(),
                                            self._info.data_ptr(), stream_ptr()), "blockband_cholesky")
         col = int(self._info.item())
+        if col < 0:
+            raise AsvgpError("blockband_cholesky gave up waiting for a block column (its workgroup never became resident): results discarded")
         if col:
             raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite at column %d" % (col - 1))
         alpha = None

@@ -8,7 +8,7 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in `_host`; the caller owns every buffer
  *     (e.g. torch tensors' data_ptr()); the library allocates nothing outside an asvgp_handle_t (asvgp_create / _destroy),
- *     except one 64-byte stream-ordered scratch (hipMallocAsync / hipFreeAsync) inside asvgp_blockband_cholesky.
+ *     except one 128-byte stream-ordered scratch (hipMallocAsync / hipFreeAsync) inside asvgp_blockband_cholesky.
  *   - state lives in the handle: algorithm choices, the Phi-pass workgroup count, chain-ordering events, the kernel-timing
  *     ring and the prior-chain plan.  Entry points that take a handle are re-entrant ACROSS handles (one handle per model /
  *     stream / host thread); a NULL handle means the process-wide default handle (single-threaded convenience).
@@ -225,7 +225,8 @@ int asvgp_kron_assemble(const double* K1, const double* K2, const double* S1, co
 /* in-place blocked band Cholesky (gpr.py:293 tf.linalg.cholesky(P)); rhs (may be NULL, length M) is overwritten with
  * L^-1 rhs (gpr.py:295 triangular_solve); logdet (may be NULL) = 2 sum log diag L; info = first bad column + 1.
  * bw <= 432: ONE persistent launch (16 workgroups, left-looking dataflow over block columns of 32 through an arrival counter in a
- * 64-byte stream-ordered allocation; fp64 MFMA updates); wider bands: one panel + one update launch per block column. */
+ * 128-byte stream-ordered allocation; fp64 MFMA updates; bounded spins: info = -1 if a block column never arrives); wider bands:
+ * one panel + one update launch per block column. */
 int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, double* rhs, double* logdet, int* info,
                              asvgp_stream_t stream);
 /* x <- L^-T x */
