@@ -473,7 +473,10 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     FusedFin ff{};
     if (fin) { ff = *fin; ff.finalize = 1; fin->finalize = -1; }   // (-1: tells the caller that the finalize rode along)
-    ff.n_helpers = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
+    // 2 + 6 = 8 workgroups: one per XCD (workgroups are dealt to the XCDs round-robin).  Every workgroup of the launch reserves the
+    // chains' ~100 KB of LDS, i.e. a CU of its own; with 10 workgroups two of them shared an XCD, and the second ELBO launch of the
+    // in-flight schedule found no free CU there for a helper - its P chain then waited for the whole previous launch to finish
+    ff.n_helpers = (int)((M + 255) / 256 < 6 ? (M + 255) / 256 : 6);
     ff.assembled = reinterpret_cast<unsigned*>(w.fin + 20);
     hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BCR_THREADS), lds_bytes, st, S, cf, w.Kuu, TANGENT ? w.dK : (double*)nullptr, A, b,
                        (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,

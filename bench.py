@@ -112,8 +112,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3), help="0 auto (planned prior chain), 1 sequential sweeps, "
                     "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
-    ap.add_argument("--in-flight", type=int, default=3, choices=(1, 2, 3, 4), help="steps in flight: 1 = one step at a time on one stream; "
+    ap.add_argument("--in-flight", type=int, default=5, choices=(1, 2, 3, 4, 5, 6, 8), help="steps in flight: 1 = one step at a time on one stream; "
                     "L >= 2 = the Phi pass of step i+1 (N-side stream) runs under the band chains of step i (M-side stream), L sets of buffers")
+    ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the in-flight schedule (2: the band chains of two steps side by side)")
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the pipelined schedule (the chain workgroups need free CUs)")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
     ap.add_argument("--kernel-events", type=int, default=10, help="HIP events around every n-th Phi kernel launch")
@@ -251,11 +252,12 @@ def main():
     out4 = model._out.cpu().numpy()
 
     # ---- schedule B (default, --in-flight L >= 2): L steps in flight.  The Phi pass needs no theta, so in a training loop over
-    # successive batches the N-side work of step i+1 (Phi pass, reduce, all-reduce: one stream) runs under the M-side work of
-    # step i (band chains + finalize: two workgroups + helpers, second stream).  Every step is still a complete ELBO + gradient
-    # evaluation from the raw points into its own statistics / workspace / output buffers (L models over the same x, y); the only
-    # cross-stream dependency is "statistics of step i complete" (one event); a lane is reused once the host has seen its previous
-    # step finish.  The Phi grid leaves CUs free for the chain workgroups (--phi-workgroups).
+    # successive batches the N-side work of step i+1 (Phi pass, reduce, all-reduce: one stream) runs under the M-side work of the
+    # steps before it (the ELBO launch - two chain workgroups + six helpers, one CU per XCD - on --chain-streams streams in turn).
+    # Every step is still a complete ELBO + gradient evaluation from the raw points into its own statistics / workspace / output
+    # buffers (L models over the same x, y); the only GPU-side cross-stream dependency is "statistics of step i complete" (one
+    # event); a lane is reused once the host has seen its previous step finish.  The Phi grid leaves CUs free for the chain
+    # workgroups (--phi-workgroups: a Phi workgroup fills the register file and the LDS of its CU).
     pipe, pipe_error = None, None
     if args.in_flight >= 2 and not two_stream:
         try:
@@ -268,12 +270,14 @@ def main():
                     mm._h.set_band_algorithm(args.band_algo)
                 mm._h.set_phi_workgroups(args.phi_workgroups)
                 lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False])
-            s_phi, s_chain = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+            s_phi = torch.cuda.Stream()
+            s_chains = [torch.cuda.Stream(priority=-1) for _ in range(max(1, args.chain_streams))]
             turn = [0]
 
             def step_pipelined(record=False):
                 lane = lanes[turn[0] % len(lanes)]
                 mm, ev_stats, ev_done, used = lane
+                s_chain = s_chains[turn[0] % len(s_chains)]
                 turn[0] += 1
                 if used:
                     ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
@@ -348,14 +352,17 @@ def main():
                   "schedule": "one step at a time on one stream: Phi pass -> reduce -> [all-reduce] -> band chains + finalize (one launch)"}
         if pipe is not None:      # the headline schedule; the one-at-a-time figures ride along as `one_step_at_a_time`
             dt_v, kern_v, launches_v = pipe["dt"], pipe["kern_us"], pipe["launches"]
-            schedule = ("%d steps in flight: N-side stream (Phi pass, reduce, all-reduce of step i+1) under the M-side stream (band chains + "
-                        "finalize of step i); every step is a complete evaluation from the raw points into its own buffers; Phi grid %d workgroups"
-                        % (args.in_flight, args.phi_workgroups))
+            schedule = ("%d steps in flight: one N-side stream (Phi pass, reduce, all-reduce of step i+1) under %d M-side stream(s) (band chains + "
+                        "finalize of steps i, i-1); every step is a complete evaluation from the raw points into its own buffers; Phi grid %d workgroups"
+                        % (args.in_flight, max(1, args.chain_streams), args.phi_workgroups))
         else:
             dt_v, kern_v, launches_v = dt, kern_us, n_launches
             schedule = serial["schedule"]
         ms_per_step = dt_v / args.steps * 1e3
-        achieved = BYTES_PER_POINT * n_local / (kern_v * 1e-6) / 1e9 if kern_v > 0 else 0.0
+        # roofline: the Phi kernel's own duration.  HIP events around a launch measure that only when the kernel has the device to
+        # itself (one-at-a-time pass: agrees with rocprofv3's kernel trace); in the in-flight pass the same events also contain the
+        # time the launch waits for CUs behind the other streams' kernels, so that figure is reported beside it, not instead of it
+        achieved = BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         line = {
             "metric": "Mpoints/s per ELBO+grad step, N=10M 1D Matern-3/2 M=2048",
             "value": N / (dt_v / args.steps) / 1e6,
@@ -380,9 +387,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "phi_moment_kernel<4, 2048, true> (Phi pass, algorithm 5)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
                          "traffic_source": "profiles/r02_phi_traffic.json (rocprofv3 PMC passes of the same kernel and workload; not re-measured in this run)",
-                         "kernel_us": kern_v, "launches": launches_v,
+                         "kernel_us": kern_us, "launches": n_launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local,
-                         "note": "HIP events around every %d-th launch of the kernel inside the timed region of the schedule `value` is quoted on" % args.kernel_events},
+                         "in_flight_event_us": (kern_v if pipe is not None else None),
+                         "note": "HIP events around every %d-th launch inside the timed one-step-at-a-time pass (the kernel alone on the device: its own "
+                                 "duration, as in profiles/r02_kernel_stats.csv); in_flight_event_us = the same events in the in-flight pass, where "
+                                 "they include the launch's wait for CUs (rocprofv3 there: profiles/r02_phi_kernel_by_schedule.json)" % args.kernel_events},
             "elbo": float(out4[0]), "grad": [float(v) for v in out4[1:4]],
         }
         if pipe is not None:
