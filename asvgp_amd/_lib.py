@@ -21,6 +21,8 @@ SIGNATURES = {
     "asvgp_phi_accumulate_1d": (_I, [_P, _P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
     "asvgp_set_phi_algorithm": (_I, [_P, _I]),
     "asvgp_set_phi_workgroups": (_I, [_P, _I]),
+    "asvgp_set_phi_deferred_reduce": (_I, [_P, _I]),
+    "asvgp_phi_reduce_1d": (_I, [_P, _P]),
     "asvgp_phi_index_1d": (_I, [_P, _L, _P, _L, _D, _P, _P]),
     "asvgp_phi_evaluate_1d": (_I, [_P, _L, _P, _L, _D, _I, _I, _P, _P, _P]),
     "asvgp_matern_coeffs": (_I, [_I, _D, _D, _c.POINTER(_D), _c.POINTER(_D), _c.POINTER(_I)]),
@@ -127,6 +129,9 @@ class Handle:
 
     def set_phi_workgroups(self, n):
         check(self._lib.asvgp_set_phi_workgroups(self.ptr, int(n)), "set_phi_workgroups")
+
+    def set_phi_deferred_reduce(self, on):
+        check(self._lib.asvgp_set_phi_deferred_reduce(self.ptr, int(on)), "set_phi_deferred_reduce")
 
     def chain_sync(self, on):
         check(self._lib.asvgp_elbo_chain_sync(self.ptr, int(on)), "elbo_chain_sync")

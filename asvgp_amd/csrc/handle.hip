@@ -113,6 +113,13 @@ extern "C" int asvgp_set_phi_workgroups(asvgp_handle_t handle, int n) {
   return ASVGP_OK;
 }
 
+extern "C" int asvgp_set_phi_deferred_reduce(asvgp_handle_t handle, int on) {
+  Handle* h = as_handle(handle);
+  h->phi_defer = on != 0;
+  if (!h->phi_defer) h->pend.valid = false;
+  return ASVGP_OK;
+}
+
 extern "C" int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo) {
   if (algo < 0 || algo > 3) {
     set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 block cyclic reduction on the GPU, 3 block cyclic reduction with the planned (host, long double) prior forward pass");

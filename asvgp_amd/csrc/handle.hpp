@@ -15,6 +15,9 @@ struct Handle {
   int device = 0;
   // Phi pass
   int phi_algo = 0, phi_blocks = 0;
+  // deferred cross-workgroup reduce (asvgp_set_phi_deferred_reduce): the moment kernel's partials wait here for asvgp_phi_reduce_1d
+  bool phi_defer = false;
+  struct PendingReduce { const double* partials; int G, M, K; double* stats; bool valid; } pend = {nullptr, 0, 0, 0, nullptr, false};
   // band algebra
   int band_algo = 0;
   bool sync_on = false;

@@ -622,6 +622,10 @@ static int launch_phi_moments_cs(Handle* h, const double* x, const double* y, lo
   if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
   const int E1 = (int)((K + 2) * M + 1);
   const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
+  if (h->phi_defer) {   // the caller enqueues the reduce itself (asvgp_phi_reduce_1d), e.g. on the stream that consumes the statistics
+    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true};
+    return check_launch("phi_accumulate_1d (moments, reduce deferred)");
+  }
   hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
   return check_launch("phi_accumulate_1d (moments)");
 }
@@ -643,6 +647,7 @@ static int launch_phi_moments(Handle* h, const double* x, const double* y, long 
 template <int K>
 static int launch_phi(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
+  h->pend.valid = false;
   const int ncells = (int)n_mesh - 1;
   if (h->phi_algo == 0 || h->phi_algo == 5) {
     const int rc = launch_phi_moments<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
@@ -734,6 +739,18 @@ extern "C" int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, c
     case 5: return launch_phi<5>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
     default: return launch_phi<6>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
   }
+}
+
+extern "C" int asvgp_phi_reduce_1d(asvgp_handle_t handle, asvgp_stream_t stream) {
+  Handle* h = as_handle(handle);
+  if (!h->pend.valid) return ASVGP_OK;                 // nothing deferred (the accumulate call has reduced already)
+  const Handle::PendingReduce p = h->pend;
+  h->pend.valid = false;
+  const int E1 = (p.K + 2) * p.M + 1;
+  const int gsplit = p.G >= 64 ? 16 : (p.G >= 8 ? 4 : 1);
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, as_stream(stream), p.partials, p.G, p.M, p.K, 0, (long)p.M, 1L, 0,
+                     1, p.stats);
+  return check_launch("phi_reduce_1d");
 }
 
 extern "C" int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,

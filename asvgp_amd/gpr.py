@@ -152,6 +152,12 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
             self._planned_kind = kind
         return S
 
+    def phi_reduce(self):
+        """With self._h.set_phi_deferred_reduce(1): enqueue the cross-workgroup reduce of the last phi_pass() on the CURRENT stream
+        (the caller orders it behind that Phi pass); a no-op otherwise."""
+        check(get_lib().asvgp_phi_reduce_1d(self._h.ptr, stream_ptr()), "phi_reduce_1d")
+        return self._stats
+
     def _launch_elbo(self):
         v, l, s = self.theta()
         b = self.basis

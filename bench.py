@@ -269,6 +269,7 @@ def main():
                 if args.band_algo:
                     mm._h.set_band_algorithm(args.band_algo)
                 mm._h.set_phi_workgroups(args.phi_workgroups)
+                mm._h.set_phi_deferred_reduce(1)     # the N-side stream carries the streaming kernels only
                 lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False])
             s_phi = torch.cuda.Stream()
             s_chains = [torch.cuda.Stream(priority=-1) for _ in range(max(1, args.chain_streams))]
@@ -282,12 +283,13 @@ def main():
                 if used:
                     ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
                 with torch.cuda.stream(s_phi):
-                    mm.phi_pass(allreduce=False)
-                    if world > 1:
-                        dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
+                    mm.phi_pass(allreduce=False)         # (reduce deferred: the partial statistics of all workgroups)
                     ev_stats.record(s_phi)
                 with torch.cuda.stream(s_chain):
                     s_chain.wait_event(ev_stats)
+                    mm.phi_reduce()                      # cross-workgroup reduce, then the one exchange step, then the band algebra
+                    if world > 1:
+                        dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
                     mm._launch_elbo()
                     ev_done.record(s_chain)
                 lane[3] = True

@@ -78,6 +78,13 @@ int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
 /* workgroups of the Phi-pass kernel: 0 = default (256, one per CU); a smaller number leaves CUs free so that a
  * concurrently enqueued asvgp_elbo_prior_chain_1d (second stream) is resident at the same time. */
 int asvgp_set_phi_workgroups(asvgp_handle_t handle, int n);
+/* Deferred reduce.  asvgp_phi_accumulate_1d is two launches: the streaming kernel (per-workgroup partial statistics into the
+ * workspace) and a small cross-workgroup reduce into `stats`.  With on = 1 the accumulate call enqueues only the first (when the
+ * default moment kernel applies; otherwise it reduces as usual) and asvgp_phi_reduce_1d enqueues the second on ITS stream argument -
+ * the stream that consumes the statistics - after the caller has ordered it behind the accumulate call (an event).  A pipelined
+ * caller thereby keeps its N-side stream to the streaming kernels alone.  asvgp_phi_reduce_1d without a pending reduce is a no-op. */
+int asvgp_set_phi_deferred_reduce(asvgp_handle_t handle, int on);
+int asvgp_phi_reduce_1d(asvgp_handle_t handle, asvgp_stream_t stream);
 
 /* basis.py:58-59  neighbour_index = relu(searchsorted_left(mesh, x) - 1)  (integer work, bit-exact) */
 int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,

@@ -1265,6 +1265,33 @@ def test_config3_n10m_m4096_matern52_single_gpu(A):
     np.testing.assert_allclose(r[1:4], ge, rtol=5e-6)       # (1.6e-6 for every elimination order, the sequential one included: cond 1e9)
 
 
+def test_deferred_reduce_gives_the_same_statistics(A):
+    """asvgp_set_phi_deferred_reduce / asvgp_phi_reduce_1d: the streaming kernel and the cross-workgroup reduce as two calls (the
+    pipelined bench keeps the reduce off its N-side stream); same statistics as the fused call, and a reduce with nothing pending
+    is a no-op."""
+    rng = np.random.default_rng(11)
+    N, M = 300_000, 1024
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+    m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern32(), A.B4Spline(0, 1, M))
+    ref = m._stats.clone()
+    m._h.set_phi_deferred_reduce(1)
+    m.phi_pass()
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        m.phi_reduce()
+        m.phi_reduce()                                   # nothing pending any more: no-op
+    torch.cuda.synchronize()
+    assert torch.max(torch.abs(m._stats - ref)).item() <= 1e-12 * torch.max(torch.abs(ref)).item()
+    m._h.set_phi_deferred_reduce(0)
+    m.phi_pass()
+    torch.cuda.synchronize()
+    assert torch.max(torch.abs(m._stats - ref)).item() <= 1e-12 * torch.max(torch.abs(ref)).item()
+
+
 def test_bench_self_launch_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` with no torchrun environment must launch its own workers (the driver's SCALE command);
     rehearsed with gloo and both ranks on the one GPU of the test box."""
