@@ -114,6 +114,7 @@ def main():
                     "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
     ap.add_argument("--in-flight", type=int, default=5, choices=(1, 2, 3, 4, 5, 6, 8), help="steps in flight: 1 = one step at a time on one stream; "
                     "L >= 2 = the Phi pass of step i+1 (N-side stream) runs under the band chains of step i (M-side stream), L sets of buffers")
+    ap.add_argument("--event-group", type=int, default=1, help="in-flight schedule: Phi passes per cross-stream event (an event record costs stream time)")
     ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the in-flight schedule (2: the band chains of two steps side by side)")
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the pipelined schedule (the chain workgroups need free CUs)")
     ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
@@ -212,6 +213,8 @@ def main():
         """W untimed + exactly K timed steps between barrier + synchronize pairs; HIP events around every n-th Phi launch of handle h."""
         for _ in range(args.warmup):
             step_fn()
+        if getattr(step_fn, "flush", None):
+            step_fn.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -223,6 +226,8 @@ def main():
             step_fn(record=(args.phase_events > 0 and it % args.phase_events == 0))
             if args.sync_each_step:
                 torch.cuda.synchronize()
+        if getattr(step_fn, "flush", None):
+            step_fn.flush()
         t_enqueue = time.perf_counter() - t0
         torch.cuda.synchronize()
         if world > 1:
@@ -270,29 +275,48 @@ def main():
                     mm._h.set_band_algorithm(args.band_algo)
                 mm._h.set_phi_workgroups(args.phi_workgroups)
                 mm._h.set_phi_deferred_reduce(1)     # the N-side stream carries the streaming kernels only
-                lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False])
+                lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False, 0])
             s_phi = torch.cuda.Stream()
             s_chains = [torch.cuda.Stream(priority=-1) for _ in range(max(1, args.chain_streams))]
             turn = [0]
 
+            pending = []
+            group = max(1, args.event_group)
+
+            def flush():
+                """One event for the Phi passes enqueued since the last one (an event record costs ~7 us of N-side stream time),
+                then the M-side work of those steps."""
+                if not pending:
+                    return
+                ev = pending[-1][1]
+                ev.record(s_phi)
+                for lane, _ in pending:
+                    mm, ev_done = lane[0], lane[2]
+                    s_chain = s_chains[lane[4] % len(s_chains)]
+                    with torch.cuda.stream(s_chain):
+                        s_chain.wait_event(ev)
+                        mm.phi_reduce()                  # cross-workgroup reduce, then the one exchange step, then the band algebra
+                        if world > 1:
+                            dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
+                        mm._launch_elbo()
+                        ev_done.record(s_chain)
+                    lane[3] = True
+                pending.clear()
+
             def step_pipelined(record=False):
                 lane = lanes[turn[0] % len(lanes)]
-                mm, ev_stats, ev_done, used = lane
-                s_chain = s_chains[turn[0] % len(s_chains)]
+                mm, ev_stats, ev_done, used = lane[:4]
+                lane[4] = turn[0]
                 turn[0] += 1
                 if used:
                     ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
                 with torch.cuda.stream(s_phi):
                     mm.phi_pass(allreduce=False)         # (reduce deferred: the partial statistics of all workgroups)
-                    ev_stats.record(s_phi)
-                with torch.cuda.stream(s_chain):
-                    s_chain.wait_event(ev_stats)
-                    mm.phi_reduce()                      # cross-workgroup reduce, then the one exchange step, then the band algebra
-                    if world > 1:
-                        dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
-                    mm._launch_elbo()
-                    ev_done.record(s_chain)
-                lane[3] = True
+                pending.append((lane, ev_stats))
+                if len(pending) >= group:
+                    flush()
+
+            step_pipelined.flush = flush
 
             dt_p, kern_us_p, n_launches_p = measure(step_pipelined, lanes[0][0]._h)
             outs = [ln[0]._out.cpu().numpy() for ln in lanes]
