@@ -114,6 +114,7 @@ def main():
                     "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
     ap.add_argument("--in-flight", type=int, default=5, choices=(1, 2, 3, 4, 5, 6, 8), help="steps in flight: 1 = one step at a time on one stream; "
                     "L >= 2 = the Phi pass of step i+1 (N-side stream) runs under the band chains of step i (M-side stream), L sets of buffers")
+    ap.add_argument("--phi-streams", type=int, default=1, help="in-flight schedule: N-side streams (2: consecutive Phi kernels may overlap at their ends)")
     ap.add_argument("--event-group", type=int, default=1, help="in-flight schedule: Phi passes per cross-stream event (an event record costs stream time)")
     ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the in-flight schedule (2: the band chains of two steps side by side)")
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the pipelined schedule (the chain workgroups need free CUs)")
@@ -276,7 +277,7 @@ def main():
                 mm._h.set_phi_workgroups(args.phi_workgroups)
                 mm._h.set_phi_deferred_reduce(1)     # the N-side stream carries the streaming kernels only
                 lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False, 0])
-            s_phi = torch.cuda.Stream()
+            s_phis = [torch.cuda.Stream() for _ in range(max(1, args.phi_streams))]
             s_chains = [torch.cuda.Stream(priority=-1) for _ in range(max(1, args.chain_streams))]
             turn = [0]
 
@@ -289,7 +290,7 @@ def main():
                 if not pending:
                     return
                 ev = pending[-1][1]
-                ev.record(s_phi)
+                ev.record(s_phis[pending[-1][0][4] % len(s_phis)])
                 for lane, _ in pending:
                     mm, ev_done = lane[0], lane[2]
                     s_chain = s_chains[lane[4] % len(s_chains)]
@@ -310,7 +311,7 @@ def main():
                 turn[0] += 1
                 if used:
                     ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
-                with torch.cuda.stream(s_phi):
+                with torch.cuda.stream(s_phis[lane[4] % len(s_phis)]):
                     mm.phi_pass(allreduce=False)         # (reduce deferred: the partial statistics of all workgroups)
                 pending.append((lane, ev_stats))
                 if len(pending) >= group:
