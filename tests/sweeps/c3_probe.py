@@ -1,5 +1,5 @@
 """BASELINE config 3 (N = 10M, M = 4096, Matern-5/2, B4Spline): timings per band algorithm and parity of the statistics, the
-bound and the gradient against the oracle (fp64 reference order and long double).  usage: python tools/c3_probe.py [N] [lengthscale]
+bound and the gradient against the oracle (fp64 reference order and long double).  usage: python tests/sweeps/c3_probe.py [N] [lengthscale]
 (N = 1_250_000 is one rank's share of the 8-GPU run).  BASELINE names no theta for this configuration: at the north star's
 lengthscale 0.05 (205 cells) Matern-5/2 gives cond(Kuu) ~ 1e17 - beyond fp64 for ANY elimination order, the oracle's own fp64 and
 long-double values differ by 6e3 - so the parity figure is taken at lengthscale 0.005 (20 cells, cond ~ 1e9)."""

@@ -1,5 +1,5 @@
 """Per-term accuracy of the bound at the BASELINE size: [log|Kuu|, log|P|, tr(Kuu^-1 A), |c|^2] of every band algorithm against the
-oracle's fp64 and long-double evaluations (gpurun: python tools/elbo_terms.py)."""
+oracle's fp64 and long-double evaluations (gpurun: python tests/sweeps/elbo_terms.py)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

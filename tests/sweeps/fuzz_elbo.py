@@ -1,5 +1,5 @@
 """Randomised parity sweep of ELBO + gradient + posterior against the oracle (run on the GPU box; prints failures).
-usage: python tools/fuzz_elbo.py [n_cases] [seed]"""
+usage: python tests/sweeps/fuzz_elbo.py [n_cases] [seed]"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A

@@ -1,5 +1,5 @@
 """Randomised parity sweep of GPR_kron and GPR_additive against the dense oracle (run on the GPU box).
-usage: python tools/fuzz_kron_additive.py [n_cases] [seed]"""
+usage: python tests/sweeps/fuzz_kron_additive.py [n_cases] [seed]"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A

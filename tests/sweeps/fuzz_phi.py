@@ -1,5 +1,5 @@
 """Randomised parity sweep of the Phi pass against the oracle (not a unit test: run on the GPU box, prints failures).
-usage: python tools/fuzz_phi.py [n_cases] [seed] [n_big]      n_big: additional cases at N = 10M (headline size), M in {512..4096}"""
+usage: python tests/sweeps/fuzz_phi.py [n_cases] [seed] [n_big]      n_big: additional cases at N = 10M (headline size), M in {512..4096}"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A

@@ -529,7 +529,7 @@ def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
 def test_phi_pass_on_float32_linspace_mesh_cells_that_are_not_exactly_delta_wide(A, order, M, N, dist):
     """basis.py:17 builds the knots of (-3.5, 10.5) in float32 (tf.linspace of Python floats): the cells are up to ulp32(10.5)/delta
     = 1e-4 wider than delta, so t = (x - knot)/delta reaches 1.0001 and the reference simply evaluates its pieces there.  (Found
-    by tools/fuzz_phi.py: the moment kernel's first 'outside the mesh' test was |t - 1/2| <= 0.50001 and reported such points.)"""
+    by tests/sweeps/fuzz_phi.py: the moment kernel's first 'outside the mesh' test was |t - 1/2| <= 0.50001 and reported such points.)"""
     rng = np.random.default_rng(order * M)
     a, b = -3.5, 10.5
     lo, hi = a + 1e-9 * (b - a), b - 1e-9 * (b - a)
@@ -970,7 +970,7 @@ def test_phi_fixed_point_scale_fallback(A):
     bs = A.B4Spline(0, 1, M)
     for kind in ("late_large", "zero_head", "zero_head_tiny", "tiny"):
         y = 1e-3 * rng.normal(size=N)
-        if kind == "zero_head_tiny":          # nothing to scale by in the first tile, small values afterwards (found by tools/fuzz_phi.py)
+        if kind == "zero_head_tiny":          # nothing to scale by in the first tile, small values afterwards (found by tests/sweeps/fuzz_phi.py)
             y[:4096] = 0.0
             y[4096:] = 1e-7 * rng.normal(size=N - 4096)
         elif kind == "late_large":
