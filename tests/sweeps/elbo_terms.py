@@ -2,7 +2,7 @@
 oracle's fp64 and long-double evaluations (gpurun: python tests/sweeps/elbo_terms.py)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import asvgp_amd as A
 import bench
 from oracle import asvgp_oracle as O
