@@ -297,11 +297,12 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
 
 
 class GPR_kron(_GPModelSurface, _ShardedStats):
-    """Drop-in for asvgp/gpr.py:239-359 (d = 2): GPR_kron((X[N,2], y[N,1]), kernels, bases) with elbo(),
+    """Drop-in for asvgp/gpr.py:239-359: GPR_kron((X[N,d], y[N,1]), kernels, bases) with elbo(),
     maximum_log_likelihood_objective(), training_loss(), predict_f(Xnew).  Never densifies: KufKfu is a block band
     (asvgp_phi_accumulate_kron2d), Kuu = K1 (x) K2 is handled factor-wise (log|Kuu| = m2 log|K1| + m1 log|K2|, the trace
     needs only band(K1^-1) (x) band(K2^-1)), and P = Kuu + KufKfu/sigma2 is a bandwidth k(m2+1) band matrix factorised by a
-    blocked band Cholesky - the reference runs dense O(M_tot^3) tf.linalg.cholesky (gpr.py:293)."""
+    blocked band Cholesky - the reference runs dense O(M_tot^3) tf.linalg.cholesky (gpr.py:293).  That is the d = 2 path (every
+    reference configuration); any other d takes the reference's own dense route on the device (_init_dense), small grids only."""
 
     def __init__(self, data, kernels, bases, process_group=None, distributed=None):
         dev = bases[0].device
@@ -309,11 +310,13 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         self.n, self.d = self.X.shape[0], self.X.shape[1]
         assert len(kernels) == len(bases) == self.d          # gpr.py:247
         assert self.y.shape[1] == 1                          # gpr.py:248
-        if self.d != 2:
-            raise NotImplementedError("asvgp_amd.GPR_kron implements the d = 2 tensor product (all reference configs)")
         for kern in kernels:
             assert isinstance(kern, (kernels_mod.Matern12, kernels_mod.Matern32, kernels_mod.Matern52))
-        assert bases[0].order == bases[1].order
+        assert all(bs.order == bases[0].order for bs in bases)
+        self._dense_mode = self.d != 2
+        if self._dense_mode:      # d != 2 (no reference config): the reference's own dense route (gpr.py:266-308) on the device
+            self._init_dense(kernels, bases, process_group, distributed)
+            return
         for i, bs in enumerate(bases):
             _require_inside(self.X[:, i], bs.a, bs.b, False, "GPR_kron dimension %d" % i)
         self.kernels, self.bases = kernels, bases
@@ -337,6 +340,119 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         self._info = torch.zeros(1, dtype=torch.int32, device=dev)
         self._post = None
 
+    # ---- d != 2: dense tensor-product route, as the reference does it for every d (kronecker.py:32-33 folds over any d;
+    # gpr.py:266-272 densifies Kuf Kuf^T, 286-308 dense Cholesky).  The statistics are [M_tot^2 dense Kuf Kuf^T | Kuf y | y^T y]
+    # (one all-reduce); the Khatri-Rao rows come from the per-dimension HIP evaluate kernels, everything after that is dense
+    # device linear algebra through torch.  No reference configuration uses it; sizes are limited by M_tot^2 memory.
+    def _init_dense(self, kernels, bases, process_group, distributed):
+        for i, bs in enumerate(bases):
+            _require_inside(self.X[:, i], bs.a, bs.b, False, "GPR_kron dimension %d" % i)
+        self.kernels, self.bases = kernels, bases
+        self.kernel = kernels[-1]
+        self.likelihood = kernels_mod.Gaussian()
+        self.m, self.order = bases[0].m, bases[0].order
+        self.bandwidth = int((self.m ** self.d - 1) * self.order / (self.m - 1)) if self.m > 1 else 0   # gpr.py:262 (as written)
+        self.inducing_features = [SplineFeatures1D(kernels[i], bases[i]) for i in range(self.d)]
+        self.Mtot = 1
+        for bs in bases:
+            self.Mtot *= bs.m
+        if self.Mtot > 8192:
+            raise NotImplementedError("GPR_kron with d != 2 takes the dense route: M_tot = %d is too large for it" % self.Mtot)
+        dev = self._dev = bases[0].device
+        self._stats = torch.zeros(self.Mtot * self.Mtot + self.Mtot + 1, dtype=torch.float64, device=dev)
+        self._setup_dist(process_group, distributed)
+        self._phi_pass_local()
+        self.num_data = allreduce_stats(self._stats, self.n, process_group) if self._distributed else self.n
+        self.KufKfu = self._stats[:self.Mtot * self.Mtot].view(self.Mtot, self.Mtot)
+        self.Kuf_y = self._stats[self.Mtot * self.Mtot:self.Mtot * self.Mtot + self.Mtot].view(self.Mtot, 1)
+        self.tr_yTy = self._stats[-1]
+        self._info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._post = None
+
+    def _dense_rows(self, X):
+        """Khatri-Rao design matrix (M_tot, n) of a chunk of points, dim-0 major (kronecker.py:27-33)."""
+        Phi = None
+        for i, bs in enumerate(self.bases):
+            P = bs.evaluate_basis(X[:, i:i + 1].contiguous(), sparse=False)              # (m_i, n)
+            Phi = P if Phi is None else (Phi[:, None, :] * P[None, :, :]).reshape(-1, X.shape[0])
+        return Phi
+
+    def _dense_phi_pass(self, chunk=8192):
+        M = self.Mtot
+        A = torch.zeros((M, M), dtype=torch.float64, device=self._dev)
+        b = torch.zeros((M, 1), dtype=torch.float64, device=self._dev)
+        for lo in range(0, self.n, chunk):
+            Phi = self._dense_rows(self.X[lo:lo + chunk])
+            A += Phi @ Phi.t()
+            b += Phi @ self.y[lo:lo + chunk]
+        self._stats[:M * M] = A.reshape(-1)
+        self._stats[M * M:M * M + M] = b.reshape(-1)
+        self._stats[-1] = (self.y * self.y).sum()
+        self._post = None
+        return self._stats
+
+    def _dense_factor(self):
+        s = float(self.likelihood.variance)
+        Ks, dKs = [], []
+        for feat, kern in zip(self.inducing_features, self.kernels):
+            K, dK, _, _, _, _ = feat.inverse_band(kern)
+            Ks.append(utils.band_to_dense_sym(K)); dKs.append(utils.band_to_dense_sym(dK))
+        Kuu = Ks[0]
+        for K in Ks[1:]:
+            Kuu = torch.kron(Kuu, K)
+        LK, info = torch.linalg.cholesky_ex(Kuu)
+        if int(info.item()):
+            raise NotPositiveDefiniteError("Kuu = kron(K_i) not positive definite at column %d" % (int(info.item()) - 1))
+        P = self.KufKfu / s + Kuu
+        LP, info = torch.linalg.cholesky_ex(P)
+        if int(info.item()):
+            raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite at column %d" % (int(info.item()) - 1))
+        return dict(s=s, Ks=Ks, dKs=dKs, Kuu=Kuu, LK=LK, LP=LP)
+
+    def _dense_elbo_and_grad(self, want_grad=True):
+        f = self._dense_factor()
+        s, N, A, bvec = f["s"], float(self.num_data), self.KufKfu, self.Kuf_y
+        vs = [float(k.variance) for k in self.kernels]
+        vprod = float(np.prod(vs))
+        alpha = torch.cholesky_solve(bvec, f["LP"]) / s
+        KinvA = torch.cholesky_solve(A, f["LK"])
+        tr = torch.trace(KinvA)
+        bTa = (bvec * alpha).sum()
+        elbo = (-0.5 * N * math.log(2 * math.pi * s) - torch.log(torch.diagonal(f["LP"])).sum() + torch.log(torch.diagonal(f["LK"])).sum()
+                - 0.5 * self.tr_yTy / s + 0.5 * bTa / s - 0.5 * N * vprod / s + 0.5 * tr / s)
+        if not want_grad:
+            return elbo, None
+        Kinv = torch.cholesky_inverse(f["LK"])
+        Pinv = torch.cholesky_inverse(f["LP"])
+        G = 0.5 * (Kinv - Pinv - alpha @ alpha.t() - KinvA @ Kinv / s)                  # SURVEY App. A-6
+        g = []
+        for i in range(self.d):
+            Kd = None
+            for j in range(self.d):
+                Mj = f["dKs"][j] if j == i else f["Ks"][j]
+                Kd = Mj if Kd is None else torch.kron(Kd, Mj)
+            g.append((G * (-f["Kuu"] / vs[i])).sum() - 0.5 * N * vprod / (vs[i] * s))
+            g.append((G * Kd).sum())
+        s2 = s * s
+        g.append(-0.5 * N / s + 0.5 * (Pinv * A).sum() / s2 + 0.5 * self.tr_yTy / s2 + 0.5 * (alpha.t() @ A @ alpha).reshape(()) / s2
+                 - bTa / s2 + 0.5 * N * vprod / s2 - 0.5 * tr / s2)
+        return elbo, torch.stack([x.reshape(()) for x in g])
+
+    def _dense_predict(self, Xnew, chunk=8192):
+        f = self._dense_factor()
+        s = f["s"]
+        alpha = torch.cholesky_solve(self.Kuf_y, f["LP"]) / s
+        X = _to_device(Xnew, self._dev)
+        vprod = float(np.prod([float(k.variance) for k in self.kernels]))
+        means, vars_ = [], []
+        for lo in range(0, X.shape[0], chunk):
+            Phi = self._dense_rows(X[lo:lo + chunk])
+            means.append(Phi.t() @ alpha)
+            tP = torch.linalg.solve_triangular(f["LP"], Phi, upper=False)
+            tK = torch.linalg.solve_triangular(f["LK"], Phi, upper=False)
+            vars_.append((vprod + (tP * tP).sum(0) - (tK * tK).sum(0)).reshape(-1, 1))     # gpr.py:319-330
+        return torch.cat(means), torch.cat(vars_)
+
     def _sort_by_cell(self):
         """Rows of (X, y) permuted into 2-D cell order + the cell offsets (the data are immutable: sorted once)."""
         lib = get_lib()
@@ -356,6 +472,8 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
     def _phi_pass_local(self, sorted_cells=True):
         """The N-dependent pass over this rank's rows -> [block band | Kuf y | y^T y].  Default: cell-sorted accumulation (one atomic per band entry and
         cell); sorted_cells=False: the per-point atomic kernel (asvgp_phi_accumulate_kron2d), same statistics."""
+        if self._dense_mode:
+            return self._dense_phi_pass()
         b1, b2 = self.bases
         lib = get_lib()
         if sorted_cells and self.n > 0:
@@ -426,6 +544,8 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
 
     def elbo(self):
         """gpr.py:282-308."""
+        if self._dense_mode:
+            return self._dense_elbo_and_grad(want_grad=False)[0]
         f = self._factor(want_alpha=False)
         s = f["s"]
         N = float(self.num_data)
@@ -489,6 +609,9 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         (asvgp_kron_grad_terms) from the band-restricted inverse of P and the two 1-D inverse bands."""
         from . import banded
         lib = get_lib()
+        if self._dense_mode:
+            e, g = self._dense_elbo_and_grad()
+            return float(e), g.cpu().numpy()
         f = self._factor(want_alpha=False)
         SigD, SigS, Bb = self._selinv(f)                         # (also fills f["alpha"])
         s, N = f["s"], float(self.num_data)
@@ -557,6 +680,8 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
 
     def predict_f_device(self, Xnew, chunk=4096):
         lib = get_lib()
+        if self._dense_mode:
+            return self._dense_predict(Xnew)
         key = self.theta()
         if self._post is None or self._post[0] != key:
             f = self._factor(want_alpha=False)

@@ -790,6 +790,34 @@ def test_kron_fit_improves_bound(A):
     assert float(model.likelihood.variance) < 0.5      # started at 1.0, the data noise is 0.01
 
 
+def test_kron_three_dimensions_dense_route_vs_oracle(A):
+    """kronecker.py:32-33 folds over any number of dimensions and gpr.py:260-308 is dense for all of them; d = 2 has the banded HIP
+    path, any other d takes the same dense route on the device: bound, analytic gradient, posterior and one optimiser step for
+    d = 3 against the dense oracle."""
+    rng = np.random.default_rng(33)
+    N = 4000
+    X = rng.uniform(0.001, 0.999, (N, 3))
+    y = (np.sin(5 * X[:, :1]) * np.cos(3 * X[:, 1:2]) + X[:, 2:] ** 2 + 0.1 * rng.standard_normal((N, 1)))
+    ms, kinds, th, s = [7, 8, 9], [1, 0, 1], [(1.0, 0.5), (0.8, 0.6), (1.2, 0.4)], 0.05
+    bases = [_mk_basis(A, 2, 0, 1, m) for m in ms]
+    obases = [O.Basis(2, 0, 1, m) for m in ms]
+    kerns = [_kernel(A, kd, v, l) for kd, (v, l) in zip(kinds, th)]
+    model = A.GPR_kron((X, y), kerns, bases)
+    model.likelihood.variance.assign(s)
+    oe, og = O.elbo_grad_kron(obases, kinds, th, s, X, y)
+    e, g = model.elbo_and_grad()
+    assert abs(e - oe) <= 1e-9 * abs(oe) + 1e-8 * (0.5 * N / s)
+    assert abs(model.elbo().item() - e) <= 1e-10 * abs(e)
+    np.testing.assert_allclose(g, og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
+    Xs = rng.uniform(0.01, 0.99, (200, 3))
+    om, ov = O.predict_f_kron(obases, kinds, th, s, X, y, Xs)
+    mean, var = model.predict_f(Xs)
+    np.testing.assert_allclose(mean, om, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(var[:, :1], ov[:, :1] if ov.ndim == 2 else ov.reshape(-1, 1), rtol=0, atol=1e-8)
+    res = model.fit(maxiter=2)
+    assert np.isfinite(res.fun)
+
+
 # ------------------------------------------------------------------------------------------------ additive model
 def _additive_case(A, rng, N, specs):
     d = len(specs)
