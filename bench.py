@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3), help="0 auto (planned prior chain), 1 sequential sweeps, "
                     "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
-    ap.add_argument("--in-flight", type=int, default=5, choices=(1, 2, 3, 4, 5, 6, 8), help="steps in flight: 1 = one step at a time on one stream; "
+    ap.add_argument("--in-flight", type=int, default=5, choices=tuple(range(1, 25)), help="steps in flight: 1 = one step at a time on one stream; "
                     "L >= 2 = the Phi pass of step i+1 (N-side stream) runs under the band chains of step i (M-side stream), L sets of buffers")
     ap.add_argument("--phi-streams", type=int, default=1, help="in-flight schedule: N-side streams (2: consecutive Phi kernels may overlap at their ends)")
     ap.add_argument("--event-group", type=int, default=1, help="in-flight schedule: Phi passes per cross-stream event (an event record costs stream time)")
