@@ -36,6 +36,9 @@ SIGNATURES = {
     "asvgp_unpack_banded_matrix_to_dense": (_I, [_P, _P, _L, _I, _I, _P]),
     "asvgp_pack_dense_matrix_to_banded": (_I, [_P, _P, _L, _I, _I, _P]),
     "asvgp_band_trace_sym": (_I, [_P, _P, _L, _I, _P, _P]),
+    "asvgp_cholesky_band_vjp": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "asvgp_inverse_from_cholesky_band_vjp": (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
+    "asvgp_band_outer_product": (_I, [_P, _P, _L, _L, _I, _D, _P, _P]),
     "asvgp_elbo_workspace_bytes": (_Z, [_L, _I, _L]),
     "asvgp_set_band_algorithm": (_I, [_P, _I]),
     "asvgp_prior_plan_1d": (_I, [_P, _P, _I, _L, _I, _c.POINTER(_I)]),

@@ -266,6 +266,130 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
   return dispatch_k<TrsvLauncher>(k, L, (int)M, B, X, (long)D, transpose_left, as_stream(stream));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Reverse mode of the four operators the reference's bound differentiates through (gpr.py:56-75; banded_matrices registers these
+// gradients for its TF ops).  The two recurrences are the adjoints of the column loops, run by ONE thread (the band, its adjoint and
+// the forward result staged in the LDS when they fit): functional, millisecond-scale at M = 2048 - the training path of this library
+// is the fused asvgp_elbo_grad_1d (one launch, analytic gradient), these exist so that a per-op binding can back-propagate at all.
+// ---------------------------------------------------------------------------------------------------------
+__device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
+  for (int j = M - 1; j >= 0; --j) {
+    const int hi = (j + k < M - 1) ? j + k : M - 1;
+    const double ljj = L[j];
+    for (int i = hi; i >= j; --i) {
+      double sb;
+      if (i == j) sb = Lb[j] / (2.0 * ljj);
+      else {
+        const double lb = Lb[(long)(i - j) * M + j];
+        sb = lb / ljj;
+        Lb[j] -= lb * L[(long)(i - j) * M + j] / ljj;
+      }
+      Kb[(long)(i - j) * M + j] = sb;
+      for (int p = (i - k > 0 ? i - k : 0); p < j; ++p) {
+        const double lip = L[(long)(i - p) * M + p], ljp = L[(long)(j - p) * M + p];
+        Lb[(long)(i - p) * M + p] -= sb * ljp;
+        Lb[(long)(j - p) * M + p] -= sb * lip;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void band_cholesky_vjp_kernel(const double* __restrict__ L, const double* __restrict__ Lbar, double* __restrict__ Kbar,
+                                                                double* __restrict__ work, int M, int k, int use_lds) {
+  extern __shared__ double sh[];
+  const long E = (long)(k + 1) * M;
+  double* Lw = use_lds ? sh : const_cast<double*>(L);
+  double* Lb = use_lds ? sh + E : work;
+  for (long e = threadIdx.x; e < E; e += blockDim.x) {
+    if (use_lds) Lw[e] = L[e];
+    Lb[e] = Lbar[e];
+    Kbar[e] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) chol_vjp_sweep(Lw, Lb, Kbar, M, k);
+}
+
+__device__ void taka_vjp_sweep(const double* L, const double* S, double* Sb, double* Lbo, int M, int k) {
+  for (int j = 0; j < M; ++j) {
+    const int hi = (j + k < M - 1) ? j + k : M - 1;
+    const double ljj = L[j];
+    double lb[ASVGP_MAX_BANDWIDTH + 1];
+    for (int d = 0; d <= k; ++d) lb[d] = 0.0;
+    for (int i = j; i <= hi; ++i) {
+      const double sb = Sb[(long)(i - j) * M + j];
+      const double accb = sb / ljj;
+      lb[0] -= sb * S[(long)(i - j) * M + j] / ljj;
+      if (i == j) lb[0] -= accb / (ljj * ljj);
+      for (int p = j + 1; p <= hi; ++p) {
+        const long o = (p >= i) ? (long)(p - i) * M + i : (long)(i - p) * M + p;     // symmetric in-band entry (p, i)
+        lb[p - j] -= accb * S[o];
+        Sb[o] -= accb * L[(long)(p - j) * M + j];
+      }
+    }
+    for (int d = 0; d <= k; ++d) Lbo[(long)d * M + j] = (j + d < M) ? lb[d] : 0.0;
+  }
+}
+__global__ __launch_bounds__(256) void band_takahashi_vjp_kernel(const double* __restrict__ L, const double* __restrict__ S, const double* __restrict__ Sbar,
+                                                                 double* __restrict__ Lbar, double* __restrict__ work, int M, int k, int use_lds) {
+  extern __shared__ double sh[];
+  const long E = (long)(k + 1) * M;
+  double* Lw = use_lds ? sh : const_cast<double*>(L);
+  double* Sw = use_lds ? sh + E : const_cast<double*>(S);
+  double* Sb = use_lds ? sh + 2 * E : work;
+  for (long e = threadIdx.x; e < E; e += blockDim.x) {
+    if (use_lds) { Lw[e] = L[e]; Sw[e] = S[e]; }
+    Sb[e] = Sbar[e];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) taka_vjp_sweep(Lw, Sw, Sb, Lbar, M, k);
+}
+
+// out[d, j] = sign * sum_c U[j + d, c] V[j, c]   (d = 0..k): the lower band of sign * U V^T  (Lbar of the triangular solves)
+__global__ void band_outer_kernel(const double* __restrict__ U, const double* __restrict__ V, long M, long D, int k, double sign, double* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)(k + 1) * M) return;
+  const long d = e / M, j = e - d * M;
+  double acc = 0.0;
+  if (j + d < M)
+    for (long c = 0; c < D; ++c) acc = fma(U[(j + d) * D + c], V[j * D + c], acc);
+  out[e] = sign * acc;
+}
+
+extern "C" int asvgp_cholesky_band_vjp(const double* L, const double* Lbar, double* Kbar, double* work, int64_t M, int k, asvgp_stream_t stream) {
+  int rc = band_args_ok(L, Lbar, M, k, "cholesky_band_vjp");
+  if (rc) return rc;
+  if (!Kbar || !work) { set_error("cholesky_band_vjp: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
+  const int use_lds = bytes <= 150 * 1024;
+  if (use_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_cholesky_vjp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+  }
+  hipLaunchKernelGGL(band_cholesky_vjp_kernel, dim3(1), dim3(256), use_lds ? bytes : 0, as_stream(stream), L, Lbar, Kbar, work, (int)M, k, use_lds);
+  return check_launch("cholesky_band_vjp");
+}
+
+extern "C" int asvgp_inverse_from_cholesky_band_vjp(const double* L, const double* S, const double* Sbar, double* Lbar, double* work, int64_t M,
+                                                    int k, asvgp_stream_t stream) {
+  int rc = band_args_ok(L, S, M, k, "inverse_from_cholesky_band_vjp");
+  if (rc) return rc;
+  if (!Sbar || !Lbar || !work) { set_error("inverse_from_cholesky_band_vjp: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  const size_t bytes = sizeof(double) * 3 * (size_t)(k + 1) * (size_t)M;
+  const int use_lds = bytes <= 150 * 1024;
+  if (use_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_takahashi_vjp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+  }
+  hipLaunchKernelGGL(band_takahashi_vjp_kernel, dim3(1), dim3(256), use_lds ? bytes : 0, as_stream(stream), L, S, Sbar, Lbar, work, (int)M, k, use_lds);
+  return check_launch("inverse_from_cholesky_band_vjp");
+}
+
+extern "C" int asvgp_band_outer_product(const double* U, const double* V, int64_t M, int64_t D, int k, double sign, double* out, asvgp_stream_t stream) {
+  if (!U || !V || !out || M < 1 || D < 1 || k < 0 || k > ASVGP_MAX_BANDWIDTH) { set_error("band_outer_product: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  const long total = (long)(k + 1) * M;
+  hipLaunchKernelGGL(band_outer_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), U, V, (long)M, (long)D, k, sign, out);
+  return check_launch("band_outer_product");
+}
+
 #define EW_LAUNCH(kern, total, ...)                                                                        \
   hipLaunchKernelGGL(kern, dim3((unsigned)(((total) + 255) / 256)), dim3(256), 0, as_stream(stream), __VA_ARGS__)
 

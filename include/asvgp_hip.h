@@ -134,6 +134,22 @@ int asvgp_pack_dense_matrix_to_banded(const double* dense, double* band, int64_t
 /* fused gpr.py:59-70: out[0] = trace(sym(S) sym(A)) for two lower bands (the only use of product_band_band on the path). */
 int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, double* out, asvgp_stream_t stream);
 
+/* Reverse mode (vector-Jacobian products) of the operators above - what banded_matrices registers as the gradients of its TF ops, so
+ * that a per-op binding (INTEGRATION.md Level 2) can back-propagate through gpr.py:56-75.  Bands are lower bands (k+1, M); `work` is
+ * (k+1) * M doubles of scratch.  The two recurrences run as single-thread adjoint sweeps (functional, not tuned: milliseconds at
+ * M = 2048; the training path of this library is the fused asvgp_elbo_grad_1d).
+ *   cholesky_band_vjp:              Kbar = d<Lbar, cholesky_band(K)> / dK          (over the stored lower-band entries)
+ *   inverse_from_cholesky_band_vjp: Lbar = d<Sbar, inverse_from_cholesky_band(L)> / dL   (S = the forward result)
+ *   solve_triang_mat:  X = L^-1 B:  Bbar = asvgp_solve_triang_mat(L, Xbar, transpose_left = 1),  Lbar = asvgp_band_outer_product(Bbar, X, sign = -1)
+ *                      X = L^-T B:  Bbar = asvgp_solve_triang_mat(L, Xbar, transpose_left = 0),  Lbar = asvgp_band_outer_product(X, Bbar, sign = -1)
+ *   product_band_band: Leftbar = product_band_band(Obar, transpose(Right)) cropped to Left's band, Rightbar = product_band_band(
+ *                      transpose(Left), Obar) cropped to Right's band (asvgp_transpose_band + asvgp_product_band_band).
+ * asvgp_band_outer_product: out[d, j] = sign * sum_c U[j + d, c] V[j, c], U, V dense (M, D) row-major. */
+int asvgp_cholesky_band_vjp(const double* L, const double* Lbar, double* Kbar, double* work, int64_t M, int k, asvgp_stream_t stream);
+int asvgp_inverse_from_cholesky_band_vjp(const double* L, const double* S, const double* Sbar, double* Lbar, double* work, int64_t M,
+                                         int k, asvgp_stream_t stream);
+int asvgp_band_outer_product(const double* U, const double* V, int64_t M, int64_t D, int k, double sign, double* out, asvgp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused ELBO + gradient   replaces GPR_1d.elbo gpr.py:49-89 and the TF reverse-mode pass through the
  * banded_matrices op gradients that opt.minimize(training_loss) triggers (example.py:31-32).

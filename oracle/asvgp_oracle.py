@@ -362,6 +362,79 @@ def inverse_from_cholesky_band(L, dL=None):
     return S if dL is None else (S, dS)
 
 
+def cholesky_band_vjp(L, Lbar):
+    """Reverse mode of cholesky_band (what banded_matrices registers for the op called at gpr.py:56,73): Kbar[d, j] = d<Lbar, L>/dK[d, j]
+    for the stored lower-band entries of K (each K[i, j], i > j, is read once by the recurrence).  The adjoint of the column loop."""
+    L = np.asarray(L, dtype=np.float64)
+    k, M = L.shape[0] - 1, L.shape[1]
+    Lb = np.array(Lbar, dtype=np.float64, copy=True)
+    Kb = np.zeros_like(L)
+    for j in range(M - 1, -1, -1):
+        for i in range(min(j + k, M - 1), j - 1, -1):
+            if i == j:
+                sb = Lb[0, j] / (2.0 * L[0, j])
+            else:
+                sb = Lb[i - j, j] / L[0, j]
+                Lb[0, j] -= Lb[i - j, j] * L[i - j, j] / L[0, j]
+            Kb[i - j, j] = sb
+            for p in range(max(0, i - k), j):
+                Lb[i - p, p] -= sb * L[j - p, p]
+                Lb[j - p, p] -= sb * L[i - p, p]
+    return Kb
+
+
+def inverse_from_cholesky_band_vjp(L, S, Sbar):
+    """Reverse mode of inverse_from_cholesky_band (gpr.py:59): Lbar = d<Sbar, S>/dL over the stored lower band of L, S the forward
+    result.  The adjoint of the Takahashi recurrence above, columns ascending."""
+    L = np.asarray(L, dtype=np.float64)
+    k, M = L.shape[0] - 1, L.shape[1]
+    Sb = np.array(Sbar, dtype=np.float64, copy=True)
+    Lb = np.zeros_like(L)
+
+    def sget(X, p, i):
+        return X[p - i, i] if p >= i else X[i - p, p]
+
+    for j in range(M):
+        hi = min(j + k, M - 1)
+        ljj = L[0, j]
+        for i in range(j, hi + 1):
+            sb = Sb[i - j, j]
+            accb = sb / ljj
+            Lb[0, j] -= sb * S[i - j, j] / ljj
+            if i == j:
+                Lb[0, j] -= accb / (ljj * ljj)
+            for p in range(j + 1, hi + 1):
+                Lb[p - j, j] -= accb * sget(S, p, i)
+                if p >= i:
+                    Sb[p - i, i] -= accb * L[p - j, j]
+                else:
+                    Sb[i - p, p] -= accb * L[p - j, j]
+    return Lb
+
+
+def solve_triang_mat_vjp(L, X, Xbar, transpose_left=False):
+    """Reverse mode of solve_triang_mat (gpr.py:75): X = L^-1 B gives Bbar = L^-T Xbar, Lbar = -band(Bbar X^T); the transposed solve
+    X = L^-T B gives Bbar = L^-1 Xbar, Lbar = -band(X Bbar^T).  Returns (Lbar (k+1, M), Bbar (M, D))."""
+    L = np.asarray(L, dtype=np.float64)
+    k, M = L.shape[0] - 1, L.shape[1]
+    Bb = solve_triang_mat(L, Xbar, transpose_left=not transpose_left)
+    Lb = np.zeros_like(L)
+    for d in range(k + 1):
+        if not transpose_left:
+            Lb[d, :M - d] = -np.sum(Bb[d:] * X[:M - d], axis=1)
+        else:
+            Lb[d, :M - d] = -np.sum(X[d:] * Bb[:M - d], axis=1)
+    return Lb, Bb
+
+
+def product_band_band_vjp(left, right, out_bar, ll, lu, rl, ru, ol, ou):
+    """Reverse mode of product_band_band (gpr.py:60-69): Leftbar = band_(ll,lu)(Obar Right^T), Rightbar = band_(rl,ru)(Left^T Obar)."""
+    Ld = unpack_banded_matrix_to_dense(left, ll, lu)
+    Rd = unpack_banded_matrix_to_dense(right, rl, ru)
+    Od = unpack_banded_matrix_to_dense(out_bar, ol, ou)
+    return pack_dense_matrix_to_banded(Od @ Rd.T, ll, lu), pack_dense_matrix_to_banded(Ld.T @ Od, rl, ru)
+
+
 def solve_triang_mat(L, B, transpose_left=False):
     """gpr.py:75: L^-1 B (or L^-T B) with L a lower band (k+1, M) and B dense (M, D)."""
     L = np.asarray(L, dtype=np.float64)

@@ -1293,6 +1293,83 @@ def test_config3_n10m_m4096_matern52_single_gpu(A):
     np.testing.assert_allclose(r[1:4], ge, rtol=5e-6)       # (1.6e-6 for every elimination order, the sequential one included: cond 1e9)
 
 
+def test_operator_vjps_vs_oracle_and_reference_style_bound_backpropagates(A):
+    """banded_matrices registers gradients for cholesky_band, inverse_from_cholesky_band, solve_triang_mat and product_band_band; the
+    reference's optimiser differentiates GPR_1d.elbo through them (gpr.py:56-87, example.py:31-32).  (i) each C-ABI VJP against the
+    oracle's adjoint sweeps (themselves checked against dense autograd on CPU); (ii) the bound written op by op exactly as
+    gpr.py:49-89 does, on torch scalars that require grad: back-propagation reproduces the fused analytic gradient."""
+    from asvgp_amd import banded as Bd
+    rng = np.random.default_rng(2)
+    M, k = 300, 4
+    ob = O.Basis(4, 0, 1, M)
+    K = O.make_Kuu(ob, 1, 1.0, 0.05)
+    L = O.cholesky_band(K)
+    S = O.inverse_from_cholesky_band(L)
+    Lbar = rng.standard_normal(L.shape)
+    Sbar = rng.standard_normal(L.shape)
+    for d in range(1, k + 1):
+        Lbar[d, M - d:] = 0
+        Sbar[d, M - d:] = 0
+    Kt = dev(K).requires_grad_(True)
+    Lt = Bd.cholesky_band(Kt)
+    (Lt * dev(Lbar)).sum().backward()
+    ref = O.cholesky_band_vjp(L, Lbar)
+    assert np.max(np.abs(Kt.grad.cpu().numpy() - ref)) <= 1e-9 * np.max(np.abs(ref))
+    Lt = dev(L).requires_grad_(True)
+    (Bd.inverse_from_cholesky_band(Lt) * dev(Sbar)).sum().backward()
+    ref = O.inverse_from_cholesky_band_vjp(L, S, Sbar)
+    assert np.max(np.abs(Lt.grad.cpu().numpy() - ref)) <= 1e-9 * np.max(np.abs(ref))
+    Bm, Xbar = rng.standard_normal((M, 2)), rng.standard_normal((M, 2))
+    for tr in (False, True):
+        Lt, Bt = dev(L).requires_grad_(True), dev(Bm).requires_grad_(True)
+        (Bd.solve_triang_mat(Lt, Bt, transpose_left=tr) * dev(Xbar)).sum().backward()
+        X = O.solve_triang_mat(L, Bm, transpose_left=tr)
+        rl, rb = O.solve_triang_mat_vjp(L, X, Xbar, transpose_left=tr)
+        assert np.max(np.abs(Lt.grad.cpu().numpy() - rl)) <= 1e-10 * np.max(np.abs(rl))
+        assert np.max(np.abs(Bt.grad.cpu().numpy() - rb)) <= 1e-10 * np.max(np.abs(rb))
+    Ssym, Asym = O.symmetrise_band(S, k), O.symmetrise_band(K, k)
+    Obar = rng.standard_normal(Ssym.shape)
+    St, At = dev(Ssym).requires_grad_(True), dev(Asym).requires_grad_(True)
+    (Bd.product_band_band(St, At, k, k, k, k, k, k) * dev(Obar)).sum().backward()
+    rl, rr = O.product_band_band_vjp(Ssym, Asym, Obar, k, k, k, k, k, k)
+    assert np.max(np.abs(St.grad.cpu().numpy() - rl)) <= 1e-12 * np.max(np.abs(rl))
+    assert np.max(np.abs(At.grad.cpu().numpy() - rr)) <= 1e-12 * np.max(np.abs(rr))
+
+    # (ii) gpr.py:49-89 op by op
+    N = 20000
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    v0, l0, s0 = 1.3, 0.04, 0.02
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=v0, lengthscales=l0), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(s0)
+    fused = model.elbo_and_grad().cpu().numpy()
+    v = torch.tensor(v0, dtype=torch.float64, device="cuda", requires_grad=True)
+    l = torch.tensor(l0, dtype=torch.float64, device="cuda", requires_grad=True)
+    sg = torch.tensor(s0, dtype=torch.float64, device="cuda", requires_grad=True)
+    St_ = model.inducing_features.static_stack(1)                    # A, B, C, BC, BC_grad (inducing_features.py:25-33)
+    s3 = np.sqrt(3.0)
+    cs = [s3 / (4 * l * v), l / (2 * s3 * v), l ** 3 / (12 * s3 * v), 1 / (2 * v), l ** 2 / (2 * v)]
+    Kuu = sum(c * St_[t] for t, c in enumerate(cs))
+    Aband, bvec, yy = model.KufKfu, model.Kuf_y, model.tr_yTy
+    Lk = Bd.cholesky_band(Kuu)                                        # gpr.py:56
+    logdet_K = torch.log(Lk[0] ** 2).sum()                            # gpr.py:57
+    Kinv = Bd.inverse_from_cholesky_band(Lk)                          # gpr.py:59
+    prod = Bd.product_band_band(Bd.symmetrise_band(Kinv, k), Bd.symmetrise_band(Aband, k), left_lower_bandwidth=k,
+                                left_upper_bandwidth=k, right_lower_bandwidth=k, right_upper_bandwidth=k,
+                                result_lower_bandwidth=0, result_upper_bandwidth=0)     # gpr.py:60-70: only the diagonal is summed
+    trace = prod.sum()
+    P = Aband / sg + Kuu                                              # gpr.py:72
+    Lp = Bd.cholesky_band(P)                                          # gpr.py:73
+    logdet_P = torch.log(Lp[0] ** 2).sum()
+    c = Bd.solve_triang_mat(Lp, bvec) / sg                            # gpr.py:75
+    elbo = (-0.5 * N * torch.log(2 * np.pi * sg) - 0.5 * logdet_P + 0.5 * logdet_K - 0.5 * yy / sg + 0.5 * (c ** 2).sum()
+            - 0.5 * N * v / sg + 0.5 * trace / sg)                    # gpr.py:78-87
+    elbo.backward()
+    assert abs(elbo.item() - fused[0]) <= 1e-9 * abs(fused[0])
+    got = np.array([v.grad.item(), l.grad.item(), sg.grad.item()])
+    np.testing.assert_allclose(got, fused[1:4], rtol=1e-7)
+
+
 def test_deferred_reduce_gives_the_same_statistics(A):
     """asvgp_set_phi_deferred_reduce / asvgp_phi_reduce_1d: the streaming kernel and the cross-workgroup reduce as two calls (the
     pipelined bench keeps the reduce off its N-side stream); same statistics as the fused call, and a reduce with nothing pending

@@ -288,3 +288,51 @@ def test_kron_long_double_yardstick_agrees_with_fp64_dense_bound_when_well_condi
     e64 = O.elbo_kron(bs, [1, 2], th, 0.05, X, y)[0]
     e80 = O.elbo_kron_extended(bs, [1, 2], th, 0.05, X, y)
     assert abs(e64 - e80) <= 1e-9 * abs(e80)
+
+
+def test_operator_vjps_against_dense_autograd():
+    """oracle.cholesky_band_vjp / inverse_from_cholesky_band_vjp / solve_triang_mat_vjp (the adjoints of the band recurrences, what the
+    HIP VJP entry points are checked against) versus torch autograd through the dense equivalents."""
+    import torch
+    rng = np.random.default_rng(0)
+    M, k = 23, 3
+    ob = O.Basis(3, 0, 1, M)
+    K = O.make_Kuu(ob, 1, 1.0, 0.3)
+    L = O.cholesky_band(K)
+    S = O.inverse_from_cholesky_band(L)
+
+    def rand_band():
+        R = rng.standard_normal(L.shape)
+        for d in range(1, k + 1):
+            R[d, M - d:] = 0
+        return R
+
+    def lower_dense(Bt, sym):
+        Amat = torch.zeros(M, M, dtype=torch.float64)
+        for d in range(k + 1):
+            idx = torch.arange(M - d)
+            Amat = Amat + torch.zeros_like(Amat).index_put((idx + d, idx), Bt[d, :M - d])
+            if sym and d > 0:
+                Amat = Amat + torch.zeros_like(Amat).index_put((idx, idx + d), Bt[d, :M - d])
+        return Amat
+
+    def band_dot(Dm, R):
+        return sum((torch.diagonal(Dm, -d) * torch.tensor(R[d, :M - d])).sum() for d in range(k + 1))
+
+    Lbar, Sbar = rand_band(), rand_band()
+    Kt = torch.tensor(K, requires_grad=True)
+    band_dot(torch.linalg.cholesky(lower_dense(Kt, True)), Lbar).backward()
+    ref = Kt.grad.numpy()
+    assert np.max(np.abs(O.cholesky_band_vjp(L, Lbar) - ref)) <= 1e-12 * np.max(np.abs(ref))
+    Lt = torch.tensor(L, requires_grad=True)
+    Lf = lower_dense(Lt, False)
+    band_dot(torch.linalg.inv(Lf @ Lf.T), Sbar).backward()
+    ref = Lt.grad.numpy()
+    assert np.max(np.abs(O.inverse_from_cholesky_band_vjp(L, S, Sbar) - ref)) <= 1e-11 * np.max(np.abs(ref))
+    Bm, Xbar = rng.standard_normal((M, 2)), rng.standard_normal((M, 2))
+    for tr in (False, True):
+        Lt, Bt = torch.tensor(L, requires_grad=True), torch.tensor(Bm, requires_grad=True)
+        Lf = lower_dense(Lt, False)
+        (torch.linalg.solve_triangular(Lf.T if tr else Lf, Bt, upper=tr) * torch.tensor(Xbar)).sum().backward()
+        lb, bb = O.solve_triang_mat_vjp(L, O.solve_triang_mat(L, Bm, transpose_left=tr), Xbar, transpose_left=tr)
+        assert np.max(np.abs(lb - Lt.grad.numpy())) <= 1e-12 and np.max(np.abs(bb - Bt.grad.numpy())) <= 1e-12
