@@ -333,10 +333,10 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_kernel(const double* _
   extern __shared__ double sh[];
   const long E = (long)(k + 1) * M;
   double* Lw = use_lds ? sh : const_cast<double*>(L);
-  double* Sw = use_lds ? sh + E : const_cast<double*>(S);
-  double* Sb = use_lds ? sh + 2 * E : work;
+  const double* Sw = S;                               // (read-only: stays in global memory so that L and the adjoint fit the LDS at M = 2048)
+  double* Sb = use_lds ? sh + E : work;
   for (long e = threadIdx.x; e < E; e += blockDim.x) {
-    if (use_lds) { Lw[e] = L[e]; Sw[e] = S[e]; }
+    if (use_lds) Lw[e] = L[e];
     Sb[e] = Sbar[e];
   }
   __syncthreads();
@@ -359,7 +359,7 @@ extern "C" int asvgp_cholesky_band_vjp(const double* L, const double* Lbar, doub
   if (rc) return rc;
   if (!Kbar || !work) { set_error("cholesky_band_vjp: bad argument"); return ASVGP_ERR_BAD_ARG; }
   const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
-  const int use_lds = bytes <= 150 * 1024;
+  const int use_lds = bytes <= 160 * 1024;
   if (use_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_cholesky_vjp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
@@ -373,8 +373,8 @@ extern "C" int asvgp_inverse_from_cholesky_band_vjp(const double* L, const doubl
   int rc = band_args_ok(L, S, M, k, "inverse_from_cholesky_band_vjp");
   if (rc) return rc;
   if (!Sbar || !Lbar || !work) { set_error("inverse_from_cholesky_band_vjp: bad argument"); return ASVGP_ERR_BAD_ARG; }
-  const size_t bytes = sizeof(double) * 3 * (size_t)(k + 1) * (size_t)M;
-  const int use_lds = bytes <= 150 * 1024;
+  const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
+  const int use_lds = bytes <= 160 * 1024;
   if (use_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_takahashi_vjp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
