@@ -377,6 +377,10 @@ def main():
         serial = {"ms_per_step": ser_ms, "value": N / (dt / args.steps) / 1e6, "unit": "Mpoints/s", "phi_kernel_us": kern_us,
                   "roofline_frac": (BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else 0.0,
                   "schedule": "one step at a time on one stream: Phi pass -> reduce -> [all-reduce] -> band chains + finalize (one launch)"}
+        if pipe is not None and pipe["dt"] >= dt:      # (e.g. M = 4096: both kernels want the whole LDS of every CU - nothing to overlap)
+            pipe_error = (pipe_error or "") + "in-flight schedule measured slower than one step at a time (%.1f vs %.1f us per step): not used" % (
+                pipe["dt"] / args.steps * 1e6, dt / args.steps * 1e6)
+            pipe = None
         if pipe is not None:      # the headline schedule; the one-at-a-time figures ride along as `one_step_at_a_time`
             dt_v, kern_v, launches_v = pipe["dt"], pipe["kern_us"], pipe["launches"]
             schedule = ("%d steps in flight: one N-side stream (Phi pass, reduce, all-reduce of step i+1) under %d M-side stream(s) (band chains + "
