@@ -825,6 +825,33 @@ def test_kron_fit_improves_bound(A):
     assert float(model.likelihood.variance) < 0.5      # started at 1.0, the data noise is 0.01
 
 
+def test_config4_float32_data_is_accepted_and_upcast(A):
+    """BASELINE config 4 says fp32 (the reference computes in fp64 throughout): float32 X, y are accepted and upcast once on the device -
+    storage precision fp32, arithmetic fp64.  The bound equals the oracle's on the float32-rounded data and sits within the
+    configuration's 1e-3 gate of the fp64-data value."""
+    rng = np.random.default_rng(40)
+    N, ms = 30000, [20, 18]
+    X = rng.uniform(0.001, 0.999, (N, 2))
+    y = np.sin(6 * X[:, :1]) * np.cos(4 * X[:, 1:]) + 0.1 * rng.standard_normal((N, 1))
+    X32, y32 = X.astype(np.float32), y.astype(np.float32)
+    kinds, th, s = [1, 1], [(1.0, 0.3), (0.9, 0.4)], 0.05
+    obases = [O.Basis(3, 0, 1, m) for m in ms]
+
+    def build(Xa, ya):
+        mdl = A.GPR_kron((torch.from_numpy(Xa).cuda(), torch.from_numpy(ya).cuda()), [_kernel(A, kd, v, l) for kd, (v, l) in zip(kinds, th)],
+                         [_mk_basis(A, 3, 0, 1, m) for m in ms])
+        mdl.likelihood.variance.assign(s)
+        return mdl
+
+    m32 = build(X32, y32)
+    assert m32.X.dtype == torch.float64
+    e32 = float(m32.elbo())
+    o32 = O.elbo_kron(obases, kinds, th, s, X32.astype(np.float64), y32.astype(np.float64))[0]
+    o64 = O.elbo_kron(obases, kinds, th, s, X, y)[0]
+    assert abs(e32 - o32) <= 1e-9 * abs(o32) + 1e-8 * (0.5 * N / s)
+    assert abs(e32 - o64) <= 1e-3 * abs(o64)
+
+
 def test_kron_three_dimensions_dense_route_vs_oracle(A):
     """kronecker.py:32-33 folds over any number of dimensions and gpr.py:260-308 is dense for all of them; d = 2 has the banded HIP
     path, any other d takes the same dense route on the device: bound, analytic gradient, posterior and one optimiser step for
