@@ -1,4 +1,5 @@
-"""Diagnostic: per-level cycle stamps of the two BCR chains (ASVGP_BCR_STAMPS=1)."""
+"""Diagnostic: per-level cycle stamps of the two all-GPU BCR chains (band algorithm 2; ASVGP_BCR_STAMPS=1).  The default path (planned
+prior chain, fused launch) carries no stamps: its P chain is the same code as the "P chain" printed here."""
 import os, sys
 os.environ["ASVGP_BCR_STAMPS"] = sys.argv[1] if len(sys.argv) > 1 else "1"   # 2 = stamp a second, warm pass
 import numpy as np, torch
@@ -9,6 +10,7 @@ rng = np.random.default_rng(1234)
 x = rng.uniform(1e-9, 1 - 1e-9, N); y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
 model = A.GPR_1d((torch.from_numpy(x).cuda().reshape(-1, 1), torch.from_numpy(y).cuda().reshape(-1, 1)), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
 model.likelihood.variance.assign(0.01)
+A.set_band_algorithm(2)
 split = len(sys.argv) > 2 and sys.argv[2] == "split"   # the bench's path: prior kernel + data kernel instead of the two-chain kernel
 for _ in range(3):
     if split:
