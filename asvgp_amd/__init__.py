@@ -21,10 +21,10 @@ def set_band_algorithm(algo):
 
 
 def set_phi_algorithm(algo):
-    """0 = auto, 1 = fp64 LDS atomic band scatter, 3 = fixed-point band scatter, 5 = fixed-point centred-moment scatter
-    (asvgp_set_phi_algorithm) - applied to every live model handle and to models created later."""
+    """0 = auto, 1 = fp64 LDS atomic band scatter, 3 = fixed-point band scatter, 5 = fixed-point centred-moment scatter,
+    6 = tile sort + register moments (asvgp_set_phi_algorithm) - applied to every live model handle and to models created later."""
     from ._lib import AsvgpError, get_lib, set_default_algorithms
     get_lib()
-    if int(algo) not in (0, 1, 3, 5):
-        raise AsvgpError("set_phi_algorithm: 0, 1, 3 or 5")
+    if int(algo) not in (0, 1, 3, 5, 6):
+        raise AsvgpError("set_phi_algorithm: 0, 1, 3, 5 or 6")
     set_default_algorithms(phi=int(algo))

@@ -51,24 +51,32 @@ double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_o
   return h->tab_host + (size_t)slot * h->slot_doubles;
 }
 
-bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hipStream_t st, double* step_out) {
+bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hipStream_t st, double* step_out, double* first_out, double* last_out) {
   for (int i = 0; i < h->n_mesh_seen; ++i)
-    if (h->mesh_seen[i].ptr == mesh_dev && h->mesh_seen[i].n == n_mesh) { *step_out = h->mesh_seen[i].step; return h->mesh_seen[i].regular != 0; }
+    if (h->mesh_seen[i].ptr == mesh_dev && h->mesh_seen[i].n == n_mesh) {
+      *step_out = h->mesh_seen[i].step;
+      if (first_out) *first_out = h->mesh_seen[i].first;
+      if (last_out) *last_out = h->mesh_seen[i].last;
+      return h->mesh_seen[i].regular != 0;
+    }
   std::vector<double> m((size_t)n_mesh);
   bool regular = false;
-  double step = 0.0;
+  double step = 0.0, first = 0.0, last = 0.0;
   if (n_mesh >= 2 && hipMemcpyAsync(m.data(), mesh_dev, sizeof(double) * (size_t)n_mesh, hipMemcpyDeviceToHost, st) == hipSuccess &&
       hipStreamSynchronize(st) == hipSuccess) {
     const double m0 = m[0];
+    first = m0; last = m[n_mesh - 1];
     step = (m[n_mesh - 1] - m0) / (double)(n_mesh - 1);
-    regular = true;
+    regular = step > 0.0 && step == step;
     for (long i = 0; i < n_mesh - 1 && regular; ++i) {
       volatile double t = (double)i * step;        // two roundings, no contraction: what numpy.linspace does
       regular = (m[i] == t + m0);
     }
   }
-  if (h->n_mesh_seen < 8) h->mesh_seen[h->n_mesh_seen++] = Handle::MeshSeen{mesh_dev, n_mesh, regular ? 1 : 0, step};
+  if (h->n_mesh_seen < 8) h->mesh_seen[h->n_mesh_seen++] = Handle::MeshSeen{mesh_dev, n_mesh, regular ? 1 : 0, step, first, last};
   *step_out = step;
+  if (first_out) *first_out = first;
+  if (last_out) *last_out = last;
   return regular;
 }
 
@@ -99,8 +107,8 @@ extern "C" int asvgp_destroy(asvgp_handle_t handle) {
 }
 
 extern "C" int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo) {
-  if (algo != 0 && algo != 1 && algo != 3 && algo != 5) {
-    set_error("set_phi_algorithm: 0 auto (5 where it applies, else 3), 1 fp64 LDS-atomic band scatter, 3 fixed-point band scatter, 5 fixed-point centred-moment scatter");
+  if (algo != 0 && algo != 1 && algo != 3 && algo != 5 && algo != 6) {
+    set_error("set_phi_algorithm: 0 auto (6 where it applies, else 5, else 3), 1 fp64 LDS-atomic band scatter, 3 fixed-point band scatter, 5 fixed-point centred-moment scatter, 6 tile sort + register moments");
     return ASVGP_ERR_BAD_ARG;
   }
   as_handle(handle)->phi_algo = algo;

@@ -38,7 +38,7 @@ struct Handle {
   unsigned long long seq = 0;
   int plan_terms = 0;
   // meshes already inspected (handle_mesh_is_linspace): device pointer, length, first / last knot -> verdict
-  struct MeshSeen { const double* ptr; long n; int regular; double step; };
+  struct MeshSeen { const double* ptr; long n; int regular; double step, first, last; };
   MeshSeen mesh_seen[8];
   int n_mesh_seen = 0;
 };
@@ -48,7 +48,7 @@ Handle* as_handle(asvgp_handle_t h);      // NULL -> the process-wide default ha
 // Is the device mesh table the fp64 linspace numpy makes (knot i = i * step + start, last knot = stop)?  Decided once per
 // (pointer, length) from a host copy (a 16 KB device-to-host copy and ONE stream synchronisation, at the first Phi pass of a
 // model); the kernel instantiation that generates its knots on the VALU re-checks the table and reports a mismatch loudly.
-bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hipStream_t st, double* step_out);
+bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hipStream_t st, double* step_out, double* first_out, double* last_out);
 
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);

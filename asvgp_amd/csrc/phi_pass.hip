@@ -366,53 +366,10 @@ __global__ __launch_bounds__(PHI_THREADS) void phi_accumulate_kernel(
 }
 
 
-// Centred-moment coefficient tables: v_i(s + 1/2) and v_i v_j as polynomials in s = t - 1/2 with exact integer-ratio
-// coefficients (used by the centred-moment Phi pass to turn per-cell moments into band / rhs entries).
-using i128 = __int128;
-// Compile-time coefficient tables (constexpr constructor => guaranteed constant evaluation; every use below has
-// static indices after unrolling, so the entries fold into instruction literals).
-template <int K> struct MomTab {
-  double single[K + 1][K + 1];             // v_i(s + 1/2) = sum_p single[i][p] s^p
-  double pair[K + 1][K + 1][2 * K + 1];    // v_i v_j      = sum_p pair[i][j][p] s^p   (j >= i)
-  static constexpr long long pnum(int i, int q) {  // integer numerator of the t^q coefficient of piece i times K!
-    long long num = 0;
-    for (int j = 0; j <= i; ++j) {
-      long long term = binom(K + 1, j) * binom(K, q) * ipow(i - j, K - q);
-      num += (j & 1) ? -term : term;
-    }
-    return num;
-  }
-  constexpr MomTab() : single{}, pair{} {
-    long long m[K + 1][K + 1] = {};        // v_i(s + 1/2) = (1 / (K! 2^K)) sum_r m[i][r] s^r
-    for (int i = 0; i <= K; ++i)
-      for (int r = 0; r <= K; ++r) {
-        long long acc = 0;
-        for (int q = r; q <= K; ++q) acc += pnum(i, q) * binom(q, r) * (1LL << (K - q + r));
-        m[i][r] = acc;
-      }
-    const double d1 = (double)fact(K) * (double)(1LL << K);
-    const double d2 = (double)(fact(K) * fact(K)) * (double)(1LL << (2 * K));
-    for (int i = 0; i <= K; ++i) {
-      for (int p = 0; p <= K; ++p) single[i][p] = (double)m[i][p] / d1;
-      for (int j = i; j <= K; ++j)
-        for (int p = 0; p <= 2 * K; ++p) {
-          i128 acc = 0;
-          for (int r = 0; r <= K; ++r) {
-            int r2 = p - r;
-            if (r2 < 0 || r2 > K) continue;
-            acc += (i128)m[i][r] * (i128)m[j][r2];
-          }
-          pair[i][j][p] = (double)acc / d2;
-        }
-    }
-  }
-};
-template <int K> struct MomCoef {
-  static constexpr MomTab<K> tab{};
-};
-
 }  // namespace asvgp
+#include "phi_tables.hpp"
 #include "phi_moments.hpp"
+#include "phi_sort.hpp"
 namespace asvgp {
 
 
@@ -635,11 +592,54 @@ static int launch_phi_moments(Handle* h, const double* x, const double* y, long 
                               long M, double* stats, double* ws, hipStream_t st) {
   if (D != 1 || N < 1 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return 1;
   double step = 0.0;
-  const bool regular = handle_mesh_is_linspace(h, mesh, n_mesh, st, &step);
+  const bool regular = handle_mesh_is_linspace(h, mesh, n_mesh, st, &step, nullptr, nullptr);
   int rc = launch_phi_moments_cs<K, 512>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, regular, step);     // plane stride: smallest that holds the cells
   if (rc == 1) rc = launch_phi_moments_cs<K, 1024>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, regular, step);
   if (rc == 1) rc = launch_phi_moments_cs<K, 2048>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, regular, step);
   return rc;
+}
+
+// Tile-sort Phi pass (algorithm 6, phi_sort.hpp).  Returns 1 when it does not apply - D != 1, unaligned inputs, fewer than two points,
+// more than 2048 columns, a mesh that is not an exact numpy.linspace, or knots so large against delta that the arithmetic cell guess
+// has no safe margin - and the caller falls back to the moment scatter (5), then the band scatter (3).
+template <int K>
+static int launch_phi_sort(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh, double delta,
+                           long M, double* stats, double* ws, hipStream_t st) {
+  if (D != 1 || N < 2 || M > PS_NCELL || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return 1;
+  double step = 0.0, m0 = 0.0, m_last = 0.0;
+  if (!handle_mesh_is_linspace(h, mesh, n_mesh, st, &step, &m0, &m_last)) return 1;
+  const double amax = fabs(m0) > fabs(m_last) ? fabs(m0) : fabs(m_last);
+  const double margin = 16.0 * 2.220446049250313e-16 * amax / delta + 1e-12;   // knot rounding (two roundings <= ulp(|knot|)) over delta
+  if (!(margin < 0.125)) return 1;
+  constexpr int TP = ps_tile_points<K>();
+  size_t lds_bytes = ps_lds_bytes<K, TP>();
+  if (ps_epilogue_bytes<K>() > lds_bytes) lds_bytes = ps_epilogue_bytes<K>();
+  if (lds_bytes > 160 * 1024) return 1;
+  long nblk = (N + TP * PS_THREADS - 1) / (TP * PS_THREADS);   // at least one tile per workgroup
+  const long gmax = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
+  const int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
+  long ppb = (N + G - 1) / G;
+  ppb = (ppb + 1) & ~1L;
+  if (ppb > 0x3fffffffL) return 1;                              // (32-bit pair indices inside a workgroup)
+  PsArgs a;
+  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M;
+  a.m0 = m0; a.m_last = m_last; a.step = step; a.smax_fast = 0.5 - margin;
+  a.partials = ws; a.ppb = ppb; a.zero_ptr = stats; a.zero_n = (K + 2) * M + 1; a.stamps = nullptr; a.stamps_wave = 0;
+  auto kern = phi_sort_kernel<K, TP, 0, 1>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+  const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
+  if (prof) (void)hipEventRecord(h->prof_ev[h->prof_n][0], st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(PS_THREADS), lds_bytes, st, a);
+  if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
+  const int E1 = (int)((K + 2) * M + 1);
+  const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
+  if (h->phi_defer) {   // the caller enqueues the reduce itself (asvgp_phi_reduce_1d), e.g. on the stream that consumes the statistics
+    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true};
+    return check_launch("phi_accumulate_1d (tile sort, reduce deferred)");
+  }
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
+  return check_launch("phi_accumulate_1d (tile sort)");
 }
 
 // Band-scatter Phi pass (algorithms 1 and 3): the (k+1)(k+2)/2 + (k+1) products of every point go straight into the
@@ -649,6 +649,11 @@ static int launch_phi(Handle* h, const double* x, const double* y, long N, long 
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
   h->pend.valid = false;
   const int ncells = (int)n_mesh - 1;
+  if (h->phi_algo == 0 || h->phi_algo == 6) {
+    const int rc = launch_phi_sort<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
+    if (rc != 1) return rc;
+    if (h->phi_algo == 6) { set_error("phi algorithm 6 (tile sort) needs D == 1, N >= 2, M <= 2048, 16-byte aligned x / y and a mesh that is an exact linspace"); return ASVGP_ERR_UNSUPPORTED; }
+  }
   if (h->phi_algo == 0 || h->phi_algo == 5) {
     const int rc = launch_phi_moments<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
     if (rc != 1) return rc;

@@ -1,0 +1,579 @@
+// Phi pass, algorithm 6 ("tile sort", the default where it applies): per-cell centred moments accumulated in REGISTERS.
+//
+// Replaces (reference): basis.py:51-76 evaluate_basis + gpr.py:41-44 (Kuf@y, Kuf@Kuf.T, sparse_to_band, sum y^2), D = 1.
+// Same sufficient statistics as algorithm 5 (phi_moments.hpp): inside one mesh cell every entry of phi phi^T is a polynomial of
+// degree 2k in the centred local coordinate s = t - 1/2, so a cell's share of Phi Phi^T is the 2k+1 power sums S_p = sum s^p and
+// its share of Phi y the k+1 sums T_p = sum y s^p.  Algorithm 5 pays 3k+2 random-address LDS atomics and as many double -> fixed
+// point conversions per point (LDS pipe 39 us + VALU 42 us at N = 10M); here no statistic ever leaves the register file:
+//   thread t of the ONE 1024-thread workgroup per CU owns cells t and t + 1024 for the whole kernel (2 (3k+1) fp64 accumulators);
+//   the workgroup streams its points in tiles of TP x 1024; per tile
+//     P1  every lane finds cell and s of its TP points and takes a rank inside the cell with ONE returning ds_add_u32,
+//     P2  exclusive scan of the 2048 per-cell counts (DPP inside a wave, 16 wave totals through the LDS),
+//     P3  (s, y) scattered into cell order: one ds_write_b128 per point,
+//     P4  owners walk their two cells' runs: one ds_read_b128 + 4k fp64 operations per point (powers of s shared by S and T),
+//         wave-uniform trip count, lanes that have run out read a (0, 0) point which adds nothing;
+//   the next tile's loads are in flight during P4; cells with more than PS_HEAVY points in a tile (sorted / clustered input) are
+//   summed by the whole wavefront (DPP reduction), so time-series order is not a worst case.
+// Per point: 1 LDS atomic + 1 16-B write + 1 16-B read instead of 14 atomics, ~60 VALU instructions instead of ~157.
+// The sums inside a cell follow the arrival order of the rank atomics: results are reproducible to rounding (a few ulp of the
+// per-cell sums), not bit for bit - algorithm 5 (fixed point, order-independent) stays selectable for that.
+// Applies to meshes that are an exact numpy.linspace (the host decides, the kernel re-checks the table), D = 1, 16-B aligned
+// x / y, at most 2048 cells.  Epilogue: moments -> band entries through the exact integer-ratio tables MomTab, one partial
+// [band | Phi y | y^T y] per workgroup, summed by phi_reduce_kernel exactly like the other algorithms.
+#pragma once
+
+namespace asvgp {
+
+constexpr int PS_THREADS = 1024;
+constexpr int PS_NCELL = 2 * PS_THREADS;   // cells an image holds (two per thread)
+constexpr int PS_HEAVY = 48;               // points of one cell in one tile beyond which the whole workgroup sums the cell
+constexpr int PS_HROUND = 16;              // heavy cells summed per round (slots of the LDS hand-over table)
+constexpr int PS_HLIST = 8192 / (PS_HEAVY + 1) + 1;   // most heavy cells a tile can have
+
+struct PsArgs {
+  const double* x; const double* y; long N;
+  const double* mesh_g; int n_mesh; double inv_delta; int M;
+  double m0, m_last;       // first / last knot (the host's copy; the kernel checks the table against them)
+  double step;             // (last knot - first knot) / (n_mesh - 1) as the HOST rounds it (numpy.linspace's step)
+  double smax_fast;        // |s| below which the arithmetic cell guess is certainly the table's cell (1/2 - knot rounding margin)
+  double* partials;        // [workgroup][(K+2) M + 1] doubles: band | Phi y | y^T y  (the layout phi_reduce_kernel sums)
+  long ppb;                // points per workgroup (even)
+  double* zero_ptr; long zero_n;   // packed stats buffer to zero (phi_reduce_kernel adds into it afterwards)
+  unsigned long long* stamps;      // diagnostics: per-phase cycles of one wave's lane 0 (ABL == 9), else unused
+  int stamps_wave;
+};
+
+// points per thread and tile: as many as leave the 2 (3k+1) owner accumulators, the tile in flight and the current tile's (s, y, rank)
+// inside 128 VGPRs without a spill (a scratch reload counts in vmcnt and stalls on the prefetched tile)
+template <int K> constexpr int ps_tile_points() { return K <= 3 ? 8 : (K == 4 ? 6 : (K == 5 ? 4 : 2)); }
+template <int K, int TP> constexpr size_t ps_lds_bytes() {
+  return (size_t)(TP * PS_THREADS + 1) * 16 + (size_t)3 * PS_NCELL * 4 + 64 * 4 + 64 * 8 +
+         (size_t)PS_HROUND * (3 * K + 1) * 8 + (size_t)PS_HLIST * 12;
+}
+template <int K> constexpr size_t ps_epilogue_bytes() { return (size_t)(2 * K + 1) * (PS_THREADS + K) * 8; }
+
+// Workgroup barrier that orders LDS traffic only: global loads issued before it (the next tile's prefetch) stay in flight across
+// it (__syncthreads() makes hipcc drain them with s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void ps_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wave64 inclusive scan on the VALU (DPP row shifts + row broadcasts)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned ps_dpp_add_u32(unsigned v) {
+  return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned ps_wave_scan_incl(unsigned v) {
+  v = ps_dpp_add_u32<0x111, 0xf>(v);   // row_shr:1
+  v = ps_dpp_add_u32<0x112, 0xf>(v);   // row_shr:2
+  v = ps_dpp_add_u32<0x114, 0xf>(v);   // row_shr:4
+  v = ps_dpp_add_u32<0x118, 0xf>(v);   // row_shr:8   -> inclusive scan inside every row of 16
+  v = ps_dpp_add_u32<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = ps_dpp_add_u32<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// wave64 maximum, returned wave-uniform (SGPR)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned ps_dpp_max_u32(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+  return v > o ? v : o;
+}
+__device__ __forceinline__ unsigned ps_wave_max_u32(unsigned v) {
+  v = ps_dpp_max_u32<0x111, 0xf>(v);
+  v = ps_dpp_max_u32<0x112, 0xf>(v);
+  v = ps_dpp_max_u32<0x114, 0xf>(v);
+  v = ps_dpp_max_u32<0x118, 0xf>(v);
+  v = ps_dpp_max_u32<0x142, 0xa>(v);
+  v = ps_dpp_max_u32<0x143, 0xc>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// one point into a cell's moments: powers s^1..s^K once (shortest chains), S_p = sum s^p (p = 1..2K), T_p = sum y s^p (p = 0..K)
+template <int K>
+__device__ __forceinline__ void ps_acc(double s, double y, double (&S)[2 * K], double (&Tm)[K + 1]) {
+  double pw[K + 1];
+  pw[0] = 1.0;
+  pw[1] = s;
+#pragma unroll
+  for (int p = 2; p <= K; ++p) pw[p] = pw[p / 2] * pw[p - p / 2];
+#pragma unroll
+  for (int p = 1; p <= K; ++p) S[p - 1] += pw[p];
+#pragma unroll
+  for (int p = K + 1; p <= 2 * K; ++p) S[p - 1] = fma(pw[K], pw[p - K], S[p - 1]);
+  Tm[0] += y;
+#pragma unroll
+  for (int p = 1; p <= K; ++p) Tm[p] = fma(y, pw[p], Tm[p]);
+}
+
+// Owner lane: the run of l points at buf[o..] of ONE cell into its moments.  Wave-uniform trip count (the longest run of the wave's 64
+// cells, in an SGPR: a loop on a wave vote makes hipcc copy all 3k+1 accumulators every iteration); a lane that has run out reads the
+// (0, 0) point at buf[ZS], which adds nothing.  Two points per iteration in two register sets, each load issued one point ahead of its
+// use.  (Heavy cells arrive here with l = 0: ps_heavy_cells has summed them.)
+template <int K, int ZS>
+__device__ __forceinline__ void ps_own_cell(const double2* buf, unsigned l, unsigned o, double (&S)[2 * K], double (&Tm)[K + 1]) {
+  const unsigned nmax = (ps_wave_max_u32(l) + 1u) & ~1u;
+  double2 p = buf[l > 0 ? o : (unsigned)ZS];
+  for (unsigned j = 0; j < nmax; j += 2) {
+    const double2 q = buf[(j + 1 < l) ? o + j + 1 : (unsigned)ZS];
+    __builtin_amdgcn_sched_barrier(0);
+    ps_acc<K>(p.x, p.y, S, Tm);
+    __builtin_amdgcn_sched_barrier(0);
+    p = buf[(j + 2 < l) ? o + j + 2 : (unsigned)ZS];
+    __builtin_amdgcn_sched_barrier(0);
+    ps_acc<K>(q.x, q.y, S, Tm);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Heavy cells: more than PS_HEAVY points of one tile in one cell (sorted / time-series / clustered input - an owner lane would walk
+// them alone while its wavefront, or the whole workgroup, waits).  The scan phase lists them (cell, count, offset); here FOUR waves per
+// cell (wave numbers equal mod 4 share a SIMD under the cyclic placement; the group rotates with the cell) take slices of 64 consecutive
+// points of the listed run, sum them lane-parallel - in TWO passes, S then T, so that at most 2k temporaries are live next to the
+// owner accumulators -, reduce on the VALU (DPP: ~700 cycles per wave and cell, which is why not all 16 waves take part) and add
+// their 3k+1 partial moments to the cell's slot of a small LDS table with ds_add_f64; the owner lane then takes the slot.  Rounds of
+// PS_HROUND cells.
+template <int K>
+__device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn, unsigned ho, int first, int lane, double* slot) {
+  constexpr int NS = 2 * K;
+  const unsigned nsl = (hn + 63u) >> 6;
+  {
+    double S2[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) S2[q] = 0.0;
+    for (unsigned sl = (unsigned)first; sl < nsl; sl += 4) {
+      const unsigned j = sl * 64 + lane;
+      if (j < hn) {
+        const double sv = buf[ho + j].x;
+        double pw[K + 1];
+        pw[0] = 1.0; pw[1] = sv;
+#pragma unroll
+        for (int q = 2; q <= K; ++q) pw[q] = pw[q / 2] * pw[q - q / 2];
+#pragma unroll
+        for (int q = 1; q <= K; ++q) S2[q - 1] += pw[q];
+#pragma unroll
+        for (int q = K + 1; q <= NS; ++q) S2[q - 1] = fma(pw[K], pw[q - K], S2[q - 1]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { const double t = wave_sum_dpp(S2[q]); if (lane == 0) lds_add(slot + q, t); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double T2[K + 1];
+#pragma unroll
+    for (int q = 0; q <= K; ++q) T2[q] = 0.0;
+    for (unsigned sl = (unsigned)first; sl < nsl; sl += 4) {
+      const unsigned j = sl * 64 + lane;
+      if (j < hn) {
+        const double2 pt = buf[ho + j];
+        double pw = 1.0;
+        T2[0] += pt.y;
+#pragma unroll
+        for (int q = 1; q <= K; ++q) { pw *= pt.x; T2[q] = fma(pt.y, pw, T2[q]); }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q <= K; ++q) { const double t = wave_sum_dpp(T2[q]); if (lane == 0) lds_add(slot + NS + q, t); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ABL: 0 product; 1 loads + cell search only; 2 + rank atomics; 3 + scan; 4 + scatter; 5 + owners (no epilogue conversion);
+//      9 product + per-phase cycle stamps of thread 0
+template <int K, int TP, int ABL = 0, int PF = 0>
+__global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
+  extern __shared__ double lds[];
+  static_assert(TP % 2 == 0 && TP * PS_THREADS <= 8192, "tile: rank field is 13 bits");
+  constexpr int T = TP * PS_THREADS;
+  constexpr int NS = 2 * K;
+  double2* buf = reinterpret_cast<double2*>(lds);                 // T sorted (s, y) + slot T = (0, 0)
+  unsigned* cnt = reinterpret_cast<unsigned*>(buf + T + 1);       // [2][PS_NCELL] per-tile histogram, double-buffered
+  unsigned* off = cnt + 2 * PS_NCELL;                             // [PS_NCELL]
+  unsigned* wtot = off + PS_NCELL;                                // [16] wave totals of the scan (+ pad)
+  double* scratch = reinterpret_cast<double*>(wtot + 64);         // 64 doubles
+  constexpr int NSTAT = 3 * K + 1;
+  double* hacc = scratch + 64;                                    // [PS_HROUND][NSTAT] hand-over table of the heavy cells
+  unsigned* hlist = reinterpret_cast<unsigned*>(hacc + PS_HROUND * NSTAT);   // [PS_HLIST] x (cell, count, offset)
+  unsigned* nheavy_p = wtot + 32;                                 // heavy cells of the current tile
+  if (a.zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.zero_n; e += (long)gridDim.x * blockDim.x) a.zero_ptr[e] = 0.0;
+  const int tid0 = threadIdx.x;
+  int tid = tid0, lane = tid0 & 63, wv = tid0 >> 6;
+  const int n_mesh = a.n_mesh, ncells = n_mesh - 1, M = a.M;
+  const double* __restrict__ mesh = a.mesh_g;
+  const double inv_delta = a.inv_delta, step = a.step, smax_fast = a.smax_fast;
+  const double m0 = a.m0, m_last = a.m_last;
+  {
+    uint4* z = reinterpret_cast<uint4*>(cnt);
+    z[tid] = make_uint4(0u, 0u, 0u, 0u);                          // 2 x 2048 counters = 1024 x 16 B
+    if (tid == 0) buf[T] = make_double2(0.0, 0.0);
+  }
+  unsigned nbad = 0;
+  {   // the host chose this kernel from its copy of the mesh; a table that is NOT that linspace here is reported loudly
+    bool okm = true;
+    for (int i = tid; i < n_mesh - 1; i += PS_THREADS) okm = okm && (mesh[i] == mq_linspace_knot(i, step, m0));
+    if (tid == 0) okm = okm && mesh[n_mesh - 1] == m_last;
+    if (!okm) ++nbad;
+  }
+  auto knot = [&](int i) __attribute__((always_inline)) -> double { return (i == n_mesh - 1) ? m_last : mq_linspace_knot(i, step, m0); };
+  // Exact table rule (basis.py:58-59: idx = max(#{mesh < x} - 1, 0)) for the rare point within rounding of a knot or outside the mesh.
+  // On a linspace the arithmetic guess is off by at most one cell for a point of [a, b]: one step either way, then the rule is
+  // VERIFIED; what does not verify (or lies more than MQ_SMAX - 1/2 of a cell outside) is not accumulated and reported.
+  auto cell_slow = [&](double x, double& s_out, bool& ok) __attribute__((always_inline)) -> int {
+    int i = mq_guess(x, m0, inv_delta, n_mesh);                   // clamped to [0, n_mesh - 2]; NaN -> 0
+    const double k0 = knot(i);
+    const bool down = !(k0 < x) && i > 0;
+    const bool up = !down && i < n_mesh - 2 && knot(i + 1) < x;
+    i += up ? 1 : (down ? -1 : 0);
+    const double lo = knot(i), hi = knot(i + 1);
+    const double s = (x - lo) * inv_delta - 0.5;
+    ok = (i == 0 || lo < x) && (i == n_mesh - 2 || !(hi < x)) && fabs(s) <= MQ_SMAX;
+    s_out = s;
+    return i;
+  };
+
+  const long beg = (long)blockIdx.x * a.ppb;
+  long end = beg + a.ppb;
+  if (end > a.N) end = a.N;
+  if (end < beg) end = beg;
+  const long ubeg = beg >> 1;
+  const int npair = (int)((end >> 1) - ubeg);                     // full pairs of this workgroup (beg is even)
+  const bool tail = (end & 1) != 0;                               // one odd last point (only the workgroup that reaches N)
+  const int nunit = npair + (tail ? 1 : 0);
+  const int n_tiles = (nunit + T / 2 - 1) / (T / 2);
+  typedef double ps_nt2 __attribute__((ext_vector_type(2)));
+  // (a workgroup without a full pair - only possible at the very end of the data - aims its unconditional loads at pair 0 of the
+  // arrays: the host sends N < 2 to another algorithm)
+  const ps_nt2* x2 = reinterpret_cast<const ps_nt2*>(a.x) + (npair > 0 ? ubeg : 0);
+  const ps_nt2* y2 = reinterpret_cast<const ps_nt2*>(a.y) + (npair > 0 ? ubeg : 0);
+  const int ulast = npair > 0 ? npair - 1 : 0;
+
+  double xs[TP], ys[TP];
+  // unconditional, clamped loads and NO branch around them: a branch makes the loaded values phi nodes, which hipcc copies right
+  // behind the loads (s_waitcnt vmcnt(1)) - the prefetch then overlaps nothing
+  auto load_tile = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q2 = 0; q2 < TP / 2; ++q2) {
+      int u = tile * (T / 2) + q2 * PS_THREADS + tid;
+      u = u < ulast ? u : ulast;
+      const ps_nt2 xv = __builtin_nontemporal_load(x2 + u);     // read exactly once: keep the stream out of the L2's LRU order
+      const ps_nt2 yv = __builtin_nontemporal_load(y2 + u);
+      xs[2 * q2] = xv.x; xs[2 * q2 + 1] = xv.y; ys[2 * q2] = yv.x; ys[2 * q2 + 1] = yv.y;
+    }
+  };
+
+  double SA[NS], TA[K + 1], SB[NS], TB[K + 1];
+#pragma unroll
+  for (int p = 0; p < NS; ++p) { SA[p] = 0.0; SB[p] = 0.0; }
+#pragma unroll
+  for (int p = 0; p <= K; ++p) { TA[p] = 0.0; TB[p] = 0.0; }
+  unsigned n0A = 0, n0B = 0;
+  double yy = 0.0;
+
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  auto stamp = [&](int i) __attribute__((always_inline)) {
+    if constexpr (ABL == 9) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (i >= 0) ph[i] += t - tprev;
+      tprev = t;
+    }
+  };
+
+  load_tile(0);
+  __syncthreads();
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    unsigned* cntb = cnt + (tile & 1) * PS_NCELL;
+    stamp(-1);
+    // the thread index is re-read per tile behind an opaque barrier: LDS addresses derived from it are then recomputed where they are
+    // used (one or two instructions) instead of being hoisted out of the tile loop and spilled - a reload from scratch counts in
+    // vmcnt and would wait for the prefetched tile
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63;
+    wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- P1: cell, centred coordinate, rank inside the cell.  One pair at a time (sched_barrier): the scheduler otherwise interleaves
+    // all TP points and needs ~120 registers for this block alone, next to the 2 (3k+1) owner accumulators.
+    double sv[TP], yv[TP];
+    int cr[TP];                                                   // cell << 13 | rank; -1 = no point
+    {
+      unsigned valm = 0;                                          // bit q: point q exists and lies inside the mesh
+#pragma unroll
+      for (int q2 = 0; q2 < TP / 2; ++q2) {
+        const int u = tile * (T / 2) + q2 * PS_THREADS + tid;
+        double xv[2] = {xs[2 * q2], xs[2 * q2 + 1]};
+        bool val[2] = {u < npair, u < npair};
+        yv[2 * q2] = ys[2 * q2]; yv[2 * q2 + 1] = ys[2 * q2 + 1];
+        if (tail && u == npair) {                                 // the odd last point: a scalar reload by ONE lane of the kernel
+          xv[0] = a.x[end - 1]; yv[2 * q2] = a.y[end - 1]; val[0] = true;
+        }
+        bool slow = false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double g = floor((xv[e] - m0) * inv_delta);
+          const int c = __double2int_rz(g);                       // (v_cvt_i32_f64: saturating; NaN -> 0)
+          double u0;
+          {
+#pragma clang fp contract(off)
+            const double t = g * step;                            // numpy.linspace's knot: i * step rounded, THEN + start rounded
+            u0 = t + m0;
+          }
+          const double s = (xv[e] - u0) * inv_delta - 0.5;
+          const bool fast = (unsigned)c < (unsigned)ncells && fabs(s) <= smax_fast;
+          slow = slow || (val[e] && !fast);
+          cr[2 * q2 + e] = c;
+          sv[2 * q2 + e] = s;
+        }
+        if (__any(slow)) {                                        // rare: the exact table rule, per lane
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            bool ok;
+            double sq;
+            const int c = cell_slow(xv[e], sq, ok);
+            cr[2 * q2 + e] = c;
+            sv[2 * q2 + e] = sq;
+            if (val[e] && !ok) { ++nbad; val[e] = false; }          // outside the mesh (or NaN): reported, never accumulated
+          }
+        }
+        valm |= (val[0] ? 1u : 0u) << (2 * q2) | (val[1] ? 2u : 0u) << (2 * q2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (ABL == 9) { __builtin_amdgcn_sched_barrier(0); ph[5] += __builtin_amdgcn_s_memtime() - tprev; __builtin_amdgcn_sched_barrier(0); }   // loads landed, cells known
+      if constexpr (ABL == 1) {
+#pragma unroll
+        for (int q = 0; q < TP; ++q) yy += sv[q] + (double)cr[q] + yv[q];
+      } else {
+        unsigned rk[TP];
+#pragma unroll
+        for (int q2 = 0; q2 < TP / 2; ++q2) {                     // all rank atomics of the tile in flight together
+          const bool va = (valm >> (2 * q2)) & 1u, vb = (valm >> (2 * q2 + 1)) & 1u;
+          const int c0 = __builtin_amdgcn_readfirstlane(cr[2 * q2]);
+          if (__all(va && vb && cr[2 * q2] == c0 && cr[2 * q2 + 1] == c0)) {
+            // sorted / time-series input: all 128 points of the wave's pair row in ONE cell - one atomic instead of 128 same-address ones
+            unsigned base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add(cntb + c0, 128u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            rk[2 * q2] = base + 2u * (unsigned)lane;
+            rk[2 * q2 + 1] = base + 2u * (unsigned)lane + 1u;
+          } else {
+            rk[2 * q2] = va ? __hip_atomic_fetch_add(cntb + cr[2 * q2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            rk[2 * q2 + 1] = vb ? __hip_atomic_fetch_add(cntb + cr[2 * q2 + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+          }
+          yy = va ? fma(yv[2 * q2], yv[2 * q2], yy) : yy;
+          yy = vb ? fma(yv[2 * q2 + 1], yv[2 * q2 + 1], yy) : yy;
+        }
+#pragma unroll
+        for (int q = 0; q < TP; ++q) cr[q] = ((valm >> q) & 1u) ? ((cr[q] << 13) | (int)rk[q]) : -1;
+      }
+    }
+    if constexpr (ABL == 1) { load_tile(tile + 1); continue; }
+    if constexpr (ABL == 9) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ph[6] += __builtin_amdgcn_s_memtime() - tprev; }   // ranks returned
+    if constexpr (PF == 0 && (ABL == 0 || ABL == 9 || ABL == 5)) load_tile(tile + 1);   // the next tile's loads fly under scan, scatter and owners
+    ps_lds_barrier();
+    stamp(0);
+    if constexpr (ABL == 2) {
+      load_tile(tile + 1);
+      cntb[tid] = 0; cntb[tid + PS_THREADS] = 0;
+#pragma unroll
+      for (int q = 0; q < TP; ++q) yy += (double)(cr[q] & 8191) + sv[q];
+      ps_lds_barrier();
+      continue;
+    }
+    // ---- P2: exclusive scan of the counts -> off   (thread t scans cells 2t, 2t+1)
+    {
+      const uint2 c2 = reinterpret_cast<const uint2*>(cntb)[tid];
+      const unsigned v = c2.x + c2.y;
+      const unsigned inc = ps_wave_scan_incl(v);
+      if (lane == 63) wtot[wv] = inc;
+      if (tid == 0) *nheavy_p = 0;
+      ps_lds_barrier();
+      unsigned w = wtot[lane & 15];
+      w = ps_dpp_add_u32<0x111, 0xf>(w);
+      w = ps_dpp_add_u32<0x112, 0xf>(w);
+      w = ps_dpp_add_u32<0x114, 0xf>(w);
+      w = ps_dpp_add_u32<0x118, 0xf>(w);                          // lane i < 16: wtot[0] + .. + wtot[i]
+      const unsigned basew = (wv == 0) ? 0u : (unsigned)__builtin_amdgcn_readlane((int)w, wv > 0 ? wv - 1 : 0);
+      const unsigned ex = basew + inc - v;
+      reinterpret_cast<uint2*>(off)[tid] = make_uint2(ex, ex + c2.x);
+      if (c2.x > PS_HEAVY || c2.y > PS_HEAVY) {                   // rare: list the heavy cells, flag them for their owners
+        if (c2.x > PS_HEAVY) {
+          const unsigned hs = __hip_atomic_fetch_add(nheavy_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          hlist[3 * hs] = 2 * tid; hlist[3 * hs + 1] = c2.x; hlist[3 * hs + 2] = ex;
+          cntb[2 * tid] = 0x80000000u | hs;
+        }
+        if (c2.y > PS_HEAVY) {
+          const unsigned hs = __hip_atomic_fetch_add(nheavy_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          hlist[3 * hs] = 2 * tid + 1; hlist[3 * hs + 1] = c2.y; hlist[3 * hs + 2] = ex + c2.x;
+          cntb[2 * tid + 1] = 0x80000000u | hs;
+        }
+      }
+    }
+    ps_lds_barrier();
+    stamp(1);
+    if constexpr (ABL == 3) {
+      load_tile(tile + 1);
+      cntb[tid] = 0; cntb[tid + PS_THREADS] = 0;
+#pragma unroll
+      for (int q = 0; q < TP; ++q) yy += (double)(cr[q] & 8191) + sv[q] + (double)off[(cr[q] >> 13) & (PS_NCELL - 1)];
+      ps_lds_barrier();
+      continue;
+    }
+    // ---- P3: (s, y) into cell order
+    {
+      unsigned pos[TP];
+#pragma unroll
+      for (int q = 0; q < TP; ++q) pos[q] = off[(cr[q] >> 13) & (PS_NCELL - 1)] + (unsigned)(cr[q] & 8191);
+#pragma unroll
+      for (int q = 0; q < TP; ++q)
+        if (cr[q] >= 0) buf[pos[q]] = make_double2(sv[q], yv[q]);
+    }
+    ps_lds_barrier();
+    stamp(2);
+    if constexpr (ABL == 4) {
+      load_tile(tile + 1);
+      cntb[tid] = 0; cntb[tid + PS_THREADS] = 0;
+      const double2 p = buf[tid];
+      yy += p.x + p.y;
+      ps_lds_barrier();
+      continue;
+    }
+    // ---- P4: owners accumulate their two cells' moments (one cell after the other: half the loop temporaries of a fused loop)
+    {
+      unsigned nA = cntb[tid], nB = cntb[tid + PS_THREADS];
+      const unsigned oA = off[tid], oB = off[tid + PS_THREADS];
+      const unsigned nheavy = *nheavy_p;
+      cntb[tid] = 0; cntb[tid + PS_THREADS] = 0;                  // (owner-exclusive; this buffer is next used two tiles on)
+      if (nheavy > 0) {                                           // (workgroup-uniform) sorted / clustered input
+        const bool hvA = (nA & 0x80000000u) != 0, hvB = (nB & 0x80000000u) != 0;
+        const unsigned slA = nA & 0x7fffffffu, slB = nB & 0x7fffffffu;
+        if (hvA) { n0A += hlist[3 * slA + 1]; nA = 0; }
+        if (hvB) { n0B += hlist[3 * slB + 1]; nB = 0; }
+        for (unsigned r0 = 0; r0 < nheavy; r0 += PS_HROUND) {
+          if (tid < PS_HROUND * NSTAT) hacc[tid] = 0.0;
+          ps_lds_barrier();
+          const unsigned rn = nheavy - r0 < (unsigned)PS_HROUND ? nheavy - r0 : (unsigned)PS_HROUND;
+          for (unsigned hh = 0; hh < rn; ++hh) {
+            const unsigned hn = hlist[3 * (r0 + hh) + 1], ho = hlist[3 * (r0 + hh) + 2];
+            // waves 4 g + i (i = 0..3) of group g = hh mod 4 take slices i, i + 4, ...
+            if ((wv >> 2) == (int)(hh & 3u) && (unsigned)(wv & 3) < ((hn + 63u) >> 6))
+              ps_heavy_slices<K>(buf, hn, ho, wv & 3, lane, hacc + hh * NSTAT);
+          }
+          ps_lds_barrier();
+          if (hvA && slA >= r0 && slA < r0 + PS_HROUND) {
+#pragma unroll
+            for (int p = 0; p < NS; ++p) SA[p] += hacc[(slA - r0) * NSTAT + p];
+#pragma unroll
+            for (int p = 0; p <= K; ++p) TA[p] += hacc[(slA - r0) * NSTAT + NS + p];
+          }
+          if (hvB && slB >= r0 && slB < r0 + PS_HROUND) {
+#pragma unroll
+            for (int p = 0; p < NS; ++p) SB[p] += hacc[(slB - r0) * NSTAT + p];
+#pragma unroll
+            for (int p = 0; p <= K; ++p) TB[p] += hacc[(slB - r0) * NSTAT + NS + p];
+          }
+          if (r0 + PS_HROUND < nheavy) ps_lds_barrier();
+        }
+      }
+      n0A += nA; n0B += nB;
+      // ---- the next tile's loads fly under the owner loops (issued behind the heavy-cell pass: its temporaries and the 4 TP prefetch
+      // registers do not fit the register file together)
+      if constexpr (PF == 1) load_tile(tile + 1);                 // (clamped: the last one re-reads the final pair)
+      ps_own_cell<K, T>(buf, nA, oA, SA, TA);
+      ps_own_cell<K, T>(buf, nB, oB, SB, TB);
+    }
+    stamp(3);
+  }
+  stamp(-1);
+
+  // ---- epilogue: moments -> band / rhs entries of this workgroup (the LDS image aliases the sort buffers)
+  double tot = block_sum(yy, scratch);                            // (its barriers also end the last owner phase)
+  const double badf = block_sum((double)nbad, scratch + 32);
+  __syncthreads();
+  double* out = a.partials + (size_t)blockIdx.x * ((size_t)(K + 2) * M + 1);
+  if constexpr (ABL == 5) {   // diagnostic: keep the moments alive, skip the conversion
+    double keep = (double)(n0A + n0B);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) keep += SA[p] + SB[p];
+#pragma unroll
+    for (int p = 0; p <= K; ++p) keep += TA[p] + TB[p];
+    out[tid] = keep;
+  } else if constexpr (ABL == 0 || ABL == 9) {
+    // Rows of cell c are c .. c+K (row = c + K - i for piece i):  band[d][j] = A[j+d, j] = sum over the cells c = j-K+i2 (i2 = piece of
+    // row j) of sum_p pair[i2-d][i2][p] S_p(c);  Phi y[j] = sum_i sum_p single[i][p] T_p(j-K+i).  Two halves of 1024 columns; the
+    // image of a half holds its 1024 cells plus the K cells below them, plane-major: img[p][K + local cell].
+    constexpr int IW = PS_THREADS + K;
+    double* img = lds;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {   // (unrolled: as a loop, hipcc hoists the ~160 table constants into SGPRs and spills 150 of them)
+      const int cbase = half * PS_THREADS;                        // first cell (= first column) of this half
+      // S planes (p = 0: the count)
+      {
+        const double s0v = (double)(half == 0 ? n0A : n0B);
+        img[K + tid] = s0v;
+#pragma unroll
+        for (int p = 1; p <= NS; ++p) img[p * IW + K + tid] = half == 0 ? SA[p - 1] : SB[p - 1];
+        if (tid >= PS_THREADS - K) {                              // the K cells below the half: zeros, or the top cells of half A
+          const int hs = tid - (PS_THREADS - K);
+          img[hs] = half == 0 ? 0.0 : (double)n0A;
+#pragma unroll
+          for (int p = 1; p <= NS; ++p) img[p * IW + hs] = half == 0 ? 0.0 : SA[p - 1];
+        }
+      }
+      __syncthreads();
+      const int j = cbase + tid;
+      if (j < M) {
+        double band[K + 1];
+#pragma unroll
+        for (int d = 0; d <= K; ++d) band[d] = 0.0;
+#pragma unroll
+        for (int i2 = 0; i2 <= K; ++i2) {
+          const int c = j - K + i2;
+          if (c < 0 || c >= ncells) continue;
+          double S[NS + 1];
+#pragma unroll
+          for (int p = 0; p <= NS; ++p) S[p] = img[p * IW + tid + i2];
+#pragma unroll
+          for (int d = 0; d <= i2; ++d) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p <= NS; ++p) v = fma(MomCoef<K>::tab.pair[i2 - d][i2][p], S[p], v);
+            band[d] += v;
+          }
+        }
+#pragma unroll
+        for (int d = 0; d <= K; ++d) __builtin_nontemporal_store((j + d < M) ? band[d] : 0.0, out + (size_t)d * M + j);
+      }
+      __syncthreads();
+      // T planes
+      {
+#pragma unroll
+        for (int p = 0; p <= K; ++p) img[p * IW + K + tid] = half == 0 ? TA[p] : TB[p];
+        if (tid >= PS_THREADS - K) {
+          const int hs = tid - (PS_THREADS - K);
+#pragma unroll
+          for (int p = 0; p <= K; ++p) img[p * IW + hs] = half == 0 ? 0.0 : TA[p];
+        }
+      }
+      __syncthreads();
+      if (j < M) {
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i <= K; ++i) {
+          const int c = j - K + i;
+          if (c < 0 || c >= ncells) continue;
+#pragma unroll
+          for (int p = 0; p <= K; ++p) r = fma(MomCoef<K>::tab.single[i][p], img[p * IW + tid + i], r);
+        }
+        __builtin_nontemporal_store(r, out + (size_t)(K + 1) * M + j);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) out[(size_t)(K + 2) * M] = (badf > 0.0) ? __builtin_nan("") : tot;   // a point outside the mesh: loud (NaN y^T y)
+  } else {
+    if (tid == 0) out[0] = tot + badf;
+  }
+  stamp(4);
+  if constexpr (ABL == 9) {
+    if (tid == (int)(a.stamps_wave * 64) && a.stamps)
+      for (int i = 0; i < 8; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = ph[i];
+  }
+}
+
+}  // namespace asvgp

@@ -70,10 +70,16 @@ int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double
                             const double* mesh, int64_t n_mesh, double delta, int order, int64_t M,
                             double* stats, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
 
-/* Phi-pass algorithm of the handle: 0 = auto (= 3), 1 = per-point LDS fp64 atomic scatter into the band, 3 = as 1 with the
- * Phi Phi^T products accumulated as 64-bit fixed-point integers (ds_add_u64 runs at twice the ds_add_f64 rate; per-diagonal
- * power-of-two scales, error per addend <= 2^-43 of the diagonal's largest product, order-independent sums).  Same statistics
- * to <= 1e-12 of the band's largest entry. */
+/* Phi-pass algorithm of the handle.  0 = auto: 6 where it applies, else 5, else 3.
+ *   1 = per-point LDS fp64 atomic scatter of the (order+1)(order+2)/2 products into the band;
+ *   3 = as 1 with the products accumulated as 64-bit fixed-point integers (ds_add_u64 runs at twice the ds_add_f64 rate; per-diagonal
+ *       power-of-two scales, error per addend <= 2^-43 of the diagonal's largest product, order-independent sums);
+ *   5 = per-cell centred power sums S_p = sum s^p (p <= 2 order) in fixed point + direct fixed-point scatter of Phi y: 3 order + 2 LDS
+ *       atomics per point; D = 1, 16-byte aligned x / y, image within the LDS (M <= 2048 at order 4);
+ *   6 = tile sort: points counting-sorted by cell inside the LDS, the 3 order + 1 moments of a cell accumulated in the REGISTERS of the
+ *       thread that owns the cell (no statistic atomics); D = 1, N >= 2, M <= 2048, 16-byte aligned x / y, mesh an exact
+ *       numpy.linspace.  Sums follow arrival order: reproducible to rounding, not bit for bit (5 and 3 are).
+ * Same statistics to <= 1e-12 of the band's largest entry. */
 int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
 /* workgroups of the Phi-pass kernel: 0 = default (256, one per CU); a smaller number leaves CUs free so that a
  * concurrently enqueued asvgp_elbo_prior_chain_1d (second stream) is resident at the same time. */

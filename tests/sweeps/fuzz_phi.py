@@ -15,7 +15,8 @@ for case in range(n_cases + n_big):
     N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 2047, 2048, 2049, 4097])) if rng.random() < 0.3 else int(rng.integers(1, 300000))
     if case >= n_cases:
         order, M, N = int(rng.choice([3, 4, 4, 5])), int(rng.choice([512, 1000, 2048, 2048, 4096])), 10_000_000
-    a, b = (0, 1) if rng.random() < 0.7 else (-3.5, 10.5)
+    u = rng.random()
+    a, b = (0, 1) if u < 0.5 else ((-3.5, 10.5) if u < 0.7 else ((-80, -25) if u < 0.85 else (1000, 1001)))   # exact linspace | float32 linspace | int endpoints | large offset
     dist = rng.choice(["uniform", "sorted", "clustered", "repeats", "two_cells"])
     lo, hi = a + 1e-9 * (b - a), b - 1e-9 * (b - a)
     if dist == "uniform": x = rng.uniform(lo, hi, N)
@@ -23,10 +24,14 @@ for case in range(n_cases + n_big):
     elif dist == "clustered": x = np.clip(a + (b - a) * (0.5 + 0.03 * rng.standard_normal(N)), lo, hi)
     elif dist == "repeats": x = rng.choice(rng.uniform(lo, hi, 7), N)
     else: x = rng.choice([lo, a + 0.3 * (b - a), hi], N)
+    if N > 20 and rng.random() < 0.3:      # a few points exactly on interior knots (the models refuse x = a, x = b like gpr.py:24-25)
+        kn = np.asarray(O.Basis(order, a, b, M).mesh, dtype=np.float64)
+        if len(kn) > 2:
+            x[rng.integers(0, N, 8)] = kn[rng.integers(1, len(kn) - 1, 8)]
     yscale = 10.0 ** rng.integers(-8, 9)
     y = yscale * rng.standard_normal((N, 1))
     if rng.random() < 0.3 and N > 10: y[rng.integers(0, N, 3)] *= 1e6
-    algo = int(rng.choice([0, 1, 3, 5]))      # auto | fp64 scatter | fixed-point band scatter | fixed-point moments
+    algo = int(rng.choice([0, 0, 1, 3, 5, 6]))      # auto | fp64 scatter | fixed-point band scatter | fixed-point moments | tile sort
     A.set_phi_algorithm(algo)
     try:
         bs = getattr(A, "B%dSpline" % order)(a, b, M)
@@ -42,7 +47,7 @@ for case in range(n_cases + n_big):
         tol = 1e-12 + 4e-16 * N      # (the oracle's own sequential fp64 sums lose ~N eps on heavily repeated x)
         ok = eb <= tol and er <= tol and ey <= tol and zero_ok
     except Exception as e:  # noqa
-        if algo == 5 and "ASVGP_ERR_UNSUPPORTED" in repr(e):
+        if algo in (5, 6) and "ASVGP_ERR_UNSUPPORTED" in repr(e):
             continue                  # forced moments beyond their LDS image / alignment (auto falls back to 3): not a parity case
         ok, eb, er, ey = False, -1, -1, -1
         print("EXC", repr(e)[:200])

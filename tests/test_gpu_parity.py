@@ -520,9 +520,10 @@ def test_block_cyclic_reduction_vs_sequential_sweeps_and_oracle(A, order, M, kd,
                                              (4, 1024, 100000, False), (4, 2048, 150001, True), (5, 200, 30000, False),
                                              (6, 90, 10000, True), (4, 4096, 60000, False), (3, 3000, 50000, True)])
 def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
-    """Algorithm 1 (per-point fp64 LDS atomic band scatter), 3 (the same in 64-bit fixed point) and 5 (fixed-point centred
-    moments per cell for Phi Phi^T + fixed-point scatter of Phi y - the default where the image fits the LDS) give the same statistics;
-    sorted (time-series) inputs exercise the wave-uniform run mode, repeated points the same-address paths."""
+    """Algorithm 1 (per-point fp64 LDS atomic band scatter), 3 (the same in 64-bit fixed point), 5 (fixed-point centred
+    moments per cell for Phi Phi^T + fixed-point scatter of Phi y) and 6 (tile sort + register moments - the default where it
+    applies) give the same statistics; sorted (time-series) inputs exercise the wave-uniform run mode / the heavy-cell path,
+    repeated points the same-address paths."""
     rng = np.random.default_rng(M + N)
     x = rng.uniform(1e-9, 1 - 1e-9, N)
     if sort:
@@ -534,12 +535,12 @@ def test_phi_algorithms_agree_with_oracle(A, order, M, N, sort):
     band, rhs, yy = O.sufficient_stats_direct(ob, x, y)
     got = {}
     try:
-        for algo in (1, 3, 5):
+        for algo in (1, 3, 5, 6):
             A.set_phi_algorithm(algo)
             try:
                 m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), bs)
             except RuntimeError:
-                assert algo == 5 and M > 2100       # the moment image exceeds the LDS: auto falls back to 3
+                assert algo in (5, 6) and M > 2048  # the moment image / the owner map exceed one workgroup: auto falls back to 3
                 continue
             got[algo] = m._stats.cpu().numpy().copy()
             gotb = m.KufKfu.cpu().numpy()
@@ -578,7 +579,7 @@ def test_phi_pass_on_float32_linspace_mesh_cells_that_are_not_exactly_delta_wide
     ob = O.Basis(order, a, b, M)
     band, rhs, yy = O.sufficient_stats_direct(ob, x, y)
     try:
-        for algo in (0, 3, 5):
+        for algo in (0, 3, 5):            # (6 needs an exact fp64 linspace: auto takes 5 on these meshes)
             A.set_phi_algorithm(algo)
             m = A.GPR_1d((x.reshape(-1, 1), y), A.Matern12(), _mk_basis(A, order, a, b, M))
             tol = 1e-12 + 4e-16 * N          # (the oracle's sequential sums lose ~N eps on heavily repeated x)
@@ -1086,7 +1087,7 @@ def test_phi_fixed_point_scale_fallback(A):
     assert torch.isnan(m.Kuf_y).any() and torch.isnan(m.tr_yTy)      # a NaN observation is not silently dropped
 
 
-@pytest.mark.parametrize("algo", [1, 3, 5])
+@pytest.mark.parametrize("algo", [1, 3, 5, 6])
 @pytest.mark.parametrize("bad", [1.5, -0.25, float("nan")])
 def test_point_outside_the_mesh_is_reported_not_wrapped(A, algo, bad):
     """C-ABI level (the model classes refuse such X first, gpr.py:25-26): an x outside (a, b), or NaN, must not wrap the
