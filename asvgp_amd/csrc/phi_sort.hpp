@@ -50,7 +50,14 @@ template <int K, int TP> constexpr size_t ps_lds_bytes() {
   return (size_t)(TP * PS_THREADS + 1) * 16 + (size_t)3 * PS_NCELL * 4 + 64 * 4 + 64 * 8 +
          (size_t)PS_HROUND * (3 * K + 1) * 8 + (size_t)PS_HLIST * 12;
 }
-template <int K> constexpr size_t ps_epilogue_bytes() { return (size_t)(2 * K + 1) * (PS_THREADS + K) * 8; }
+// LDS of the epilogue's largest round: the Q planes of one half (all (K+1)(K+2)/2 for K <= 4, else those of the sub-diagonals d >= 2 or
+// d < 2, whichever are more) or the 2 (K+1) rhs planes
+template <int K> constexpr size_t ps_epilogue_bytes() {
+  int all = (K + 1) * (K + 2) / 2, lo = (K + 1) + K, hi = all - lo;
+  int planes = K <= 4 ? all : (lo > hi ? lo : hi);
+  if (planes < 2 * (K + 1)) planes = 2 * (K + 1);
+  return (size_t)planes * (PS_THREADS + K) * 8;
+}
 
 // Workgroup barrier that orders LDS traffic only: global loads issued before it (the next tile's prefetch) stay in flight across
 // it (__syncthreads() makes hipcc drain them with s_waitcnt vmcnt(0)).
@@ -495,75 +502,105 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
     for (int p = 0; p <= K; ++p) keep += TA[p] + TB[p];
     out[tid] = keep;
   } else if constexpr (ABL == 0 || ABL == 9) {
-    // Rows of cell c are c .. c+K (row = c + K - i for piece i):  band[d][j] = A[j+d, j] = sum over the cells c = j-K+i2 (i2 = piece of
-    // row j) of sum_p pair[i2-d][i2][p] S_p(c);  Phi y[j] = sum_i sum_p single[i][p] T_p(j-K+i).  Two halves of 1024 columns; the
-    // image of a half holds its 1024 cells plus the K cells below them, plane-major: img[p][K + local cell].
+    // Rows of cell c are c .. c+K (row = c + K - i for piece i).  Every thread turns the moments of its OWN cell into the cell's
+    // (K+1)(K+2)/2 band contributions Q_ij = sum_p pair[i][j][p] S_p (i <= j: sub-diagonal d = j - i, column c + K - j) straight from
+    // its registers, and into the K+1 rhs contributions R_i = sum_p single[i][p] T_p; the mirror symmetry of the pieces,
+    // v_i(s) = v_{K-i}(-s), makes Q_{K-j,K-i} / R_{K-i} the same sums with the odd powers negated, so a mirror pair costs one set of
+    // multiplies.  The contributions go through plane-major LDS images (conflict-free both ways); column col then adds
+    //   band[d][col] = sum_{j=d..K} Q_{j-d,j}(col - K + j),     Phi y[col] = sum_i R_i(col - K + i).
+    // Two halves of 1024 columns (an image holds the half's cells plus the K cells below it); the Q planes of a half in one round
+    // for K <= 4, in two rounds (d < 2, d >= 2) above, so that a round's planes fit the LDS.
     constexpr int IW = PS_THREADS + K;
     double* img = lds;
+    auto q_planes = [&](const double (&S)[NS], unsigned n0, int slot, int d0, int d1) __attribute__((always_inline)) {
+      const double s0v = (double)n0;
+      int pid = 0;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {   // (unrolled: as a loop, hipcc hoists the ~160 table constants into SGPRs and spills 150 of them)
-      const int cbase = half * PS_THREADS;                        // first cell (= first column) of this half
-      // S planes (p = 0: the count)
-      {
-        const double s0v = (double)(half == 0 ? n0A : n0B);
-        img[K + tid] = s0v;
+      for (int d = d0; d < d1; ++d) {
 #pragma unroll
-        for (int p = 1; p <= NS; ++p) img[p * IW + K + tid] = half == 0 ? SA[p - 1] : SB[p - 1];
-        if (tid >= PS_THREADS - K) {                              // the K cells below the half: zeros, or the top cells of half A
-          const int hs = tid - (PS_THREADS - K);
-          img[hs] = half == 0 ? 0.0 : (double)n0A;
+        for (int i = 0; i + d <= K; ++i) {
+          const int j = i + d, mi = K - j, mj = K - i;             // (mi, mj): the mirror pair, same sub-diagonal
+          if (mi < i) continue;                                    // written together with its mirror
+          double e = MomCoef<K>::tab.pair[i][j][0] * s0v, o = 0.0;
 #pragma unroll
-          for (int p = 1; p <= NS; ++p) img[p * IW + hs] = half == 0 ? 0.0 : SA[p - 1];
+          for (int p = 2; p <= NS; p += 2) e = fma(MomCoef<K>::tab.pair[i][j][p], S[p - 1], e);
+          if (mi != i) {
+#pragma unroll
+            for (int p = 1; p <= NS; p += 2) o = fma(MomCoef<K>::tab.pair[i][j][p], S[p - 1], o);
+            img[(pid + mi) * IW + slot] = e - o;
+          }
+          img[(pid + i) * IW + slot] = e + o;
         }
+        pid += K + 1 - d;
       }
-      __syncthreads();
-      const int j = cbase + tid;
-      if (j < M) {
-        double band[K + 1];
+    };
+    auto r_planes = [&](const double (&Tm)[K + 1], int slot, int plane0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int d = 0; d <= K; ++d) band[d] = 0.0;
+      for (int i = 0; 2 * i <= K; ++i) {
+        double e = 0.0, o = 0.0;
 #pragma unroll
-        for (int i2 = 0; i2 <= K; ++i2) {
-          const int c = j - K + i2;
-          if (c < 0 || c >= ncells) continue;
-          double S[NS + 1];
+        for (int p = 0; p <= K; p += 2) e = fma(MomCoef<K>::tab.single[i][p], Tm[p], e);
+        if (2 * i != K) {
 #pragma unroll
-          for (int p = 0; p <= NS; ++p) S[p] = img[p * IW + tid + i2];
+          for (int p = 1; p <= K; p += 2) o = fma(MomCoef<K>::tab.single[i][p], Tm[p], o);
+          img[(plane0 + K - i) * IW + slot] = e - o;
+        }
+        img[(plane0 + i) * IW + slot] = e + o;
+      }
+    };
+    constexpr int DSPLIT = (K <= 4) ? K + 1 : 2;
 #pragma unroll
-          for (int d = 0; d <= i2; ++d) {
-            double v = 0.0;
+    for (int half = 0; half < 2; ++half) {
+      const int j = half * PS_THREADS + tid;                       // this thread's column (= its cell) in the half
 #pragma unroll
-            for (int p = 0; p <= NS; ++p) v = fma(MomCoef<K>::tab.pair[i2 - d][i2][p], S[p], v);
-            band[d] += v;
+      for (int rnd = 0; rnd < (DSPLIT <= K ? 2 : 1); ++rnd) {
+        const int d0 = rnd == 0 ? 0 : DSPLIT, d1 = rnd == 0 ? DSPLIT : K + 1;
+        if (half == 0) q_planes(SA, n0A, K + tid, d0, d1); else q_planes(SB, n0B, K + tid, d0, d1);
+        if (tid >= PS_THREADS - K) {                               // the K cells below the half: none (zeros), or the top cells of half A
+          const int hs = tid - (PS_THREADS - K);
+          if (half == 0) {
+            int np = 0;
+#pragma unroll
+            for (int d = d0; d < d1; ++d) np += K + 1 - d;
+            for (int pl = 0; pl < np; ++pl) img[pl * IW + hs] = 0.0;
+          } else {
+            q_planes(SA, n0A, hs, d0, d1);
           }
         }
+        __syncthreads();
+        if (j < M) {
+          int pid = 0;
 #pragma unroll
-        for (int d = 0; d <= K; ++d) __builtin_nontemporal_store((j + d < M) ? band[d] : 0.0, out + (size_t)d * M + j);
-      }
-      __syncthreads();
-      // T planes
-      {
+          for (int d = d0; d < d1; ++d) {
+            double v = 0.0;
 #pragma unroll
-        for (int p = 0; p <= K; ++p) img[p * IW + K + tid] = half == 0 ? TA[p] : TB[p];
-        if (tid >= PS_THREADS - K) {
-          const int hs = tid - (PS_THREADS - K);
-#pragma unroll
-          for (int p = 0; p <= K; ++p) img[p * IW + hs] = half == 0 ? 0.0 : TA[p];
+            for (int jj = d; jj <= K; ++jj) v += img[(pid + jj - d) * IW + tid + jj];
+            __builtin_nontemporal_store((j + d < M) ? v : 0.0, out + (size_t)d * M + j);   // written once, read once by the reduce
+            pid += K + 1 - d;
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
+    }
+    // rhs: both halves in one round (2 (K+1) planes)
+    r_planes(TA, K + tid, 0);
+    r_planes(TB, K + tid, K + 1);
+    if (tid >= PS_THREADS - K) {
+      const int hs = tid - (PS_THREADS - K);
+#pragma unroll
+      for (int i = 0; i <= K; ++i) img[i * IW + hs] = 0.0;
+      r_planes(TA, hs, K + 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int j = half * PS_THREADS + tid;
       if (j < M) {
         double r = 0.0;
 #pragma unroll
-        for (int i = 0; i <= K; ++i) {
-          const int c = j - K + i;
-          if (c < 0 || c >= ncells) continue;
-#pragma unroll
-          for (int p = 0; p <= K; ++p) r = fma(MomCoef<K>::tab.single[i][p], img[p * IW + tid + i], r);
-        }
+        for (int i = 0; i <= K; ++i) r += img[(half * (K + 1) + i) * IW + tid + i];
         __builtin_nontemporal_store(r, out + (size_t)(K + 1) * M + j);
       }
-      __syncthreads();
     }
     if (tid == 0) out[(size_t)(K + 2) * M] = (badf > 0.0) ? __builtin_nan("") : tot;   // a point outside the mesh: loud (NaN y^T y)
   } else {
