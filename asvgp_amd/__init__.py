@@ -11,12 +11,12 @@ from .kernels import Gaussian, Matern12, Matern32, Matern52  # noqa: F401
 
 def set_band_algorithm(algo):
     """0 = auto, 1 = sequential single-wave sweeps, 2 = block cyclic reduction on the GPU, 3 = block cyclic reduction with the
-    planned (host, long double) prior forward pass (asvgp_set_band_algorithm) - applied to every live model handle and to
+    planned (host, long double) prior forward pass, 4 = the planned chains on the matrix cores (asvgp_set_band_algorithm) - applied to every live model handle and to
     models created later."""
     from ._lib import AsvgpError, get_lib, set_default_algorithms
     get_lib()
-    if int(algo) not in (0, 1, 2, 3):
-        raise AsvgpError("set_band_algorithm: 0..3")
+    if int(algo) not in (0, 1, 2, 3, 4):
+        raise AsvgpError("set_band_algorithm: 0..4")
     set_default_algorithms(band=int(algo))
 
 

@@ -20,6 +20,8 @@ SIGNATURES = {
     "asvgp_destroy": (_I, [_P]),
     "asvgp_phi_accumulate_1d": (_I, [_P, _P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
     "asvgp_set_phi_algorithm": (_I, [_P, _I]),
+    "asvgp_phi_last_algorithm": (_I, [_P]),
+    "asvgp_stream_probe": (_I, [_P, _P, _L, _P, _P]),
     "asvgp_set_phi_workgroups": (_I, [_P, _I]),
     "asvgp_set_phi_deferred_reduce": (_I, [_P, _I]),
     "asvgp_phi_reduce_1d": (_I, [_P, _P]),
@@ -129,6 +131,9 @@ class Handle:
 
     def set_phi_algorithm(self, algo):
         check(self._lib.asvgp_set_phi_algorithm(self.ptr, int(algo)), "set_phi_algorithm")
+
+    def phi_last_algorithm(self):
+        return int(self._lib.asvgp_phi_last_algorithm(self.ptr))
 
     def set_phi_workgroups(self, n):
         check(self._lib.asvgp_set_phi_workgroups(self.ptr, int(n)), "set_phi_workgroups")

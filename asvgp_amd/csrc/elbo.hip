@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "bcr_pre.hpp"
+#include "bcr_mfma.hpp"
 #include "handle.hpp"
 
 namespace asvgp {
@@ -20,8 +21,9 @@ namespace asvgp {
 // and once without: the C entry points.  asvgp_amd/build.py runs the units in parallel.)
 // Band algorithm (Handle::band_algo): 0 auto, 1 sequential single-wave sweeps (the reference's elimination order),
 // 2 block cyclic reduction, both chains on the GPU, 3 block cyclic reduction with the PLANNED prior chain: forward pass of
-// the Kuu chain on the host in long double over the distinct nodes (prior_plan.cpp), backward pass on the GPU (bcr_pre.hpp).
-// Auto = 3 when the handle holds a plan (asvgp_prior_plan_1d) for this (M, k, kind), else 2, else 1 (D > 1 or LDS).
+// the Kuu chain on the host in long double over the distinct nodes (prior_plan.cpp), backward pass on the GPU (bcr_pre.hpp),
+// 4 the planned chains on the matrix cores (bcr_mfma.hpp: k = 4, D = 1, M <= 2048).
+// Auto = 4 where it applies, else 3 when the handle holds a plan (asvgp_prior_plan_1d) for this (M, k, kind), else 2, else 1 (D > 1 or LDS).
 // With asvgp_elbo_chain_sync the prior chain (stream A) and the data chain (stream B) of algorithm 2 are ordered by the
 // handle's own events: evK = Kuu assembled (the P chain may start), evP = prior chain complete (the finalize may start).
 
@@ -223,7 +225,11 @@ __device__ __forceinline__ void elbo_finalize_body(
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  for (long j = (long)bid * blockDim.x + threadIdx.x; j < M; j += (long)nblk * blockDim.x) {
+  // (contiguous column chunks, one per workgroup whatever its size: the ~740 KB of bands come from memory / the other XCDs' write-backs at
+  //  ~25 GB/s per CU, so the traffic is spread over all nblk CUs - with 1024-thread workgroups a grid-stride loop left it to two of them)
+  const long chunk = (M + nblk - 1) / nblk;
+  const long j_end = ((long)(bid + 1) * chunk < M) ? (long)(bid + 1) * chunk : M;
+  for (long j = (long)bid * chunk + threadIdx.x; j < j_end; j += blockDim.x) {
     if (!logdets) {
       double lk = LK[j], lp = LP[j];
       acc[LOGK] += log(lk * lk);  // gpr.py:57  log(square(L[0,:]))
@@ -270,17 +276,19 @@ __device__ __forceinline__ void elbo_finalize_body(
   int* is_last_p = reinterpret_cast<int*>(part_lds + 16 * NACC);
 #define is_last (*is_last_p)
   if (threadIdx.x == 0) {
+    // Every word the workgroups share here (partial sums, ticket) is touched by agent-scope atomics only, on both sides: they are performed at
+    // the memory side, so no cache write-back / invalidate is needed - two __threadfence() calls here cost ~7 us of the launch's tail.
+    // The adds are drained (vmcnt) before the ticket is taken, so the workgroup that draws the last ticket reads complete sums.
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
       if (tot[i] != 0.0) __hip_atomic_fetch_add(gacc + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == (unsigned)nblk - 1);
   }
   __syncthreads();
   if (!is_last) return;
   if (threadIdx.x == 0) {
-    __threadfence();
 #pragma unroll
     for (int i = 0; i < NACC; ++i) tot[i] = __hip_atomic_load(gacc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
 // The helpers need no LDS and are dispatched after workgroups 0 and 1.
 struct FusedFin {
   const double* stats; ElboScalars th; double alpha_scale; double* gacc; unsigned* ticket; unsigned* arrived; unsigned* assembled; double* out;
-  long D; int n_helpers; int finalize;
+  long D; int n_helpers; int finalize; int debug_no_assembly; int debug_stamps;
 };
 __device__ __forceinline__ void assemble_band_slice(const double* __restrict__ S, const double* __restrict__ coef, const double* __restrict__ dcoef, int n_terms,
                                                     long E, long e, double* __restrict__ Kuu, double* __restrict__ dK) {
@@ -364,16 +372,22 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
                                                                   unsigned long long* done_flag, unsigned long long seq, int D, int lds_doubles, FusedFin fin) {
   extern __shared__ double lds[];
   const long E = (long)(K + 1) * M;
+  __shared__ int gave_up;
+  if (threadIdx.x == 0) gave_up = 0;
+  __syncthreads();
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
       long spins = 0;                                 // bounded: helpers that never became resident must not hang the device
       while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1L << 25)) { atomicExch(info + 1, -1); break; }       // reported like a failed factorisation (negative: gave up waiting)
+        if (++spins > (1L << 25)) { gave_up = 1; break; }
       }
-      __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (nobody else reads it)
+      if (!gave_up) __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (nobody else reads it)
     }
     __syncthreads();
+    // gave up waiting: reported like a failed factorisation (negative), and STICKY - this workgroup neither solves (bcr_solve's epilogue
+    // would overwrite the flag) nor signals its arrival; the host re-arms the workspace before the next launch (gpr.py)
+    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     bcr_solve<double, K, 1, BandSumP, BIG>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, BandOut<double>{SP, nullptr}, x, logdets + 2, info + 1, nullptr, D);
     more_columns<K, BIG>(b, x, D, M, wsP, lds, lds_doubles);
@@ -401,15 +415,193 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
     long spins = 0;                                   // bounded like the wait above; the bound is minutes of chain time
     while (__hip_atomic_load(fin.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1L << 25)) { atomicExch(info + 1, -1); break; }
+      if (++spins > (1L << 25)) { gave_up = 1; break; }
     }
   }
   __syncthreads();
+  if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }   // (no finalize from incomplete bands; the chains wrote info before)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // (Kuu / dK slices of the OTHER helpers: each helper's release precedes its chain-arrival wait only in program order of that helper;
   //  the chains arrive tens of microseconds after every helper has published, and workgroup 0 has acquired all of them before it arrives)
   elbo_finalize_body<K>((int)blockIdx.x - 2, fin.n_helpers, lds, fin.stats, Kuu, dK, nullptr, nullptr, SK, dSK, SP, nullptr, x, logdets, (long)M, fin.D,
                         fin.th, fin.alpha_scale, fin.gacc, fin.ticket, fin.arrived, fin.out);
+}
+
+// The same fused launch with both chains on the matrix cores (bcr_mfma.hpp; k = 4, D = 1): 1024-thread workgroups, workgroup 0 the P chain,
+// workgroup 1 the planned Kuu backward pass, the helpers assemble Kuu / dKuu and leave.  The finalize is done by the chains themselves:
+// each sums the traces / quadratic forms that involve ITS bands (which its CU has just written: no write-back, no wait for six other
+// CUs to fetch 740 KB from memory - that tail cost 10-17 us), adds them to the shared slots with agent-scope atomics and draws a ticket;
+// whoever draws the last one (normally the P chain) evaluates the bound and re-arms the slots.
+// A wait that gives up (helpers that never became resident) is sticky: the waiting workgroup sets info[1] = -1 and does NOT go on to solve
+// or to draw a ticket - nothing later overwrites the flag - and the host re-arms the workspace and re-issues the step through the
+// multi-launch sweeps (gpr.py).
+template <int K>
+__global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(const double* S_static, KuuCoefs2 cf, double* Kuu, double* dK, const double* A, const double* b, int M,
+                                                                      double* wsP, double* SP, double* x, double* logdets, int* info,
+                                                                      double s, const double* tab, int n_rec, const int* node_rec,
+                                                                      double* wsK, double* SK, double* dSK,
+                                                                      unsigned long long* done_flag, unsigned long long seq, long spin_limit, FusedFin fin) {
+  extern __shared__ double lds[];
+  static_assert(K == BM_B, "matrix-core chains: bandwidth 4");
+  const long E = (long)(K + 1) * M;
+  // diagnostic (ASVGP_CHAIN_STAMPS): 100 MHz wall-clock stamps per role into logdets[8 + 4 * min(block, 2) ..]: start, chain done, end
+  const unsigned long long t_start = fin.debug_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  auto rstamp = [&](int slot) {
+    if (fin.debug_stamps && threadIdx.x == 0 && blockIdx.x <= 2)
+      logdets[8 + 4 * (int)blockIdx.x + slot] = (slot == 0) ? (double)(t_start & 0xffffffffull) : (double)((__builtin_amdgcn_s_memrealtime() - t_start) & 0xffffffffull);
+  };
+  rstamp(0);
+  if (blockIdx.x >= 2) {                                       // helpers: Kuu, dKuu/dl (theta-only), then gone
+    for (long e = (long)(blockIdx.x - 2) * blockDim.x + threadIdx.x; e < E; e += (long)fin.n_helpers * blockDim.x)
+      assemble_band_slice(S_static, cf.c, cf.dc, cf.n, E, e, Kuu, dK);
+    __syncthreads();
+    if (threadIdx.x == 0 && fin.debug_no_assembly == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(fin.assembled, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    rstamp(2);
+    return;
+  }
+  __shared__ int gave_up;
+  if (threadIdx.x == 0) gave_up = 0;
+  __syncthreads();
+  auto wait_assembled = [&]() {                                // (both chains read the helpers' bands; the counter is re-armed by the last ticket)
+    if (threadIdx.x == 0) {
+      long spins = 0;
+      while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > spin_limit) { gave_up = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (!gave_up) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  };
+  const double* stats = fin.stats;
+  enum { LOGK, LOGP, TRKA, DTRKA, SKDK, SPDK, SKK, SPK, SPA, CC, AKA, ADKA, AAA, BA, NACC };
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  if (blockIdx.x == 0) {
+    wait_assembled();
+    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
+    rstamp(1);
+    bcr_mfma_solve<BandSumP>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, SP, x, logdets + 2, info + 1);
+    __syncthreads();                                           // (the band of P^-1 and x are re-read below by other lanes of this workgroup)
+    if (fin.finalize) {
+      for (long j = threadIdx.x; j < M; j += blockDim.x) {
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          const long o = (long)r * M + j;
+          const double w2 = (r == 0) ? 1.0 : 2.0;
+          const double sp = SP[o];
+          acc[SPDK] = fma(w2 * sp, dK[o], acc[SPDK]);
+          acc[SPK] = fma(w2 * sp, Kuu[o], acc[SPK]);
+          acc[SPA] = fma(w2 * sp, stats[o], acc[SPA]);
+        }
+        acc[AKA] += quad_col<K>(Kuu, M, j, x, 1, 0);
+        acc[ADKA] += quad_col<K>(dK, M, j, x, 1, 0);
+        acc[AAA] += quad_col<K>(stats, M, j, x, 1, 0);
+        acc[BA] = fma(stats[(long)(K + 1) * M + j], x[j], acc[BA]);
+      }
+    }
+  } else {
+    bcr_mfma_backward_pre(tab, n_rec, node_rec, M, wsK, lds, SK, dSK, logdets, info, done_flag, seq);
+    rstamp(1);
+    if (fin.finalize) {
+      wait_assembled();
+      if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
+      for (long j = threadIdx.x; j < M; j += blockDim.x) {
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          const long o = (long)r * M + j;
+          const double w2 = (r == 0) ? 1.0 : 2.0;
+          const double sk = SK[o], av = stats[o];
+          acc[TRKA] = fma(w2 * sk, av, acc[TRKA]);
+          acc[DTRKA] = fma(w2 * dSK[o], av, acc[DTRKA]);
+          acc[SKDK] = fma(w2 * sk, dK[o], acc[SKDK]);
+          acc[SKK] = fma(w2 * sk, Kuu[o], acc[SKK]);
+        }
+      }
+    }
+  }
+  if (!fin.finalize) { rstamp(2); return; }
+  // ---- workgroup sums -> this chain's own slots (agent-scope stores: two writers, disjoint slots, no atomic adds) -> ticket; the last
+  // ticket evaluates the bound (elbo_finalize_body's formulas).  Only the accumulators this chain owns are reduced.
+  double (*part)[8] = reinterpret_cast<double (*)[8]>(lds);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const bool isP = blockIdx.x == 0;
+  double mine[7];
+  mine[0] = isP ? acc[SPDK] : acc[TRKA];
+  mine[1] = isP ? acc[SPK] : acc[DTRKA];
+  mine[2] = isP ? acc[SPA] : acc[SKDK];
+  mine[3] = isP ? acc[AKA] : acc[SKK];
+  mine[4] = acc[ADKA]; mine[5] = acc[AAA]; mine[6] = acc[BA];
+  const int nmine = isP ? 7 : 4;                               // (workgroup-uniform)
+  __syncthreads();                                             // (the chains' LDS images are dead)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    if (i < nmine) {
+      const double v = wave_sum_dpp(mine[i]);
+      if (lane == 0) part[wv][i] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  double tot[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
+  double red[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) red[i] = (i < nmine) ? wave_sum_dpp(lane < nw ? part[lane][i] : 0.0) : 0.0;
+  if (threadIdx.x != 0) return;
+  double* slot = fin.gacc + (isP ? 0 : 8);                     // P: gacc[0..6], Kuu: gacc[8..11]
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+    if (i < nmine) __hip_atomic_store(slot + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drained before the ticket; agent-scope accesses on both sides: no fences)
+  const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != 1u) { rstamp(2); return; }
+  tot[SPDK] = __hip_atomic_load(fin.gacc + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[SPK] = __hip_atomic_load(fin.gacc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[SPA] = __hip_atomic_load(fin.gacc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[AKA] = __hip_atomic_load(fin.gacc + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[ADKA] = __hip_atomic_load(fin.gacc + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[AAA] = __hip_atomic_load(fin.gacc + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[BA] = __hip_atomic_load(fin.gacc + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[TRKA] = __hip_atomic_load(fin.gacc + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[DTRKA] = __hip_atomic_load(fin.gacc + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[SKDK] = __hip_atomic_load(fin.gacc + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[SKK] = __hip_atomic_load(fin.gacc + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels add into these slots)
+  __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    const double v = fin.th.v, sn = fin.th.s, N = fin.th.N;
+    const double yy = stats[(long)(K + 1) * M + M];
+    const double asc = fin.alpha_scale;                        // x = P^-1 b unscaled: alpha = x / s
+    tot[AKA] *= asc * asc; tot[ADKA] *= asc * asc; tot[AAA] *= asc * asc; tot[BA] *= asc;
+    // the log-determinants were written by the two chains' lane 0 before their atomics (same lanes: program order + the drain above)
+    tot[LOGK] = __hip_atomic_load(logdets + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[LOGP] = __hip_atomic_load(logdets + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[CC] = tot[BA] / sn;
+    const double two_pi = 6.283185307179586476925286766559;
+    double elbo = -0.5 * N * log(two_pi * sn);
+    elbo -= 0.5 * tot[LOGP];
+    elbo += 0.5 * tot[LOGK];
+    elbo -= 0.5 * yy / sn;
+    elbo += 0.5 * tot[CC];
+    elbo -= 0.5 * N * v / sn;
+    elbo += 0.5 * tot[TRKA] / sn;
+    const double d_l = 0.5 * (tot[SKDK] - tot[SPDK] - tot[ADKA] + tot[DTRKA] / sn);
+    const double d_v = 0.5 * (-tot[SKK] / v + tot[SPK] / v + tot[AKA] / v + tot[TRKA] / (v * sn)) - 0.5 * N / sn;
+    const double s2 = sn * sn;
+    const double d_s = -0.5 * N / sn + 0.5 * tot[SPA] / s2 + 0.5 * yy / s2 + 0.5 * tot[AAA] / s2 - tot[BA] / s2 + 0.5 * N * v / s2 - 0.5 * tot[TRKA] / s2;
+    double* out = fin.out;
+    out[0] = elbo; out[1] = d_v; out[2] = d_l; out[3] = d_s;
+    out[4] = tot[LOGK]; out[5] = tot[LOGP]; out[6] = tot[TRKA]; out[7] = tot[CC];
+  }
+  rstamp(2);
 }
 
 static __global__ void scale_sub_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
@@ -436,10 +628,10 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
   const int algo = h->band_algo;
   // the planned prior chain needs the LDS only for the P chain and the factor table
   const bool have_plan = h->plan && prior_plan_M(h->plan) == M && prior_plan_k(h->plan) == K && prior_plan_terms(h->plan) == cf.n;
-  if (algo == 3 && !have_plan) { set_error("band algorithm 3 needs asvgp_prior_plan_1d for this (M, k, kernel)"); return ASVGP_ERR_BAD_ARG; }
+  if ((algo == 3 || algo == 4) && !have_plan) { set_error("band algorithms 3 and 4 need asvgp_prior_plan_1d for this (M, k, kernel)"); return ASVGP_ERR_BAD_ARG; }
   size_t ldsK = sizeof(double) * (TANGENT ? bcr_lds_doubles<Dual, K, 0>(nb) : bcr_lds_doubles<double, K, 0>(nb));
   size_t ldsP = sizeof(double) * bcr_lds_doubles<double, K, 1>(nb);
-  bool planned = have_plan && (algo == 0 || algo == 3);
+  bool planned = have_plan && (algo == 0 || algo == 3 || algo == 4);
   size_t lds_bytes = planned ? ldsP : (ldsK > ldsP ? ldsK : ldsP);
   bool fits = lds_bytes <= 160 * 1024 - 256;
   bool big = false;   // BIG layout (bcr.hpp): twice the nodes, couplings in an L2-resident plane - M up to 4096 at k = 4
@@ -450,7 +642,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     size_t bb = planned ? bP : (bK > bP ? bK : bP);
     if (bb <= 160 * 1024 - 256) { big = true; fits = true; lds_bytes = bb; }
   }
-  use_bcr = (algo == 2 || algo == 3 || (algo == 0 && fits));   // (D > 1: column 0 rides through the levels, the others replay the factors)
+  use_bcr = (algo == 2 || algo == 3 || algo == 4 || (algo == 0 && fits));   // (D > 1: column 0 rides through the levels, the others replay the factors)
   planned = planned && use_bcr;
   if (part != 0 && (!use_bcr || planned)) {
     // split scheduling exists for the all-GPU BCR path only: the sweeps and the planned chain run as one unit in the data call
@@ -468,9 +660,6 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     const int n_rec = prior_plan_nrec(h->plan);
     size_t lds_pre = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
     if (lds_pre > lds_bytes) lds_bytes = lds_pre;
-    auto kern = big ? elbo_chains_kernel<K, HAS_BIG> : elbo_chains_kernel<K, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     FusedFin ff{};
     if (fin) { ff = *fin; ff.finalize = 1; fin->finalize = -1; }   // (-1: tells the caller that the finalize rode along)
     // 2 + 6 = 8 workgroups: one per XCD (workgroups are dealt to the XCDs round-robin).  Every workgroup of the launch reserves the
@@ -478,10 +667,35 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     // in-flight schedule found no free CU there for a helper - its P chain then waited for the whole previous launch to finish
     ff.n_helpers = (int)((M + 255) / 256 < 6 ? (M + 255) / 256 : 6);
     ff.assembled = reinterpret_cast<unsigned*>(w.fin + 20);
+    ff.debug_no_assembly = getenv("ASVGP_DEBUG_NO_ASSEMBLY") ? 1 : 0;
+    ff.debug_stamps = getenv("ASVGP_CHAIN_STAMPS") ? 1 : 0;   // test hook: the helpers never report -> the P chain gives up waiting
+    const long spin_limit = getenv("ASVGP_SPIN_LIMIT") ? atol(getenv("ASVGP_SPIN_LIMIT")) : (1L << 25);
+    bool use_mfma = false;
+    if constexpr (K == BM_B) {
+      // matrix-core chains: k = 4, one output column, the whole tree in one workgroup's LDS, no explicit request for the older kernel
+      use_mfma = (algo == 0 || algo == 4) && D == 1 && nb <= 512 && TANGENT && fin != nullptr &&
+                 sizeof(double) * bcr_mfma_lds_doubles(nb) <= 160 * 1024 && sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec) <= 160 * 1024;
+      if (use_mfma) {
+        size_t lb = sizeof(double) * bcr_mfma_lds_doubles(nb), lk = sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec);
+        if (lk > lb) lb = lk;
+        if (sizeof(double) * FIN_LDS_DOUBLES > lb) lb = sizeof(double) * FIN_LDS_DOUBLES;
+        auto kern = elbo_chains_mfma_kernel<K>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+        hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BM_THREADS), lb, st, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
+                           h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq, spin_limit, ff);
+      }
+    }
+    if (algo == 4 && !use_mfma) { set_error("band algorithm 4 (matrix-core chains) needs k = 4, D = 1, M <= 2048 and the ELBO + gradient entry point"); return ASVGP_ERR_UNSUPPORTED; }
+    if (!use_mfma) {
+    auto kern = big ? elbo_chains_kernel<K, HAS_BIG> : elbo_chains_kernel<K, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BCR_THREADS), lds_bytes, st, S, cf, w.Kuu, TANGENT ? w.dK : (double*)nullptr, A, b,
                        (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                        h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK,
                        h->done_dev + slot, seq, (int)D, (int)(lds_bytes / sizeof(double)), ff);
+    }
     if (scale_alpha) {
       long n = M * D;
       hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.alpha, 1.0 / s, n);

@@ -129,8 +129,8 @@ extern "C" int asvgp_set_phi_deferred_reduce(asvgp_handle_t handle, int on) {
 }
 
 extern "C" int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo) {
-  if (algo < 0 || algo > 3) {
-    set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 block cyclic reduction on the GPU, 3 block cyclic reduction with the planned (host, long double) prior forward pass");
+  if (algo < 0 || algo > 4) {
+    set_error("set_band_algorithm: 0 auto, 1 sequential sweeps, 2 block cyclic reduction on the GPU, 3 block cyclic reduction with the planned (host, long double) prior forward pass, 4 the planned chains on the matrix cores");
     return ASVGP_ERR_BAD_ARG;
   }
   as_handle(handle)->band_algo = algo;

@@ -651,15 +651,16 @@ static int launch_phi(Handle* h, const double* x, const double* y, long N, long 
   const int ncells = (int)n_mesh - 1;
   if (h->phi_algo == 0 || h->phi_algo == 6) {
     const int rc = launch_phi_sort<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
-    if (rc != 1) return rc;
+    if (rc != 1) { h->phi_last = 6; return rc; }
     if (h->phi_algo == 6) { set_error("phi algorithm 6 (tile sort) needs D == 1, N >= 2, M <= 2048, 16-byte aligned x / y and a mesh that is an exact linspace"); return ASVGP_ERR_UNSUPPORTED; }
   }
   if (h->phi_algo == 0 || h->phi_algo == 5) {
     const int rc = launch_phi_moments<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
-    if (rc != 1) return rc;
+    if (rc != 1) { h->phi_last = 5; return rc; }
     if (h->phi_algo == 5) { set_error("phi algorithm 5 (centred moments) needs D == 1, 16-byte aligned x / y and M small enough for the LDS split"); return ASVGP_ERR_UNSUPPORTED; }
   }
   const bool fx = (h->phi_algo != 1);
+  h->phi_last = fx ? 3 : 1;
   int maxc = phi_max_cols(K, n_mesh, fx);
   if (maxc < 2 * K + 2) {
     set_error("phi_accumulate_1d: mesh table (%ld knots) leaves no LDS for the band", n_mesh);
@@ -744,6 +745,49 @@ extern "C" int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, c
     case 5: return launch_phi<5>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
     default: return launch_phi<6>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, part, st);
   }
+}
+
+extern "C" int asvgp_phi_last_algorithm(asvgp_handle_t handle) { return as_handle(handle)->phi_last; }
+
+// Read-only stream of x and y with the Phi pass's launch shape (one 1024-thread workgroup per CU, 16-byte loads, two per array in
+// flight per lane): the measured ceiling the Phi kernel's roofline fraction is quoted beside.  sink: >= 8 bytes, never written
+// for finite data.
+__global__ __launch_bounds__(1024) void stream_probe_kernel(const double* __restrict__ x, const double* __restrict__ y, long N, long ppb,
+                                                            double* __restrict__ sink) {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const long beg = (long)blockIdx.x * ppb;
+  long end = beg + ppb;
+  if (end > N) end = N;
+  if (end <= beg) return;
+  const v2* x2 = reinterpret_cast<const v2*>(x) + (beg >> 1);
+  const v2* y2 = reinterpret_cast<const v2*>(y) + (beg >> 1);
+  const int npair = (int)((end - beg) >> 1);
+  double acc = 0.0;
+  for (int base = 0; base < npair; base += 2 * 1024) {
+    v2 xv[2], yv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      int u = base + d * 1024 + (int)threadIdx.x;
+      u = u < npair - 1 ? u : npair - 1;
+      xv[d] = __builtin_nontemporal_load(x2 + u);
+      yv[d] = __builtin_nontemporal_load(y2 + u);
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) acc += xv[d].x + xv[d].y + yv[d].x + yv[d].y;
+  }
+  if (acc == 1.2345e300) sink[0] = acc;
+}
+
+extern "C" int asvgp_stream_probe(const double* x, const double* y, int64_t N, double* sink, asvgp_stream_t stream) {
+  if (!x || !y || !sink || N < 2 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) {
+    set_error("stream_probe: bad argument (N >= 2, 16-byte aligned x / y)");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  const int G = 256;
+  long ppb = ((long)N + G - 1) / G;
+  ppb = (ppb + 1) & ~1L;
+  hipLaunchKernelGGL(stream_probe_kernel, dim3(G), dim3(1024), 0, as_stream(stream), x, y, (long)N, ppb, sink);
+  return check_launch("stream_probe");
 }
 
 extern "C" int asvgp_phi_reduce_1d(asvgp_handle_t handle, asvgp_stream_t stream) {

@@ -17,6 +17,16 @@
 // Per point: 1 LDS atomic + 1 16-B write + 1 16-B read instead of 14 atomics, ~60 VALU instructions instead of ~157.
 // The sums inside a cell follow the arrival order of the rank atomics: results are reproducible to rounding (a few ulp of the
 // per-cell sums), not bit for bit - algorithm 5 (fixed point, order-independent) stays selectable for that.
+// What bounds it (tools/micro/phi_sort_bench.hip: per-stage ablations and in-kernel phase stamps; N = 10M, M = 2048, k = 4, TP = 6):
+// 118 K cycles per workgroup ~ 58-61 us = P1 15 K (search 6.5, ranks 5, barrier) + scan 9.5 K (three barriers) + scatter 18 K (LDS: a
+// random-address ds_write_b128 per point) + owners 62 K (VALU: 16 fp64 operations per point at 4.5 cycles with four waves per SIMD,
+// but only 1 in 2.8 lane-iterations carries a point: the loops run as long as the longest of 64 Poisson(3) runs) + epilogue 13 K.
+// The memory stream is hidden (the tile's loads have landed when P1 starts); a read-only kernel of the same launch shape takes
+// 23-25 us (tools/micro/phi_sort_bench.hip `stream ceiling`).  Measured and NOT adopted: tiles of 8 points per thread (longer runs,
+// 13 % fewer owner iterations, but 11 spilled registers whose reloads wait on the prefetched tile: +8 us); issuing the next tile's
+// loads before the scan instead of behind the scatter (no change: the stream is not the bound); a run-length cap per cell and tile
+// with the surplus points carried to the next tile through an LDS queue (owner loops 62 K -> 57 K cycles, but scatter, scan and
+// rank phases +20 K: 8 us slower); the in-wave heavy-cell path of the first version (sorted input: one wave walks 8192 points).
 // Applies to meshes that are an exact numpy.linspace (the host decides, the kernel re-checks the table), D = 1, 16-B aligned
 // x / y, at most 2048 cells.  Epilogue: moments -> band entries through the exact integer-ratio tables MomTab, one partial
 // [band | Phi y | y^T y] per workgroup, summed by phi_reduce_kernel exactly like the other algorithms.

@@ -281,6 +281,35 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
           ua[r][c] = (double)Ua.v[r][c]; ub[r][c] = (double)Ub.v[r][c];
         }
       }
+      {   // L^-1 (long double) with its tangent d L^-1 = -L^-1 dL L^-1, then G_a^T = U_a^T L^-1, G_b^T = U_b^T L^-1, D^-1 = L^-T L^-1
+        ld Li[MAXB][MAXB];
+        double Lid[MAXB][MAXB], dLi[MAXB][MAXB], tmp[MAXB][MAXB];
+        for (int c = 0; c < B; ++c)
+          for (int r = 0; r < B; ++r) {
+            ld t = (r == c) ? 1.0L : 0.0L;
+            for (int q2 = 0; q2 < r; ++q2) t -= D.v[r][q2] * Li[q2][c];
+            Li[r][c] = (r >= c) ? t * inv[r] : 0.0L;
+            Lid[r][c] = (double)Li[r][c];
+          }
+        for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { double t = 0.0; for (int q2 = 0; q2 < B; ++q2) t += D.d[r][q2] * Lid[q2][c]; tmp[r][c] = t; }
+        for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { double t = 0.0; for (int q2 = 0; q2 < B; ++q2) t -= Lid[r][q2] * tmp[q2][c]; dLi[r][c] = t; }
+        for (int r = 0; r < B; ++r)
+          for (int c = 0; c < B; ++c) {
+            ld ga = 0.0L, gb = 0.0L, di = 0.0L;
+            double dga = 0.0, dgb = 0.0, ddi = 0.0;
+            for (int q2 = 0; q2 < B; ++q2) {
+              ga += Ua.v[q2][r] * Li[q2][c];
+              gb += Ub.v[q2][r] * Li[q2][c];
+              di += Li[q2][r] * Li[q2][c];
+              dga += Ua.d[q2][r] * Lid[q2][c] + ua[q2][r] * dLi[q2][c];
+              dgb += Ub.d[q2][r] * Lid[q2][c] + ub[q2][r] * dLi[q2][c];
+              ddi += dLi[q2][r] * Lid[q2][c] + Lid[q2][r] * dLi[q2][c];
+            }
+            put(rec, prior_f_GAT(B) + r * B + c, ga, dga);
+            put(rec, prior_f_GBT(B) + r * B + c, gb, dgb);
+            put(rec, prior_f_DINV(B) + r * B + c, di, ddi);
+          }
+      }
       // log L_jj in double: |log| ~ 10 at 1e-16 relative, times the class count - far below the 1e-9 |ELBO| gate of the bound
       logdet += (ld)L.node_count[q] * 2.0L * (ld)log(prod);
       for (int r = 0; r < B; ++r)

@@ -2,7 +2,8 @@
 // Table layout (doubles): [PRIOR_TAB_HEADER header | value plane: n_rec records of prior_rec_fields(B) | tangent plane: same]
 // header: [0] log|Kuu|, [1] d log|Kuu| / d lengthscale, [2] first failing column + 1 (0 = positive definite), [3] n_rec.
 // Record of an eliminated node (the fields bcr.hpp keeps per node in its workspace): L (B x B, lower, row-major), 1 / diag(L)
-// (B), U_a = L^-1 A[i,a] (B x B), U_b = L^-1 A[i,b] (B x B).  The root record carries Sigma_00 in the U_a slot.
+// (B), U_a = L^-1 A[i,a] (B x B), U_b = L^-1 A[i,b] (B x B), then what the matrix-core backward pass (bcr_mfma.hpp) consumes directly:
+// G_a^T = U_a^T L^-1, G_b^T = U_b^T L^-1, D^-1 = L^-T L^-1 (B x B each).  The root record carries Sigma_00 in the U_a slot.
 #pragma once
 #include <stddef.h>
 
@@ -21,7 +22,10 @@ ASVGP_HD constexpr int prior_f_L(int) { return 0; }
 ASVGP_HD constexpr int prior_f_I(int B) { return B * B; }
 ASVGP_HD constexpr int prior_f_UA(int B) { return B * B + B; }
 ASVGP_HD constexpr int prior_f_UB(int B) { return 2 * B * B + B; }
-ASVGP_HD constexpr int prior_rec_fields(int B) { return 3 * B * B + B; }
+ASVGP_HD constexpr int prior_f_GAT(int B) { return 3 * B * B + B; }
+ASVGP_HD constexpr int prior_f_GBT(int B) { return 4 * B * B + B; }
+ASVGP_HD constexpr int prior_f_DINV(int B) { return 5 * B * B + B; }
+ASVGP_HD constexpr int prior_rec_fields(int B) { return 6 * B * B + B; }
 
 struct PriorPlan;
 PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, int k, char* err, size_t errlen);

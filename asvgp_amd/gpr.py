@@ -189,10 +189,23 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
                                                  self._elbo_ws.numel() * 8, stream_ptr()), "elbo_data_chain_1d")
         return self._out
 
-    def _check_pd(self):
+    def _check_pd(self, relaunch=None, _retry=True):
         info = self._info.tolist()
         if info[0] < 0 or info[1] < 0:
-            raise AsvgpError("the ELBO launch gave up waiting for its helper workgroups (they never became resident): results discarded")
+            # The fused launch gave up waiting for its helper workgroups (they never became resident next to other work on the device).
+            # Its results are discarded; the arrival slots of the workspace are half-armed, so the workspace is zero-filled again, and the
+            # SAME step is re-issued through the multi-launch sweeps (band algorithm 1: no cross-workgroup waits), once.
+            self.fused_launch_fallbacks = getattr(self, "fused_launch_fallbacks", 0) + 1
+            self._elbo_ws.zero_()
+            self._info.zero_()
+            if not _retry or relaunch is None:
+                raise AsvgpError("the fused launch gave up waiting for its helper workgroups (they never became resident): results discarded")
+            self._h.set_band_algorithm(1)
+            try:
+                relaunch()
+            finally:
+                self._h.set_band_algorithm(Handle._defaults["band"])
+            return self._check_pd(_retry=False)
         if info[0]:
             raise NotPositiveDefiniteError("Kuu band not positive definite at column %d" % (info[0] - 1))
         if info[1]:
@@ -202,7 +215,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         """Variational bound on the log marginal likelihood (gpr.py:49-89); 0-d device tensor."""
         out = self._launch_elbo()
         if check_pd:
-            self._check_pd()
+            self._check_pd(self._launch_elbo)
         return out[0].clone()
 
     def maximum_log_likelihood_objective(self):
@@ -216,7 +229,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         """(elbo, d elbo / d (variance, lengthscale, noise variance)) as a 4-vector device tensor [e, dv, dl, ds]."""
         out = self._launch_elbo()
         if check_pd:
-            self._check_pd()
+            self._check_pd(self._launch_elbo)
         return out[:4].clone()
 
     # -- optimiser (example.py:28-33: gpflow.optimizers.Scipy = scipy L-BFGS-B on unconstrained variables) ---

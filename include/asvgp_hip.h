@@ -81,6 +81,11 @@ int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double
  *       numpy.linspace.  Sums follow arrival order: reproducible to rounding, not bit for bit (5 and 3 are).
  * Same statistics to <= 1e-12 of the band's largest entry. */
 int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
+/* the algorithm the handle's last asvgp_phi_accumulate_1d call actually ran (1, 3, 5 or 6; 0 before the first call) */
+int asvgp_phi_last_algorithm(asvgp_handle_t handle);
+/* Measurement aid: a read-only pass over x and y (16 B/point) with the Phi pass's launch shape - the stream ceiling the
+ * Phi kernel's achieved bandwidth is reported beside.  sink: device buffer of >= 8 bytes (never written for finite data). */
+int asvgp_stream_probe(const double* x, const double* y, int64_t N, double* sink, asvgp_stream_t stream);
 /* workgroups of the Phi-pass kernel: 0 = default (256, one per CU); a smaller number leaves CUs free so that a
  * concurrently enqueued asvgp_elbo_prior_chain_1d (second stream) is resident at the same time. */
 int asvgp_set_phi_workgroups(asvgp_handle_t handle, int n);
@@ -168,8 +173,12 @@ size_t asvgp_elbo_workspace_bytes(int64_t M, int k, int64_t D);   /* the workspa
 /* band algorithm of the fused drivers below: 0 = auto, 1 = sequential single-wave sweeps (the reference's elimination order),
  * 2 = block cyclic reduction (O(log M) dependent levels), both chains on the GPU, 3 = block cyclic reduction with the PLANNED
  * prior chain (asvgp_prior_plan_1d): forward pass of the Kuu chain on the host in long double over the O(log M) distinct
- * nodes, backward (selected inverse) pass on the GPU.  Auto = 3 when the handle holds a matching plan, else 2 when both chains
- * fit the 160 KiB LDS and D == 1, else 1.  2 / 3 return ASVGP_ERR_LDS_CAPACITY when the chains do not fit. */
+ * nodes, backward (selected inverse) pass on the GPU, 4 = the planned chains with every 4 x 4 block product on the matrix cores
+ * (v_mfma_f64_4x4x4f64; k = 4, D = 1, M <= 2048, asvgp_elbo_grad_1d).  Auto = 4 where it applies, else 3 when the handle holds a
+ * matching plan, else 2 when both chains fit the 160 KiB LDS and D == 1, else 1.  2 / 3 return ASVGP_ERR_LDS_CAPACITY when the chains
+ * do not fit.  info[1] < 0 after a fused launch: the launch gave up waiting for its helper workgroups (they never became resident);
+ * its results are to be discarded, the workspace zero-filled again and the step re-issued (asvgp_amd.GPR_1d does that through
+ * algorithm 1). */
 int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo);
 /* Plan of the prior chain for one (basis, kernel kind).  static_bands_host: HOST copy of the (n_terms, k+1, M) array the ELBO
  * entry points receive on the device (inducing_features.py:16-44 order).  Kuu = sum_t c_t(theta) S_t is Toeplitz away from the

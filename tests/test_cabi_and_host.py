@@ -260,7 +260,7 @@ def test_prior_plan_host_forward_vs_long_double_bcr(lib, order, M, kind, l):
     assert lib.asvgp_prior_forward_host(S.ctypes.data, len(terms), M, order, c.ctypes.data, dc.ctypes.data, tab.ctypes.data, n,
                                         rec.ctypes.data) == 0
     B, R = order, int(tab[3])
-    W = 3 * B * B + B
+    W = 6 * B * B + B          # L, 1/diag, U_a, U_b | G_a^T, G_b^T, D^-1 (the matrix-core backward pass's operands)
     assert n == 8 + 2 * R * W and tab[2] == 0 and R <= 3 * 12 and rec.min() >= 0 and rec.max() == R - 1 == rec[0]
     val, tan = tab[8:8 + R * W].reshape(R, W), tab[8 + R * W:].reshape(R, W)
     K, dK = O.make_Kuu(bs, kind, 0.9, l, want_dl=True)
@@ -271,6 +271,11 @@ def test_prior_plan_host_forward_vs_long_double_bcr(lib, order, M, kind, l):
             got = val[rec[i], off:off + B * B].reshape(B, B)
             assert np.max(np.abs(got - X.astype(np.float64))) <= cond_slack * max(1.0, float(np.max(np.abs(X)))), (i, off)
         np.testing.assert_allclose(val[rec[i], B * B:B * B + B] * np.diag(L).astype(np.float64), 1.0, rtol=cond_slack)
+        Li = np.linalg.inv(L.astype(np.float64)).astype(np.longdouble)      # (4 x 4 .. 6 x 6 triangular: well conditioned)
+        Li = Li + Li @ (np.eye(B, dtype=np.longdouble) - L @ Li)             # one refinement step in long double
+        for off, X in ((3 * B * B + B, Ua.T @ Li), (4 * B * B + B, Ub.T @ Li), (5 * B * B + B, Li.T @ Li)):
+            got = val[rec[i], off:off + B * B].reshape(B, B)
+            assert np.max(np.abs(got - X.astype(np.float64))) <= 10 * cond_slack * max(1.0, float(np.max(np.abs(X)))), (i, off)
     np.testing.assert_allclose(val[rec[0], :B * B].reshape(B, B), L0.astype(np.float64), rtol=0, atol=cond_slack * float(np.max(L0)))
     assert abs(tab[0] - float(logdet)) <= max(1e-12, cond_slack * 1e-2) * abs(float(logdet))
     # tangents against central differences of the long-double pass (well-conditioned cases only resolve this)
@@ -284,6 +289,15 @@ def test_prior_plan_host_forward_vs_long_double_bcr(lib, order, M, kind, l):
                 fd = ((fp[i][q] - fm[i][q]) / (2 * h)).astype(np.float64)
                 got = tan[rec[i], off:off + B * B].reshape(B, B)
                 assert np.max(np.abs(got - fd)) <= 1e-5 * max(1e-12, float(np.max(np.abs(fd)))), (i, off)
+
+            def gmats(f):
+                L_, Ua_, Ub_ = f
+                Li_ = np.linalg.inv(L_.astype(np.float64))
+                return Ua_.astype(np.float64).T @ Li_, Ub_.astype(np.float64).T @ Li_, Li_.T @ Li_
+            for off, Xp, Xm in zip((3 * B * B + B, 4 * B * B + B, 5 * B * B + B), gmats(fp[i]), gmats(fm[i])):
+                fd = (Xp - Xm) / (2 * h)
+                got = tan[rec[i], off:off + B * B].reshape(B, B)
+                assert np.max(np.abs(got - fd)) <= 1e-4 * max(1e-12, float(np.max(np.abs(fd)))), (i, off)
     # a band without Toeplitz structure has no plan
     rng = np.random.default_rng(0)
     Sr = np.ascontiguousarray(S + rng.uniform(0, 1e-3, S.shape) * (np.abs(S) > 0))

@@ -1477,3 +1477,33 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "roofline" in d
+
+
+def test_fused_launch_that_gives_up_waiting_falls_back_to_the_multi_launch_path(A):
+    """ADVICE r2 / VERDICT r2 #6: a fused ELBO launch whose helper workgroups never report (forced through the library's test hook, with a
+    short spin limit) must not return a bound built from incomplete bands: info stays negative (sticky), the model re-arms its
+    workspace, re-issues the step through the multi-launch sweeps and counts the event; the next ordinary call works again."""
+    rng = np.random.default_rng(3)
+    N, M = 20000, 2048
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    good = model.elbo_and_grad().cpu().numpy()
+    os.environ["ASVGP_DEBUG_NO_ASSEMBLY"] = "1"
+    os.environ["ASVGP_SPIN_LIMIT"] = "20000"
+    try:
+        model._launch_elbo()
+        torch.cuda.synchronize()
+        assert model._info.tolist()[1] < 0                      # the abort reached the host
+        got = model.elbo_and_grad().cpu().numpy()               # aborts again, falls back inside the call
+    finally:
+        del os.environ["ASVGP_DEBUG_NO_ASSEMBLY"], os.environ["ASVGP_SPIN_LIMIT"]
+    assert getattr(model, "fused_launch_fallbacks", 0) >= 1
+    ob = O.Basis(4, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
+    oe, og, _ = O.elbo_grad_1d(ob, O.MATERN32, Ab, b, yy, N, 1.0, 0.05, 0.01)
+    assert abs(got[0] - oe) <= elbo_tol(oe, N, 1.0, 0.01, yy)
+    np.testing.assert_allclose(got[1:4], og, rtol=1e-6)
+    again = model.elbo_and_grad().cpu().numpy()                 # the fused path, re-armed
+    np.testing.assert_allclose(again, good, rtol=1e-9)

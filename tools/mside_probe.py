@@ -1,0 +1,42 @@
+"""M-side timing: the fused ELBO + gradient launch against its parts (Kuu backward pass alone through asvgp_kuu_inverse_band_1d).
+usage: python tools/mside_probe.py [M=2048]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import asvgp_amd as A
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+N = 1_000_000
+rng = np.random.default_rng(1234)
+x = rng.uniform(1e-9, 1 - 1e-9, N); y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+model = A.GPR_1d((torch.from_numpy(x).cuda().reshape(-1, 1), torch.from_numpy(y).cuda().reshape(-1, 1)), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+model.likelihood.variance.assign(0.01)
+def timed(fn, reps=40):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps, t_enq * 1e6 / reps
+for algo in (0, 2):
+    A.set_band_algorithm(algo)
+    us, enq = timed(model._launch_elbo)
+    print("band algorithm %d: ELBO + gradient launch %.1f us per call (host enqueue %.1f us)  -> %s" % (algo, us, enq, model._out[:4].tolist()))
+A.set_band_algorithm(0)
+os.environ["ASVGP_CHAIN_STAMPS"] = "1"
+for _ in range(3):
+    model._launch_elbo()
+torch.cuda.synchronize()
+del os.environ["ASVGP_CHAIN_STAMPS"]
+k, D = 4, 1
+ws = model._elbo_ws.cpu().numpy()
+off = 9 * (k + 1) * M + 2 * M * D
+st = ws[off + 8: off + 8 + 12].reshape(3, 4)
+t0 = st[:, 0].min()
+for name, row in zip(("P chain (workgroup 0)", "Kuu backward (workgroup 1)", "helper 0 (assemble, wait, finalize)"), st):
+    print("%-38s start +%.2f us | phase mark +%.2f us | end +%.2f us (100 MHz wall clock, relative to the earliest start)" % (
+        name, (row[0] - t0) / 100, (row[0] - t0 + row[1]) / 100, (row[0] - t0 + row[2]) / 100))
+feat = model.inducing_features
+us, enq = timed(lambda: feat.inverse_band(model.kernel))
+print("Kuu chain alone (asvgp_kuu_inverse_band_1d: assemble + planned backward pass): %.1f us per call (host enqueue %.1f us)" % (us, enq))
