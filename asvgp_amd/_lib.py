@@ -22,6 +22,9 @@ SIGNATURES = {
     "asvgp_set_phi_algorithm": (_I, [_P, _I]),
     "asvgp_phi_last_algorithm": (_I, [_P]),
     "asvgp_stream_probe": (_I, [_P, _P, _L, _P, _P]),
+    "asvgp_debug_reload_env": (_I, []),
+    "asvgp_result_mirror": (_I, [_P, _I, _c.POINTER(_P)]),
+    "asvgp_result_mirror_pending": (_c.c_uint64, [_P]),
     "asvgp_set_phi_workgroups": (_I, [_P, _I]),
     "asvgp_set_phi_deferred_reduce": (_I, [_P, _I]),
     "asvgp_phi_reduce_1d": (_I, [_P, _P]),
@@ -135,6 +138,20 @@ class Handle:
     def phi_last_algorithm(self):
         return int(self._lib.asvgp_phi_last_algorithm(self.ptr))
 
+    def result_mirror(self, enable=True):
+        """asvgp_result_mirror: the handle's 16 pinned doubles [out[0..7], info[0], info[1], sequence] as a numpy view (None when off)."""
+        import numpy as np
+        ptr = _P()
+        check(self._lib.asvgp_result_mirror(self.ptr, int(bool(enable)), ctypes.byref(ptr)), "result_mirror")
+        if not enable or not ptr.value:
+            self._mirror = None
+            return None
+        self._mirror = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(_D)), shape=(16,))
+        return self._mirror
+
+    def result_mirror_pending(self):
+        return int(self._lib.asvgp_result_mirror_pending(self.ptr))
+
     def set_phi_workgroups(self, n):
         check(self._lib.asvgp_set_phi_workgroups(self.ptr, int(n)), "set_phi_workgroups")
 
@@ -178,7 +195,19 @@ def set_default_algorithms(band=None, phi=None):
             h.set_phi_algorithm(phi)
 
 
+_stream_override = None
+
+
+def set_stream(stream=None):
+    """Launch every following library call on `stream` (a torch.cuda.Stream) instead of torch's current stream; None restores the
+    default.  Saves the `with torch.cuda.stream(...)` enter / exit (several microseconds each) in latency-bound host loops."""
+    global _stream_override
+    _stream_override = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
+
+
 def stream_ptr():
+    if _stream_override is not None:
+        return _stream_override
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -385,7 +385,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
       // (agent-scope stores: the fused launch's last ticket may read them from another XCD, where a plain store would still be a dirty L2 line)
       __hip_atomic_store(logdet + 0, 2.0 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(logdet + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *info = (bmin == 0x7fffffff) ? 0 : bmin;
+      __hip_atomic_store(info, (bmin == 0x7fffffff) ? 0 : bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   stamp();
@@ -415,9 +415,24 @@ __device__ __forceinline__ BmDual bm_dmfma(BmDual x, BmDual y, BmDual c) {   // 
 
 __device__ __attribute__((always_inline)) void bcr_mfma_backward_pre(const double* __restrict__ tab, int n_rec, const int* __restrict__ node_rec, int M,
                                                                       double* ws, double* lds, double* Sv, double* Sd, double* logdet, int* info,
-                                                                      unsigned long long* done_flag, unsigned long long seq) {
+                                                                      unsigned long long* done_flag, unsigned long long seq,
+                                                                      const unsigned long long* ready_flag = nullptr, long spin_limit = 0, int* gave_up = nullptr) {
   constexpr int B = BM_B, W = prior_rec_fields(B);
   const int tid = threadIdx.x;
+  if (ready_flag) {
+    // The launch was issued BEFORE the host ran this theta's forward pass (elbo.hip, run_chains): wait until the host has published table
+    // `seq` in this slot (pinned memory, one 8-byte system-scope load per poll).  Bounded: *gave_up (LDS) is set and the caller leaves.
+    if (tid == 0) {
+      long spins = 0;
+      while (__hip_atomic_load(ready_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > spin_limit) { *gave_up = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (*gave_up) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane >> 4, q = (lane >> 2) & 3, c = lane & 3;
   const int e = r * 4 + c, et = c * 4 + r;
@@ -520,7 +535,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_backward_pre(const doubl
   if (tid == 0) {
     __hip_atomic_store(logdet + 0, tl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(logdet + 1, tl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *info = (int)tl[2];
+    __hip_atomic_store(info, (int)tl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -10,6 +10,7 @@
 //   phase 2  inverse  : block0 dual Takahashi(Kuu) (gpr.py:59) | block1 Takahashi(P) + alpha = L_P^-T c
 //   phase 3  finalize : log-dets (gpr.py:57,74), band traces (gpr.py:60-70), 7-term bound (gpr.py:78-87), gradient
 #include <stdlib.h>
+#include <time.h>
 
 #include "bcr_pre.hpp"
 #include "bcr_mfma.hpp"
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(
 struct FusedFin {
   const double* stats; ElboScalars th; double alpha_scale; double* gacc; unsigned* ticket; unsigned* arrived; unsigned* assembled; double* out;
   long D; int n_helpers; int finalize; int debug_no_assembly; int debug_stamps;
+  double* mirror; unsigned long long mirror_seq;   // asvgp_result_mirror (matrix-core launch only)
 };
 __device__ __forceinline__ void assemble_band_slice(const double* __restrict__ S, const double* __restrict__ coef, const double* __restrict__ dcoef, int n_terms,
                                                     long E, long e, double* __restrict__ Kuu, double* __restrict__ dK) {
@@ -440,7 +442,8 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(const doub
                                                                       double* wsP, double* SP, double* x, double* logdets, int* info,
                                                                       double s, const double* tab, int n_rec, const int* node_rec,
                                                                       double* wsK, double* SK, double* dSK,
-                                                                      unsigned long long* done_flag, unsigned long long seq, long spin_limit, FusedFin fin) {
+                                                                      unsigned long long* done_flag, unsigned long long seq,
+                                                                      const unsigned long long* ready_flag, long spin_limit, FusedFin fin) {
   extern __shared__ double lds[];
   static_assert(K == BM_B, "matrix-core chains: bandwidth 4");
   const long E = (long)(K + 1) * M;
@@ -505,7 +508,9 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(const doub
       }
     }
   } else {
-    bcr_mfma_backward_pre(tab, n_rec, node_rec, M, wsK, lds, SK, dSK, logdets, info, done_flag, seq);
+    bcr_mfma_backward_pre(tab, n_rec, node_rec, M, wsK, lds, SK, dSK, logdets, info, done_flag, seq, ready_flag,
+                          spin_limit < (1L << 20) ? spin_limit : (1L << 20), &gave_up);
+    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }   // (the host never published the table: sticky, like the helpers' case)
     rstamp(1);
     if (fin.finalize) {
       wait_assembled();
@@ -600,6 +605,21 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(const doub
     double* out = fin.out;
     out[0] = elbo; out[1] = d_v; out[2] = d_l; out[3] = d_s;
     out[4] = tot[LOGK]; out[5] = tot[LOGP]; out[6] = tot[TRKA]; out[7] = tot[CC];
+    if (fin.mirror) {
+      // Pinned host memory: ten values and their sum, then - once those stores have been acknowledged - the sequence number.  (No
+      // system-scope RELEASE here: that would write the whole L2 back first, ~10 us.  System-scope stores go straight through; the
+      // host re-checks the sum after it has seen the sequence number.)
+      double* m = fin.mirror;
+      const double mv[10] = {elbo, d_v, d_l, d_s, tot[LOGK], tot[LOGP], tot[TRKA], tot[CC],
+                             (double)__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             (double)__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { __hip_atomic_store(m + i, mv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); sum += mv[i]; }
+      __hip_atomic_store(m + 11, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(m + 10, (double)fin.mirror_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   rstamp(2);
 }
@@ -617,6 +637,8 @@ static __global__ void scale_kernel(double* __restrict__ x, double f, long n) {
 template <int K, bool TANGENT>
 static int run_chains(Handle* h, const double* stats, const double* S, int kind, double v, double l, double s, long M, long D,
                       Ws w, int* info, hipStream_t st, bool& use_bcr, int part = 0, bool scale_alpha = true, FusedFin* fin = nullptr) {
+  double t_enter = 0.0;
+  if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_enter = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
   KuuCoefs2 cf;
   for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
   int rc = asvgp_matern_coeffs(kind, v, l, cf.c, cf.dc, &cf.n);
@@ -655,8 +677,10 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     if (!fits) { set_error("BCR needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
     unsigned long long seq = 0;
     int slot = 0;
+    double t_acq0 = 0.0, t_acq1 = 0.0;
+    if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_acq0 = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
     double* tab = handle_table_acquire(h, &seq, &slot);
-    (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);   // a non-positive pivot is reported through `info` by the kernel
+    if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_acq1 = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
     const int n_rec = prior_plan_nrec(h->plan);
     size_t lds_pre = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
     if (lds_pre > lds_bytes) lds_bytes = lds_pre;
@@ -667,9 +691,9 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     // in-flight schedule found no free CU there for a helper - its P chain then waited for the whole previous launch to finish
     ff.n_helpers = (int)((M + 255) / 256 < 6 ? (M + 255) / 256 : 6);
     ff.assembled = reinterpret_cast<unsigned*>(w.fin + 20);
-    ff.debug_no_assembly = getenv("ASVGP_DEBUG_NO_ASSEMBLY") ? 1 : 0;
-    ff.debug_stamps = getenv("ASVGP_CHAIN_STAMPS") ? 1 : 0;   // test hook: the helpers never report -> the P chain gives up waiting
-    const long spin_limit = getenv("ASVGP_SPIN_LIMIT") ? atol(getenv("ASVGP_SPIN_LIMIT")) : (1L << 25);
+    ff.debug_no_assembly = debug_env().no_assembly;
+    ff.debug_stamps = debug_env().chain_stamps;   // test hook: the helpers never report -> the P chain gives up waiting
+    const long spin_limit = debug_env().spin_limit;
     bool use_mfma = false;
     if constexpr (K == BM_B) {
       // matrix-core chains: k = 4, one output column, the whole tree in one workgroup's LDS, no explicit request for the older kernel
@@ -680,14 +704,47 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         if (lk > lb) lb = lk;
         if (sizeof(double) * FIN_LDS_DOUBLES > lb) lb = sizeof(double) * FIN_LDS_DOUBLES;
         auto kern = elbo_chains_mfma_kernel<K>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+        static size_t lds_granted[16] = {0};                     // per device: the dynamic-LDS size already granted to this kernel
+        size_t& granted = lds_granted[h->device & 15];
+        if (lb > granted) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+          if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+          granted = lb;
+        }
+        if (h->mirror_dev) { ff.mirror = h->mirror_dev; ff.mirror_seq = ++h->mirror_seq; h->mirror_pending = ff.mirror_seq; }
+        // The launch goes out FIRST: its ~8 us of dispatch latency, the helpers' assembly and the P chain (which needs only Kuu, not its
+        // factors) run while this thread does the forward pass below; the Kuu workgroup waits on ready[slot] (bcr_mfma_backward_pre).
+        const bool plan_first = debug_env().plan_first != 0;   // (measurement aid: the round-2 order, forward pass then launch)
+        const bool host_times = debug_env().host_times != 0;   // (measurement aid: where this call's host time goes)
+        auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+        const double t0 = host_times ? now_us() : 0.0;
+        if (plan_first) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
         hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BM_THREADS), lb, st, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
-                           h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq, spin_limit, ff);
+                           h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
+                           plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
+        const double t1 = host_times ? now_us() : 0.0;
+        if (!plan_first) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);   // a non-positive pivot is reported through `info` by the kernel
+        if (host_times) {
+          static double acc_launch = 0.0, acc_plan = 0.0, acc_pre = 0.0, acc_acq = 0.0, acc_a = 0.0;
+          acc_acq += t_acq1 - t_acq0; acc_a += t_acq0 - t_enter;
+          static long calls = 0;
+          const double t2 = now_us();
+          acc_pre += t0 - t_enter; acc_launch += t1 - t0; acc_plan += t2 - t1;
+          if (++calls % 200 == 0) {
+            fprintf(stderr, "[entry -> acquire %.1f us, table acquire %.1f us] ", acc_a / 200, acc_acq / 200);
+            acc_a = acc_acq = 0.0;
+            fprintf(stderr, "[asvgp host times, mean of 200 calls] entry -> launch call %.1f us | launch call (%s) %.1f us | %s %.1f us\n", acc_pre / 200,
+                    plan_first ? "forward pass + hipLaunchKernel" : "hipLaunchKernel", acc_launch / 200, plan_first ? "-" : "forward pass", acc_plan / 200);
+            acc_launch = acc_plan = acc_pre = 0.0;
+          }
+        }
+        __atomic_store_n(h->ready_host + slot, seq, __ATOMIC_RELEASE);
       }
     }
     if (algo == 4 && !use_mfma) { set_error("band algorithm 4 (matrix-core chains) needs k = 4, D = 1, M <= 2048 and the ELBO + gradient entry point"); return ASVGP_ERR_UNSUPPORTED; }
     if (!use_mfma) {
+    (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);     // a non-positive pivot is reported through `info` by the kernel
+    __atomic_store_n(h->ready_host + slot, seq, __ATOMIC_RELEASE);
     auto kern = big ? elbo_chains_kernel<K, HAS_BIG> : elbo_chains_kernel<K, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
@@ -719,19 +776,19 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
         hipLaunchKernelGGL(kern, dim3(1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK, (int)M, w.bcrK, w.SK, w.dSK, w.logdets, info,
-                           getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0);
+                           debug_env().bcr_stamps);
       }
     } else if (pfly) {
       auto kern = big ? elbo_bcr_data_kernel<K, HAS_BIG> : elbo_bcr_data_kernel<K, false>;
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
       hipLaunchKernelGGL(kern, dim3(1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info,
-                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, s, (int)D, (int)(lds_bytes / sizeof(double)));
+                         debug_env().bcr_stamps, s, (int)D, (int)(lds_bytes / sizeof(double)));
     } else {
       auto kern = big ? elbo_bcr_kernel<K, TANGENT, HAS_BIG> : elbo_bcr_kernel<K, TANGENT, false>;
       hipLaunchKernelGGL(kern, dim3(part == 0 ? 2 : 1), dim3(BCR_THREADS), lds_bytes, st, w.Kuu, w.dK,
                          w.P, b, (int)M, w.bcrK, w.bcrP, w.SK, w.dSK, w.SP, w.alpha, w.logdets, info,
-                         getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0, part == 2 ? 1 : 0, (int)D, (int)(lds_bytes / sizeof(double)));
+                         debug_env().bcr_stamps, part == 2 ? 1 : 0, (int)D, (int)(lds_bytes / sizeof(double)));
     }
     if (part == 1) {
       if (h->sync_on) (void)hipEventRecord(h->evP, st);
@@ -764,6 +821,7 @@ int ElboLauncher<K>::run(Handle* h, const double* stats, const double* S, int ki
   {
     Ws w = carve(ws, M, K, D);
     bool bcr = false;
+    h->mirror_pending = 0;                                    // (set again by the one launch that writes the mirror)
     ElboScalars th{v, l, s, (double)N};
     const int fin_blocks = (int)((M + 255) / 256 < 64 ? (M + 255) / 256 : 64);
     static_assert(BCR_THREADS == 256, "the fused finalize shares the chain kernel's workgroup size");

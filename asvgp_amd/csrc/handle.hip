@@ -1,5 +1,6 @@
 // asvgp_create / asvgp_destroy and the per-handle settings (C-ABI, include/asvgp_hip.h).
 #include <sched.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -9,6 +10,22 @@
 #include "handle.hpp"
 
 namespace asvgp {
+
+static DebugEnv g_dbg;
+static bool g_dbg_loaded = false;
+static void debug_env_load() {
+  g_dbg.no_assembly = getenv("ASVGP_DEBUG_NO_ASSEMBLY") ? 1 : 0;   // test hook: the helpers never report -> the chains give up waiting
+  g_dbg.chain_stamps = getenv("ASVGP_CHAIN_STAMPS") ? 1 : 0;
+  g_dbg.spin_limit = getenv("ASVGP_SPIN_LIMIT") ? atol(getenv("ASVGP_SPIN_LIMIT")) : (1L << 25);
+  g_dbg.host_times = getenv("ASVGP_HOST_TIMES") ? 1 : 0;
+  g_dbg.plan_first = getenv("ASVGP_PLAN_FIRST") ? 1 : 0;
+  g_dbg.bcr_stamps = getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0;
+  g_dbg_loaded = true;
+}
+const DebugEnv& debug_env() {
+  if (!g_dbg_loaded) debug_env_load();
+  return g_dbg;
+}
 
 static Handle* g_default = nullptr;
 static std::mutex g_default_mu;
@@ -28,6 +45,7 @@ static void plan_release(Handle* h) {
   if (h->node_rec_dev) { (void)hipFree(h->node_rec_dev); h->node_rec_dev = nullptr; }
   if (h->tab_host) { (void)hipHostFree(h->tab_host); h->tab_host = nullptr; h->tab_dev = nullptr; }
   if (h->done_host) { (void)hipHostFree(h->done_host); h->done_host = nullptr; h->done_dev = nullptr; }
+  if (h->ready_host) { (void)hipHostFree(h->ready_host); h->ready_host = nullptr; h->ready_dev = nullptr; }
   h->slot_doubles = 0;
 }
 
@@ -84,6 +102,11 @@ bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hip
 
 using namespace asvgp;
 
+extern "C" int asvgp_debug_reload_env(void) {
+  asvgp::debug_env_load();
+  return ASVGP_OK;
+}
+
 extern "C" int asvgp_create(asvgp_handle_t* out) {
   if (!out) { set_error("asvgp_create: bad argument"); return ASVGP_ERR_BAD_ARG; }
   Handle* h = new Handle;
@@ -97,6 +120,7 @@ extern "C" int asvgp_destroy(asvgp_handle_t handle) {
   Handle* h = reinterpret_cast<Handle*>(handle);
   if (h->magic != 0x41535647u) { set_error("asvgp_destroy: not a handle"); return ASVGP_ERR_BAD_ARG; }
   plan_release(h);
+  if (h->mirror_host) (void)hipHostFree(h->mirror_host);
   if (h->evK) (void)hipEventDestroy(h->evK);
   if (h->evP) (void)hipEventDestroy(h->evP);
   if (h->prof_made)
@@ -136,6 +160,29 @@ extern "C" int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo) {
   as_handle(handle)->band_algo = algo;
   return ASVGP_OK;
 }
+
+extern "C" int asvgp_result_mirror(asvgp_handle_t handle, int enable, const double** host_ptr) {
+  Handle* h = as_handle(handle);
+  if (enable && !h->mirror_host) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->mirror_host), sizeof(double) * 16, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->mirror_dev), h->mirror_host, 0) != hipSuccess) {
+      if (h->mirror_host) { (void)hipHostFree(h->mirror_host); h->mirror_host = nullptr; }
+      h->mirror_dev = nullptr;
+      set_error("result_mirror: pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
+      return ASVGP_ERR_HIP;
+    }
+    memset(h->mirror_host, 0, sizeof(double) * 16);
+  }
+  if (!enable && h->mirror_host) {
+    (void)hipDeviceSynchronize();            // (a launch in flight may still write it)
+    (void)hipHostFree(h->mirror_host);
+    h->mirror_host = nullptr; h->mirror_dev = nullptr; h->mirror_pending = 0;
+  }
+  if (host_ptr) *host_ptr = h->mirror_host;
+  return ASVGP_OK;
+}
+
+extern "C" uint64_t asvgp_result_mirror_pending(asvgp_handle_t handle) { return as_handle(handle)->mirror_pending; }
 
 extern "C" int asvgp_elbo_chain_sync(asvgp_handle_t handle, int enable) {
   Handle* h = as_handle(handle);
@@ -200,10 +247,12 @@ extern "C" int asvgp_prior_plan_1d(asvgp_handle_t handle, const double* static_b
   h->slot_doubles = (prior_plan_table_doubles(p) + 63) / 64 * 64;
   bool ok = hipMalloc(reinterpret_cast<void**>(&h->node_rec_dev), sizeof(int) * (size_t)nb) == hipSuccess &&
             hipMemcpy(h->node_rec_dev, prior_plan_node_rec(p), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void**>(&h->tab_host), sizeof(double) * h->slot_doubles * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&h->tab_host), sizeof(double) * h->slot_doubles * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess &&
             hipHostGetDevicePointer(reinterpret_cast<void**>(&h->tab_dev), h->tab_host, 0) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void**>(&h->done_host), sizeof(unsigned long long) * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
-            hipHostGetDevicePointer(reinterpret_cast<void**>(&h->done_dev), h->done_host, 0) == hipSuccess;
+            hipHostMalloc(reinterpret_cast<void**>(&h->done_host), sizeof(unsigned long long) * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&h->done_dev), h->done_host, 0) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&h->ready_host), sizeof(unsigned long long) * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ready_dev), h->ready_host, 0) == hipSuccess;
   if (!ok) {
     prior_plan_destroy(p);
     plan_release(h);
@@ -211,6 +260,7 @@ extern "C" int asvgp_prior_plan_1d(asvgp_handle_t handle, const double* static_b
     return ASVGP_ERR_HIP;
   }
   memset(h->done_host, 0, sizeof(unsigned long long) * TAB_SLOTS);
+  memset(h->ready_host, 0, sizeof(unsigned long long) * TAB_SLOTS);
   h->plan = p;
   h->plan_terms = n_terms;
   h->seq = 0;

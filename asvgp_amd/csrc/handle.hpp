@@ -35,14 +35,26 @@ struct Handle {
   double* tab_dev = nullptr;              // the same memory as seen from the device
   unsigned long long* done_host = nullptr;   // per slot: sequence number of the last table the GPU has finished reading
   unsigned long long* done_dev = nullptr;
+  unsigned long long* ready_host = nullptr;  // per slot: sequence number of the table the HOST has finished writing (the matrix-core launch is
+  unsigned long long* ready_dev = nullptr;   // issued BEFORE the host forward pass; its Kuu workgroup waits here - run_chains in elbo.hip)
   size_t slot_doubles = 0;
   unsigned long long seq = 0;
   int plan_terms = 0;
+  // result mirror (asvgp_result_mirror): 16 pinned doubles the fused launch's last ticket writes [out[0..7], info[0], info[1], sequence]
+  double* mirror_host = nullptr;
+  double* mirror_dev = nullptr;
+  unsigned long long mirror_seq = 0;      // sequence number of the last launch that writes the mirror
+  unsigned long long mirror_pending = 0;  // = mirror_seq when the LAST ELBO launch writes the mirror, else 0
   // meshes already inspected (handle_mesh_is_linspace): device pointer, length, first / last knot -> verdict
   struct MeshSeen { const double* ptr; long n; int regular; double step, first, last; };
   MeshSeen mesh_seen[8];
   int n_mesh_seen = 0;
 };
+
+// Debug / measurement switches from the environment, read ONCE (a getenv per launch costs microseconds where the environment is large)
+// and again on asvgp_debug_reload_env() - the tests that flip them call that.
+struct DebugEnv { int no_assembly; int chain_stamps; long spin_limit; int host_times; int plan_first; int bcr_stamps; };
+const DebugEnv& debug_env();
 
 Handle* as_handle(asvgp_handle_t h);      // NULL -> the process-wide default handle (created on first use)
 

@@ -8,6 +8,7 @@ banded_matrices op gradients), fit() (L-BFGS-B driver, replacing gpflow.optimize
 N-sharded construction over RCCL.
 """
 import math
+import time
 
 import numpy as np
 import torch
@@ -160,12 +161,15 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
 
     def _launch_elbo(self):
         v, l, s = self.theta()
-        b = self.basis
         S = self._statics()
-        check(get_lib().asvgp_elbo_grad_1d(self._h.ptr, self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, v, l, s,
-                                           self.num_data, b.m, self.bandwidth, self.D, self._out.data_ptr(),
-                                           self._info.data_ptr(), self._elbo_ws.data_ptr(),
-                                           self._elbo_ws.numel() * 8, stream_ptr()), "elbo_grad_1d")
+        c = self.__dict__.get("_elbo_call")
+        if c is None or c[0] is not S or c[1] is not self._stats:       # (device pointers of this model's buffers, looked up once)
+            c = self._elbo_call = (S, self._stats, get_lib().asvgp_elbo_grad_1d, self._h.ptr, self._stats.data_ptr(), S.data_ptr(),
+                                   self.basis.m, self.bandwidth, self.D, self._out.data_ptr(), self._info.data_ptr(),
+                                   self._elbo_ws.data_ptr(), self._elbo_ws.numel() * 8)
+        rc = c[2](c[3], c[4], c[5], self.kernel.kind, v, l, s, self.num_data, c[6], c[7], c[8], c[9], c[10], c[11], c[12], stream_ptr())
+        if rc:
+            check(rc, "elbo_grad_1d")
         return self._out
 
     # -- the same computation split for scheduling (asvgp_elbo_prior_chain_1d / asvgp_elbo_data_chain_1d) ------------
@@ -232,6 +236,44 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
             self._check_pd(self._launch_elbo)
         return out[:4].clone()
 
+    def launch_elbo_host(self):
+        """First half of elbo_and_grad_host(): enqueue the ELBO + gradient launch on the current stream with the handle's result mirror
+        armed; returns the token read_elbo_host() takes.  (Split so that a caller can enqueue other work - the next Phi pass - before it
+        starts polling.)"""
+        if getattr(self, "_mirror", None) is None:
+            self._mirror = self._h.result_mirror(True)
+        self._launch_elbo()
+        return self._h.result_mirror_pending()
+
+    def read_elbo_host(self, token, check_pd=True, poll_seconds=0.05):
+        """Second half: [e, dv, dl, ds] as Python floats.  token != 0: the launch writes the pinned mirror, sequence number last - poll that
+        word of host memory (no device-to-host copy, no stream synchronisation); otherwise, or when nothing arrives within poll_seconds
+        (a launch that gave up waiting never writes the mirror), read through the stream (and through _check_pd's re-issue)."""
+        m = self._mirror
+        if token:
+            want = float(token)
+            t_end = time.perf_counter() + poll_seconds
+            spins = 0
+            while m[10] != want:
+                spins += 1
+                if (spins & 255) == 0 and time.perf_counter() > t_end:
+                    break
+            while m[10] == want:
+                r = m[:12].tolist()
+                if sum(r[:10]) == r[11] or r[11] != r[11]:       # (the sum the kernel wrote with the values; NaN results pass through)
+                    if (r[8] == 0.0 and r[9] == 0.0) or not check_pd:
+                        return r[:4]
+                    break
+                if time.perf_counter() > t_end:
+                    break
+        if check_pd:
+            self._check_pd(self._launch_elbo)
+        return self._out[:4].tolist()
+
+    def elbo_and_grad_host(self, check_pd=True):
+        """elbo_and_grad() for a host that needs the four numbers NOW (an optimiser step: example.py:31-32); a list [e, dv, dl, ds]."""
+        return self.read_elbo_host(self.launch_elbo_host(), check_pd)
+
     # -- optimiser (example.py:28-33: gpflow.optimizers.Scipy = scipy L-BFGS-B on unconstrained variables) ---
     @property
     def trainable_parameters(self):
@@ -245,7 +287,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
             for p, ui in zip(params, u):
                 p.unconstrained = float(ui)
             try:
-                r = self.elbo_and_grad().tolist()
+                r = self.elbo_and_grad_host()
             except NotPositiveDefiniteError:
                 return np.inf, np.zeros(3)
             g = np.array(r[1:4]) * np.array([p.dtheta_du() for p in params])

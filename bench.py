@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
 """bench.py - Mpoints/s per ELBO+gradient step (BASELINE.json metric) on N GPUs of one node.
 
-A "step" = one pass of the hot path over the synthetic batch: fused Phi pass over this rank's N-shard ->
-one all-reduce(sum) of the packed band buffer (RCCL, only when N>1) -> banded ELBO + analytic gradient
-(replicated on every rank).  Inputs are resident in HBM before the timed region.  Strong scaling: the
-BASELINE workload is N = 10M points in total, sharded contiguously over the ranks.
+A "step" = one pass of the hot path over the synthetic batch: Phi pass over this rank's N-shard -> cross-workgroup reduce ->
+one all-reduce(sum) of the packed band buffer (RCCL, only when N>1) -> banded ELBO + analytic gradient (replicated on every
+rank).  Inputs are resident in HBM before the timed region.  Strong scaling: the BASELINE workload is N = 10M points in
+total, sharded contiguously over the ranks.
+
+`value` is the DEPENDENT-step figure (schedule C): theta of step i+1 is computed on the host from the result of step i that
+the host has read (an optimiser step, /root/reference's experiments/snelson/example.py:31-32 semantics), so neither the M-side
+launch nor the host forward pass of step i+1 can start before step i is finished; the only overlap is the theta-free Phi pass
+of step i+1 under the M-side of step i.  The --steps block is timed R times (--repeats) inside the process: `value` /
+`ms_per_step` are the median block, min / max ride along.  Extras: `one_step_at_a_time` (one stream, fixed theta, host runs
+ahead: the device-side latency of a full step) and `independent_evaluations` (several steps with the SAME theta in flight: a
+throughput of independent evaluations, not a step latency).
 
 Prints ONE JSON line on rank 0.  python bench.py [--gpus N --steps K --warmup W]
 With --gpus N > 1 and no torchrun environment (RANK unset) the script launches itself: the parent - before any GPU
@@ -25,6 +33,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_POINT = 16           # x and y read once, fp64
+PHI_KERNEL_NAMES = {6: "phi_sort_kernel<4, 6, 0, 1> (Phi pass, algorithm 6: tile sort + register moments)",
+                    5: "phi_moment_kernel<4, 2048, true> (Phi pass, algorithm 5)",
+                    3: "phi_band_kernel (Phi pass, algorithm 3)", 1: "phi_band_kernel (Phi pass, algorithm 1)"}
 
 
 def synth(N, seed=1234):
@@ -35,20 +46,20 @@ def synth(N, seed=1234):
     return x, y
 
 
-def measured_traffic(n_local):
+def measured_traffic(n_local, algo):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B streaming reads at 64 B).  The PMC passes
-    cannot run inside this process; the committed summary profiles/r02_phi_traffic.json (same kernel, same per-rank workload,
-    taken with tools/collect_profiles.sh) is quoted when the workload matches, otherwise null.  It is a labelled constant from
-    the committed profile, not a measurement of this run."""
-    path = os.path.join(ROOT, "profiles", "r02_phi_traffic.json")
+    cannot run inside this process; the committed summary profiles/r03_phi_traffic.json (same kernel, same per-rank workload,
+    taken with tools/collect_profiles.sh) is quoted when kernel and workload match, otherwise null.  It is a labelled constant
+    from the committed profile, not a measurement of this run."""
+    path = os.path.join(ROOT, "profiles", "r03_phi_traffic.json")
     try:
         d = json.load(open(path))
-        if int(d["points_per_launch"]) == int(n_local):
-            return d["hbm_bytes_per_launch"]
+        if int(d["points_per_launch"]) == int(n_local) and int(d.get("phi_algorithm", -1)) == int(algo):
+            return d["hbm_bytes_per_launch"], "profiles/r03_phi_traffic.json"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(x, y, M, theta, kind, gpu_stats=None, gpu_out=None):
@@ -76,10 +87,12 @@ def cpu_baseline(x, y, M, theta, kind, gpu_stats=None, gpu_out=None):
         parity = {"stats_max_abs_over_max": float(np.max(np.abs(gpu_stats - ref)) / np.max(np.abs(ref))),
                   "elbo_gpu": float(gpu_out[0]), "elbo_oracle_f64": oe, "elbo_oracle_long_double": ee,
                   "abs_elbo_vs_oracle": abs(float(gpu_out[0]) - oe), "abs_elbo_vs_long_double": abs(float(gpu_out[0]) - ee),
+                  "rel_elbo_vs_long_double": abs(float(gpu_out[0]) - ee) / abs(ee),
                   "abs_oracle_vs_long_double": abs(oe - ee),
                   "grad_max_rel_vs_oracle": float(np.max(np.abs((g - og) / og))),
                   "grad_max_rel_vs_long_double": float(np.max(np.abs((g - ge) / ge))),
-                  "gates": "stats 1e-12 of the largest entry; |dELBO| <= 1e-9|ELBO| + 5 x |oracle - long double|; gradient rel 1e-6"}
+                  "gates": "stats 1e-12 of the largest entry; |ELBO - long double| <= 1e-9 |ELBO|; gradient rel 1e-6 (the fp64-oracle "
+                           "differences are information: the fp64 reference order itself sits ~1e-8 |ELBO| from the long-double value)"}
     return base, parity
 
 
@@ -98,11 +111,17 @@ def self_launch(argv, n):
     return subprocess.call(cmd, env=env)
 
 
+def spread(ms_list):
+    a = np.sort(np.asarray(ms_list, dtype=np.float64))
+    return {"median": float(np.median(a)), "min": float(a[0]), "max": float(a[-1]), "blocks": [round(float(v), 5) for v in ms_list]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=11, help="the --steps block is timed this many times; median / min / max are reported")
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--features", type=int, default=2048)
     ap.add_argument("--sorted", action="store_true", help="secondary case: time-series (sorted) inputs")
@@ -110,17 +129,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="points of the workload the CPU oracle is timed on (a prefix; "
                     "parity is reported when it covers the whole workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3), help="0 auto (planned prior chain), 1 sequential sweeps, "
-                    "2 all-GPU block cyclic reduction with the round-1 two-stream schedule, 3 planned prior chain")
-    ap.add_argument("--in-flight", type=int, default=5, choices=tuple(range(1, 25)), help="steps in flight: 1 = one step at a time on one stream; "
-                    "L >= 2 = the Phi pass of step i+1 (N-side stream) runs under the band chains of step i (M-side stream), L sets of buffers")
-    ap.add_argument("--phi-streams", type=int, default=1, help="in-flight schedule: N-side streams (2: consecutive Phi kernels may overlap at their ends)")
-    ap.add_argument("--event-group", type=int, default=1, help="in-flight schedule: Phi passes per cross-stream event (an event record costs stream time)")
-    ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the in-flight schedule (2: the band chains of two steps side by side)")
-    ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the pipelined schedule (the chain workgroups need free CUs)")
-    ap.add_argument("--sync-each-step", action="store_true", help="diagnostic: host-synchronise after every step")
-    ap.add_argument("--kernel-events", type=int, default=10, help="HIP events around every n-th Phi kernel launch")
-    ap.add_argument("--phase-events", type=int, default=25, help="record per-phase events on every n-th step (0 = never)")
+    ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3, 4), help="0 auto (matrix-core chains, planned prior), 1 sequential sweeps, "
+                    "2 all-GPU block cyclic reduction, 3 planned prior chain (round-2 kernels), 4 matrix-core chains or error")
+    ap.add_argument("--phi-algo", type=int, default=0, choices=(0, 1, 3, 5, 6))
+    ap.add_argument("--in-flight", type=int, default=5, choices=tuple(range(0, 25)), help="extra `independent_evaluations`: steps in flight (0 = skip)")
+    ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the independent-evaluations extra")
+    ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the overlapped schedules (the chain workgroups need free CUs)")
+    ap.add_argument("--no-mirror", action="store_true", help="dependent schedule: read results through the stream (D2H copy + sync) instead of the pinned mirror")
+    ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
+    ap.add_argument("--phase-events", type=int, default=25, help="one-at-a-time schedule: per-phase events on every n-th step (0 = never)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -157,185 +174,242 @@ def main():
     lib = _lib.get_lib()
 
     N, M = args.points, args.features
-    theta = (1.0, 0.05, 0.01)
+    K_steps, R = args.steps, max(1, args.repeats)
+    theta0 = (1.0, 0.05, 0.01)
     x, y = synth(N)
     if args.sorted:
         o = np.argsort(x)
         x, y = x[o], y[o]
     lo, hi = shard_bounds(N, world, rank)
+    n_local = hi - lo
     xd = torch.from_numpy(x[lo:hi].copy()).cuda().reshape(-1, 1)
     yd = torch.from_numpy(y[lo:hi].copy()).cuda().reshape(-1, 1)
     basis = A.B4Spline(0, 1, M)
     Kern = {12: A.Matern12, 32: A.Matern32, 52: A.Matern52}[args.matern]
-    model = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
-    model.likelihood.variance.assign(theta[2])
-    model.num_data = N
-    stats = model._stats
-    hdl = model._h
-    two_stream = (args.band_algo == 2)   # the all-GPU chains of round 1: prior chain on a second stream under the Phi pass
-    if args.band_algo:
-        hdl.set_band_algorithm(args.band_algo)
-    if two_stream:
-        hdl.chain_sync(1)               # prior chain / data chain ordered by the handle's own events
-        hdl.set_phi_workgroups(248)     # 31 of 32 CUs per XCD, so the concurrently running prior chain finds a free CU
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)   # (timing events cost ~25 us of stream time each here: sampled)
-    marks = []
-    main = torch.cuda.current_stream()
-    side = torch.cuda.Stream(priority=-1)   # the theta-only prior chain runs here, concurrently with the Phi pass;
-                                            # high priority so that it is dispatched (one CU) ahead of the Phi grid
-    prior_done = torch.cuda.Event()
+    def new_model(n_total, overlapped, defer=True):
+        mm = A.GPR_1d((xd, yd), Kern(variance=theta0[0], lengthscales=theta0[1]), basis)
+        mm.likelihood.variance.assign(theta0[2])
+        mm.num_data = n_total
+        if args.band_algo:
+            mm._h.set_band_algorithm(args.band_algo)
+        if args.phi_algo:
+            mm._h.set_phi_algorithm(args.phi_algo)
+        if overlapped:
+            mm._h.set_phi_workgroups(args.phi_workgroups)
+            if defer:
+                mm._h.set_phi_deferred_reduce(1)     # the N-side stream carries the streaming kernel only; the reduce rides with the M-side
+        return mm
 
-    def step(record=False):
-        if record:
-            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
-            e0.record()
-        if two_stream:
-            side.wait_stream(main)      # previous step's finalize has consumed the prior-chain buffers
-            with torch.cuda.stream(side):
-                model.launch_prior_chain()
-        model.phi_pass()
-        if record:
-            e1.record()
-        if world > 1:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        if record:
-            e2.record()
-        if two_stream:
-            model.launch_data_chain()   # waits (inside the library) for Kuu, then for the prior chain before the finalize
-        else:
-            model._launch_elbo()        # planned prior chain: host forward pass (long double) while the Phi pass is in flight,
-                                        # then ONE launch for the P chain and the Kuu backward pass, then the finalize
-        if record:
-            e3.record()
-            marks.append((e0, e1, e2, e3))
+    def set_theta(mm, th):
+        mm.kernel.variance.assign(th[0])
+        mm.kernel.lengthscales.assign(th[1])
+        mm.likelihood.variance.assign(th[2])
 
-    def measure(step_fn, h):
-        """W untimed + exactly K timed steps between barrier + synchronize pairs; HIP events around every n-th Phi launch of handle h."""
-        for _ in range(args.warmup):
-            step_fn()
-        if getattr(step_fn, "flush", None):
-            step_fn.flush()
+    def timed_blocks(block_fn, h, settle=None):
+        """args.warmup untimed steps, then R blocks of EXACTLY K steps, each between barrier + synchronize pairs; max over ranks per block.
+        HIP events around every n-th Phi launch of handle h inside the timed blocks."""
+        block_fn(args.warmup)
+        if settle:
+            settle()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        if not os.environ.get("ASVGP_BENCH_NOPROF"):
-            lib.asvgp_profile_enable(h.ptr, args.kernel_events)
-        t0 = time.perf_counter()
-        for it in range(args.steps):
-            step_fn(record=(args.phase_events > 0 and it % args.phase_events == 0))
-            if args.sync_each_step:
-                torch.cuda.synchronize()
-        if getattr(step_fn, "flush", None):
-            step_fn.flush()
-        t_enqueue = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if os.environ.get("ASVGP_BENCH_VERBOSE"):
-            print("host enqueue %.1f us/step, total %.1f us/step" % (t_enqueue / args.steps * 1e6, dt / args.steps * 1e6), file=sys.stderr)
+        lib.asvgp_profile_enable(h.ptr, args.kernel_events)
+        ms = []
+        for _ in range(R):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            block_fn(K_steps)
+            if settle:
+                settle()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = t.item()
+            ms.append(dt / K_steps * 1e3)
         ms_sum, launches = ctypes.c_double(0), ctypes.c_int64(0)
         lib.asvgp_profile_read(h.ptr, ctypes.byref(ms_sum), ctypes.byref(launches))
         lib.asvgp_profile_enable(h.ptr, 0)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt, ms_sum.value / max(launches.value, 1) * 1e3, launches.value
+        return ms, ms_sum.value / max(launches.value, 1) * 1e3, int(launches.value)
 
-    # ---- schedule A: one step at a time on one stream (the latency of an ELBO + gradient evaluation from raw data)
-    dt, kern_us, n_launches = measure(step, hdl)
+    # ---- stream ceiling (SURVEY 8d): a read-only pass over the same x, y with the Phi pass's launch shape, HIP events per launch
+    sink = torch.zeros(8, dtype=torch.float64, device="cuda")
+    st_main = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    probe_us = []
+    for i in range(23):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.asvgp_stream_probe(xd.data_ptr(), yd.data_ptr(), n_local, sink.data_ptr(), st_main), "stream_probe")
+        e1.record()
+        e1.synchronize()
+        if i >= 3:
+            probe_us.append(e0.elapsed_time(e1) * 1e3)
+    ceiling_us = float(np.median(probe_us))
+    ceiling_gbs = BYTES_PER_POINT * n_local / (ceiling_us * 1e-6) / 1e9
+
+    # ---- schedule A: one step at a time on one stream, theta fixed (the host enqueues ahead): device-side latency of a full step
+    model = new_model(N, overlapped=False)
+    stats = model._stats
+    marks = []
+    n_marks = (args.warmup + K_steps * R) // max(args.phase_events, 1) + 2 if args.phase_events > 0 else 0
+    ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(4 * n_marks)]   # (made before the timed region; sampled: a record costs stream time)
+    ev = ev_pool.pop
+    count = [0]
+
+    def serial_block(k):
+        for _ in range(k):
+            rec = args.phase_events > 0 and count[0] % args.phase_events == 0 and len(ev_pool) >= 4
+            count[0] += 1
+            if rec:
+                e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+                e0.record()
+            model.phi_pass(allreduce=False)
+            if rec:
+                e1.record()
+            if world > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            if rec:
+                e2.record()
+            model._launch_elbo()
+            if rec:
+                e3.record()
+                marks.append((e0, e1, e2, e3))
+
+    ser_ms, kern_us, n_launches = timed_blocks(serial_block, model._h)
     model._check_pd()
-    if marks:
-        t_phi = np.mean([a.elapsed_time(b) for a, b, _, _ in marks]) * 1e3
-        t_comm = np.mean([b.elapsed_time(c) for _, b, c, _ in marks]) * 1e3
-        t_band = np.mean([c.elapsed_time(d) for _, _, c, d in marks]) * 1e3
-    else:
-        t_phi = t_comm = t_band = 0.0
+    phi_algo_ran = model._h.phi_last_algorithm()
+    t_phi = float(np.mean([a.elapsed_time(b) for a, b, _, _ in marks]) * 1e3) if marks else 0.0
+    t_comm = float(np.mean([b.elapsed_time(c) for _, b, c, _ in marks]) * 1e3) if marks else 0.0
+    t_band = float(np.mean([c.elapsed_time(d) for _, _, c, d in marks]) * 1e3) if marks else 0.0
     out4 = model._out.cpu().numpy()
+    stats_host = stats.cpu().numpy()
 
-    # ---- schedule B (default, --in-flight L >= 2): L steps in flight.  The Phi pass needs no theta, so in a training loop over
-    # successive batches the N-side work of step i+1 (Phi pass, reduce, all-reduce: one stream) runs under the M-side work of the
-    # steps before it (the ELBO launch - two chain workgroups + six helpers, one CU per XCD - on --chain-streams streams in turn).
-    # Every step is still a complete ELBO + gradient evaluation from the raw points into its own statistics / workspace / output
-    # buffers (L models over the same x, y); the only GPU-side cross-stream dependency is "statistics of step i complete" (one
-    # event); a lane is reused once the host has seen its previous step finish.  The Phi grid leaves CUs free for the chain
-    # workgroups (--phi-workgroups: a Phi workgroup fills the register file and the LDS of its CU).
-    pipe, pipe_error = None, None
-    if args.in_flight >= 2 and not two_stream:
+    # ---- schedule C (`value`): dependent steps.  Two sets of buffers (lanes) alternate.  Per step, in host order:
+    #   ELBO + gradient launch of step i with theta_i on the M stream (behind the statistics event of lane i; the launch goes out before
+    #   the host's long-double forward pass of the prior chain, which the Kuu workgroup waits for) -> Phi pass, cross-workgroup reduce and
+    #   [all-reduce] of step i+1 on the N stream into the OTHER lane (they need no theta) -> the host polls the pinned result mirror of
+    #   step i -> theta_{i+1} = theta_0 (1 + 1e-6 delta(result_i)).  Nothing of step i+1 that needs theta can start earlier.
+    dep, dep_error = None, None
+    try:
+        lanes = [new_model(N, overlapped=True, defer=False) for _ in range(2)]
+        s_n = torch.cuda.Stream()
+        s_m = torch.cuda.Stream(priority=-1)
+        ev_stats = [torch.cuda.Event(), torch.cuda.Event()]
+        state = {"i": 0, "theta": theta0, "primed": False, "last": None, "t_m": 0.0, "t_n": 0.0, "t_poll": 0.0, "n": 0}
+
+        def phi_into(lane_idx):
+            # N stream: Phi pass, cross-workgroup reduce, [all-reduce] - none of it needs theta
+            if world > 1:
+                with torch.cuda.stream(s_n):
+                    lanes[lane_idx].phi_pass(allreduce=False)
+                    dist.all_reduce(lanes[lane_idx]._stats, op=dist.ReduceOp.SUM)
+            else:
+                _lib.set_stream(s_n)
+                lanes[lane_idx].phi_pass(allreduce=False)
+            ev_stats[lane_idx].record(s_n)
+
+        def dependent_block(k):
+            if not state["primed"]:
+                phi_into(state["i"] % 2)
+                state["primed"] = True
+            for _ in range(k):
+                i = state["i"]
+                ln = lanes[i % 2]
+                t0 = time.perf_counter()
+                set_theta(ln, state["theta"])
+                if not ev_stats[i % 2].query():                     # (normally long finished: the host has seen it, no stream-side wait needed)
+                    s_m.wait_event(ev_stats[i % 2])
+                _lib.set_stream(s_m)
+                if args.no_mirror:
+                    ln._launch_elbo()
+                    tok = None
+                else:
+                    tok = ln.launch_elbo_host()
+                t1 = time.perf_counter()
+                phi_into((i + 1) % 2)
+                t2 = time.perf_counter()
+                if tok is None:
+                    with torch.cuda.stream(s_m):
+                        ln._check_pd(ln._launch_elbo)
+                        r = ln._out[:4].tolist()
+                else:
+                    r = ln.read_elbo_host(tok)
+                t3 = time.perf_counter()
+                d = (r[0] * 1e3) % 1.0 - 0.5                       # any function of the host-read result; 1e-6 relative keeps the workload
+                state["theta"] = tuple(t * (1.0 + 1e-6 * d) for t in theta0)
+                state["last"] = r
+                state["i"] = i + 1
+                if k == K_steps:                                    # (timed blocks only: the warm-up carries one-time allocations)
+                    state["t_m"] += t1 - t0; state["t_n"] += t2 - t1; state["t_poll"] += t3 - t2; state["n"] += 1
+            _lib.set_stream(None)
+
+        dep_ms, dep_kern_us, dep_launches = timed_blocks(dependent_block, lanes[0]._h)
+        n_acc = max(state["n"], 1)
+        dep = {"ms": dep_ms, "kern_us": dep_kern_us, "launches": dep_launches, "last": state["last"],
+               "fallbacks": sum(getattr(ln, "fused_launch_fallbacks", 0) for ln in lanes),
+               "host_us": {"theta_and_elbo_launch_incl_forward_pass": state["t_m"] / n_acc * 1e6, "phi_enqueue": state["t_n"] / n_acc * 1e6,
+                           "wait_for_result": state["t_poll"] / n_acc * 1e6}}
+        torch.cuda.synchronize()
+        del lanes
+    except Exception as exc:   # the contract line must come out: fall back to the one-at-a-time figures and say why
+        dep, dep_error = None, repr(exc)[:300]
         try:
-            lanes = []
-            for _ in range(args.in_flight):
-                mm = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
-                mm.likelihood.variance.assign(theta[2])
-                mm.num_data = N
-                if args.band_algo:
-                    mm._h.set_band_algorithm(args.band_algo)
-                mm._h.set_phi_workgroups(args.phi_workgroups)
-                mm._h.set_phi_deferred_reduce(1)     # the N-side stream carries the streaming kernels only
-                lanes.append([mm, torch.cuda.Event(), torch.cuda.Event(), False, 0])
-            s_phis = [torch.cuda.Stream() for _ in range(max(1, args.phi_streams))]
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    # ---- schedule B (extra): L steps with the SAME theta in flight - a throughput of independent evaluations.  N-side stream: Phi pass of
+    # step i+1; M-side streams in turn: reduce, [all-reduce], ELBO launch of steps i, i-1.  Every step is a complete evaluation from the raw
+    # points into its own buffers; a lane is reused once the host has seen its previous step finish.
+    ind, ind_error = None, None
+    if args.in_flight >= 2:
+        try:
+            lanes = [[new_model(N, overlapped=True), torch.cuda.Event(), torch.cuda.Event(), False] for _ in range(args.in_flight)]
+            s_phi = torch.cuda.Stream()
             s_chains = [torch.cuda.Stream(priority=-1) for _ in range(max(1, args.chain_streams))]
             turn = [0]
 
-            pending = []
-            group = max(1, args.event_group)
-
-            def flush():
-                """One event for the Phi passes enqueued since the last one (an event record costs ~7 us of N-side stream time),
-                then the M-side work of those steps."""
-                if not pending:
-                    return
-                ev = pending[-1][1]
-                ev.record(s_phis[pending[-1][0][4] % len(s_phis)])
-                for lane, _ in pending:
-                    mm, ev_done = lane[0], lane[2]
-                    s_chain = s_chains[lane[4] % len(s_chains)]
-                    with torch.cuda.stream(s_chain):
-                        s_chain.wait_event(ev)
-                        mm.phi_reduce()                  # cross-workgroup reduce, then the one exchange step, then the band algebra
+            def independent_block(k):
+                for _ in range(k):
+                    j = turn[0]
+                    turn[0] += 1
+                    mm, ev_s, ev_done, used = lanes[j % len(lanes)]
+                    if used:
+                        ev_done.synchronize()            # host-side: the chains of step j-L have consumed this lane's buffers
+                    with torch.cuda.stream(s_phi):
+                        mm.phi_pass(allreduce=False)
+                        ev_s.record(s_phi)
+                    sc = s_chains[j % len(s_chains)]
+                    with torch.cuda.stream(sc):
+                        sc.wait_event(ev_s)
+                        mm.phi_reduce()
                         if world > 1:
                             dist.all_reduce(mm._stats, op=dist.ReduceOp.SUM)
                         mm._launch_elbo()
-                        ev_done.record(s_chain)
-                    lane[3] = True
-                pending.clear()
+                        ev_done.record(sc)
+                    lanes[j % len(lanes)][3] = True
 
-            def step_pipelined(record=False):
-                lane = lanes[turn[0] % len(lanes)]
-                mm, ev_stats, ev_done, used = lane[:4]
-                lane[4] = turn[0]
-                turn[0] += 1
-                if used:
-                    ev_done.synchronize()            # host-side: the chains of step i-L have consumed this lane's buffers
-                with torch.cuda.stream(s_phis[lane[4] % len(s_phis)]):
-                    mm.phi_pass(allreduce=False)         # (reduce deferred: the partial statistics of all workgroups)
-                pending.append((lane, ev_stats))
-                if len(pending) >= group:
-                    flush()
-
-            step_pipelined.flush = flush
-
-            dt_p, kern_us_p, n_launches_p = measure(step_pipelined, lanes[0][0]._h)
+            ind_ms, _, _ = timed_blocks(independent_block, lanes[0][0]._h)
             outs = [ln[0]._out.cpu().numpy() for ln in lanes]
             for ln in lanes:
                 ln[0]._check_pd()
-            pipe = {"dt": dt_p, "kern_us": kern_us_p, "launches": n_launches_p,
-                    "max_rel_diff_vs_serial": float(max(np.max(np.abs(o[:4] - out4[:4]) / np.abs(out4[:4])) for o in outs))}
+            ind = {"ms": ind_ms, "max_rel_diff_vs_serial": float(max(np.max(np.abs(o[:4] - out4[:4]) / np.abs(out4[:4])) for o in outs))}
             del lanes
-
-        except Exception as exc:   # the contract line must come out: fall back to the one-at-a-time figures and say why
-            pipe, pipe_error = None, repr(exc)[:300]
+        except Exception as exc:
+            ind, ind_error = None, repr(exc)[:300]
             try:
                 torch.cuda.synchronize()
             except Exception:
                 pass
 
-    # Extra, N > 1 only: the same step with the BASELINE N on EVERY rank (weak scaling).  `value` above stays the strong-scaling
-    # figure the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
+    # Extra, N > 1 only: the one-at-a-time step with the BASELINE N on EVERY rank (weak scaling).  `value` stays the strong-scaling figure
+    # the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
     weak = None
     if world > 1 and not os.environ.get("ASVGP_BENCH_NOWEAK"):
         try:
@@ -343,63 +417,40 @@ def main():
             del model
             xd = torch.from_numpy(xw).cuda().reshape(-1, 1)
             yd = torch.from_numpy(yw).cuda().reshape(-1, 1)
-            model = A.GPR_1d((xd, yd), Kern(variance=theta[0], lengthscales=theta[1]), basis)
-            model.likelihood.variance.assign(theta[2])
-            model.num_data = N * world
+            model = new_model(N * world, overlapped=False)
             stats = model._stats
-            if args.band_algo:
-                model._h.set_band_algorithm(args.band_algo)
-            if two_stream:
-                model._h.chain_sync(1)
-                model._h.set_phi_workgroups(248)
-            marks.clear()
-            for _ in range(args.warmup):
-                step()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            tw0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            tw = torch.tensor([time.perf_counter() - tw0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            weak = {"value": N * world / (tw.item() / args.steps) / 1e6, "unit": "Mpoints/s", "points_per_rank": N,
-                    "ms_per_step": tw.item() / args.steps * 1e3, "scaling": "weak"}
+            count[0] = 1                                  # (no phase events)
+            pe, args.phase_events = args.phase_events, 0
+            wk_ms, _, _ = timed_blocks(serial_block, model._h)
+            args.phase_events = pe
+            wk = spread(wk_ms)
+            weak = {"value": N * world / (wk["median"] * 1e-3) / 1e6, "unit": "Mpoints/s", "points_per_rank": N,
+                    "ms_per_step": wk, "scaling": "weak", "schedule": "one step at a time"}
         except Exception as exc:   # never let the extra measurement break the contract line
             weak = {"error": repr(exc)[:200]}
 
     if rank == 0:
-        n_local = hi - lo
-        ser_ms = dt / args.steps * 1e3
-        serial = {"ms_per_step": ser_ms, "value": N / (dt / args.steps) / 1e6, "unit": "Mpoints/s", "phi_kernel_us": kern_us,
-                  "roofline_frac": (BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else 0.0,
-                  "schedule": "one step at a time on one stream: Phi pass -> reduce -> [all-reduce] -> band chains + finalize (one launch)"}
-        if pipe is not None and pipe["dt"] >= dt:      # (e.g. M = 4096: both kernels want the whole LDS of every CU - nothing to overlap)
-            pipe_error = (pipe_error or "") + "in-flight schedule measured slower than one step at a time (%.1f vs %.1f us per step): not used" % (
-                pipe["dt"] / args.steps * 1e6, dt / args.steps * 1e6)
-            pipe = None
-        if pipe is not None:      # the headline schedule; the one-at-a-time figures ride along as `one_step_at_a_time`
-            dt_v, kern_v, launches_v = pipe["dt"], pipe["kern_us"], pipe["launches"]
-            schedule = ("%d steps in flight: one N-side stream (Phi pass, reduce, all-reduce of step i+1) under %d M-side stream(s) (band chains + "
-                        "finalize of steps i, i-1); every step is a complete evaluation from the raw points into its own buffers; Phi grid %d workgroups"
-                        % (args.in_flight, max(1, args.chain_streams), args.phi_workgroups))
+        ser = spread(ser_ms)
+        mp = lambda ms: N / (ms * 1e-3) / 1e6
+        serial = {"ms_per_step": ser, "value": mp(ser["median"]), "unit": "Mpoints/s", "phi_kernel_us": kern_us,
+                  "schedule": "one stream, theta fixed, the host enqueues ahead: Phi pass -> reduce -> [all-reduce] -> band chains + bound (one launch)"}
+        if dep is not None:
+            dsp = spread(dep["ms"])
+            schedule = ("dependent steps: theta_{i+1} computed on the host from the host-read result of step i (pinned result mirror%s); "
+                        "ELBO + gradient launch of step i on one stream, the theta-free part of step i+1 (Phi pass, reduce, [all-reduce]) on a "
+                        "second stream under it; two buffer sets alternate; Phi grid %d workgroups"
+                        % (" off: D2H copy + synchronise" if args.no_mirror else "", args.phi_workgroups))
         else:
-            dt_v, kern_v, launches_v = dt, kern_us, n_launches
-            schedule = serial["schedule"]
-        ms_per_step = dt_v / args.steps * 1e3
-        # roofline: the Phi kernel's own duration.  HIP events around a launch measure that only when the kernel has the device to
-        # itself (one-at-a-time pass: agrees with rocprofv3's kernel trace); in the in-flight pass the same events also contain the
-        # time the launch waits for CUs behind the other streams' kernels, so that figure is reported beside it, not instead of it
+            dsp = ser
+            schedule = serial["schedule"] + " (dependent schedule failed: see dependent_schedule_error)"
         achieved = BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        traffic, traffic_src = measured_traffic(n_local, phi_algo_ran)
         line = {
             "metric": "Mpoints/s per ELBO+grad step, N=10M 1D Matern-3/2 M=2048",
-            "value": N / (dt_v / args.steps) / 1e6,
+            "value": mp(dsp["median"]),
             "unit": "Mpoints/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": K_steps, "warmup": args.warmup,
+            "ms_per_step": dsp["median"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -409,35 +460,43 @@ def main():
                                    % (N, "sorted" if args.sorted else "unsorted", args.matern // 10, M),
                        "parallelism": "dp%d (contiguous N-shards, one all-reduce of the %d-double band buffer)" % (world, stats.numel()),
                        "points_per_rank": n_local, "schedule": schedule},
+            "repeats": {"R": R, "steps_per_block": K_steps, "ms_per_step": dsp, "value_min": mp(dsp["max"]), "value_max": mp(dsp["min"]),
+                        "note": "the --steps block timed R times in this process between barrier + synchronize pairs; value / ms_per_step = the median block"},
             "one_step_at_a_time": serial,
-            "phases_us": {"phi_pass": t_phi, "band_allreduce": t_comm, "data_chain_after_stats": t_band,
-                          "note": "measured in the one-step-at-a-time schedule; planned prior chain: host forward pass under the Phi pass, "
-                                  "P chain + Kuu backward pass + finalize in ONE launch"
-                                  if not two_stream else "the theta-only prior chain (Kuu, tangent) runs on a second stream under the Phi pass"},
-            "phi_pass_mpoints_per_s": n_local * world / (t_phi * 1e-6) / 1e6 if t_phi > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "phi_moment_kernel<4, 2048, true> (Phi pass, algorithm 5)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
-                         "traffic_source": "profiles/r02_phi_traffic.json (rocprofv3 PMC passes of the same kernel and workload; not re-measured in this run)",
-                         "kernel_us": kern_us, "launches": n_launches,
-                         "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local,
-                         "in_flight_event_us": (kern_v if pipe is not None else None),
-                         "note": "HIP events around every %d-th launch inside the timed one-step-at-a-time pass (the kernel alone on the device: its own "
-                                 "duration, as in profiles/r02_kernel_stats.csv); in_flight_event_us = the same events in the in-flight pass, where "
-                                 "they include the launch's wait for CUs (rocprofv3 there: profiles/r02_phi_kernel_by_schedule.json)" % args.kernel_events},
+            "phases_us": {"phi_pass_and_reduce": t_phi, "band_allreduce": t_comm, "elbo_and_gradient_launch": t_band,
+                          "note": "events in the one-step-at-a-time schedule (sampled every %d-th step)" % args.phase_events},
+            "roofline": {"bound": "hbm", "kernel": PHI_KERNEL_NAMES.get(phi_algo_ran, "Phi pass, algorithm %d" % phi_algo_ran), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "stream_ceiling": {"achieved": ceiling_gbs, "unit": "GB/s", "us": ceiling_us, "frac_of_peak": ceiling_gbs / HBM_PEAK_GBS,
+                                            "kernel": "stream_probe_kernel: read-only 16 B/point over the same x, y, 256 x 1024 threads, non-temporal "
+                                                      "16-byte loads (asvgp_stream_probe), median of 20 launches in this run"},
+                         "frac_of_stream_ceiling": (achieved / ceiling_gbs) if ceiling_gbs > 0 else None,
+                         "kernel_us": kern_us, "launches": n_launches, "algorithmic_bytes_per_launch": BYTES_PER_POINT * n_local,
+                         "kernel_us_in_dependent_schedule": (dep["kern_us"] if dep else None),
+                         "note": "HIP events around every %d-th launch inside the timed one-step-at-a-time blocks (the kernel alone on the device: its own "
+                                 "duration, as in rocprofv3's kernel trace); in the dependent schedule the same events also contain the launch's wait "
+                                 "for CUs next to the chain workgroups" % args.kernel_events},
             "elbo": float(out4[0]), "grad": [float(v) for v in out4[1:4]],
         }
-        if pipe is not None:
-            line["pipelined_max_rel_diff_vs_one_at_a_time"] = pipe["max_rel_diff_vs_serial"]
-        if pipe_error is not None:
-            line["in_flight_schedule_error"] = pipe_error
+        if dep is not None:
+            line["dependent_schedule"] = {"host_us_per_step": dep["host_us"], "fused_launch_fallbacks": dep["fallbacks"],
+                                          "last_result": dep["last"], "rel_diff_elbo_vs_fixed_theta": abs(dep["last"][0] - out4[0]) / abs(out4[0])}
+        if dep_error is not None:
+            line["dependent_schedule_error"] = dep_error
+        if ind is not None:
+            isp = spread(ind["ms"])
+            line["independent_evaluations"] = {"value": mp(isp["median"]), "unit": "Mpoints/s", "ms_per_step": isp, "in_flight": args.in_flight,
+                                               "max_rel_diff_vs_one_at_a_time": ind["max_rel_diff_vs_serial"],
+                                               "note": "same theta in every step: a throughput of independent evaluations, not an optimiser's step rate"}
+        if ind_error is not None:
+            line["independent_evaluations_error"] = ind_error
         if weak is not None:
             line["weak_scaling_extra"] = weak
         if not args.no_cpu_baseline and world == 1:
             ns = min(args.cpu_sample, N)
             full = (ns == N)
             okind = {12: 0, 32: 1, 52: 2}[args.matern]
-            line["cpu_baseline"], parity = cpu_baseline(x[:ns], y[:ns], M, theta, okind,
-                                                        stats.cpu().numpy() if full else None, out4 if full else None)
+            line["cpu_baseline"], parity = cpu_baseline(x[:ns], y[:ns], M, theta0, okind, stats_host if full else None, out4 if full else None)
             if parity is not None:
                 line["parity"] = parity
         print(json.dumps(line), flush=True)

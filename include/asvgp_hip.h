@@ -81,6 +81,18 @@ int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double
  *       numpy.linspace.  Sums follow arrival order: reproducible to rounding, not bit for bit (5 and 3 are).
  * Same statistics to <= 1e-12 of the band's largest entry. */
 int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
+/* The library reads its debug / measurement switches (ASVGP_SPIN_LIMIT, ASVGP_DEBUG_NO_ASSEMBLY, ASVGP_CHAIN_STAMPS, ASVGP_BCR_STAMPS,
+ * ASVGP_HOST_TIMES, ASVGP_PLAN_FIRST) from the environment once; call this after changing them in a running process. */
+int asvgp_debug_reload_env(void);
+/* Result mirror: 16 pinned host doubles owned by the handle.  While enabled, the fused ELBO + gradient launch (band algorithm 0 / 4 where
+ * the matrix-core chains apply) also writes [out[0..7], info[0], info[1], sequence, sum of the first ten] there, the sequence number
+ * last (after the other stores have been acknowledged; check the sum after seeing it), so a host that has to read every result - an optimiser: the next theta depends on it, the reference's example.py:31-32 -
+ * polls 8 bytes of its own memory instead of paying a device-to-host copy and a stream synchronisation per step.
+ * asvgp_result_mirror_pending: the sequence number the mirror will show when the handle's LAST ELBO launch has finished, or 0 when
+ * that launch does not write the mirror (other algorithms, D > 1, ...): then read `out` / `info` as usual.  A launch that gave up
+ * waiting (info[1] < 0, see asvgp_set_band_algorithm) never writes it: bound the poll and fall back to the stream. */
+int asvgp_result_mirror(asvgp_handle_t handle, int enable, const double** host_ptr);
+uint64_t asvgp_result_mirror_pending(asvgp_handle_t handle);
 /* the algorithm the handle's last asvgp_phi_accumulate_1d call actually ran (1, 3, 5 or 6; 0 before the first call) */
 int asvgp_phi_last_algorithm(asvgp_handle_t handle);
 /* Measurement aid: a read-only pass over x and y (16 B/point) with the Phi pass's launch shape - the stream ceiling the

@@ -38,6 +38,11 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a)).cuda()
 
 
+def _reload_env():
+    from asvgp_amd import _lib
+    _lib.get_lib().asvgp_debug_reload_env()       # the library reads its debug switches once; tests that flip them say so
+
+
 def _spec(F, tag):
     order, a, b, m, isf = F[tag + "/spec"]
     order, m = int(order), int(m)
@@ -1492,6 +1497,7 @@ def test_fused_launch_that_gives_up_waiting_falls_back_to_the_multi_launch_path(
     good = model.elbo_and_grad().cpu().numpy()
     os.environ["ASVGP_DEBUG_NO_ASSEMBLY"] = "1"
     os.environ["ASVGP_SPIN_LIMIT"] = "20000"
+    _reload_env()
     try:
         model._launch_elbo()
         torch.cuda.synchronize()
@@ -1499,6 +1505,7 @@ def test_fused_launch_that_gives_up_waiting_falls_back_to_the_multi_launch_path(
         got = model.elbo_and_grad().cpu().numpy()               # aborts again, falls back inside the call
     finally:
         del os.environ["ASVGP_DEBUG_NO_ASSEMBLY"], os.environ["ASVGP_SPIN_LIMIT"]
+        _reload_env()
     assert getattr(model, "fused_launch_fallbacks", 0) >= 1
     ob = O.Basis(4, 0, 1, M)
     Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
@@ -1507,3 +1514,60 @@ def test_fused_launch_that_gives_up_waiting_falls_back_to_the_multi_launch_path(
     np.testing.assert_allclose(got[1:4], og, rtol=1e-6)
     again = model.elbo_and_grad().cpu().numpy()                 # the fused path, re-armed
     np.testing.assert_allclose(again, good, rtol=1e-9)
+
+
+def test_host_result_mirror_gives_the_stream_path_numbers(A):
+    """asvgp_result_mirror (include/asvgp_hip.h): the fused launch writes [out, info, sequence] into pinned host memory and the host polls
+    the sequence word; the numbers are the ones the stream path returns, a launch that cannot write the mirror (band algorithm 1)
+    reports token 0 and is read through the stream, and an aborted launch (no mirror write) ends in the same fallback as before."""
+    rng = np.random.default_rng(5)
+    N, M = 30000, 1024
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    dev = model.elbo_and_grad().tolist()
+    for rep in range(3):                                            # sequence numbers advance; every read is this launch's
+        tok = model.launch_elbo_host()
+        assert tok == rep + 1
+        host = model.read_elbo_host(tok)
+        assert host == dev
+    model.kernel.lengthscales.assign(0.07)
+    host2 = model.elbo_and_grad_host()
+    dev2 = model.elbo_and_grad().tolist()
+    assert host2 == dev2 and host2 != dev
+    model._h.set_band_algorithm(1)
+    try:
+        tok = model.launch_elbo_host()
+        assert tok == 0
+        np.testing.assert_allclose(model.read_elbo_host(tok), dev2, rtol=1e-7)
+    finally:
+        model._h.set_band_algorithm(0)
+    os.environ["ASVGP_DEBUG_NO_ASSEMBLY"] = "1"
+    os.environ["ASVGP_SPIN_LIMIT"] = "20000"
+    _reload_env()
+    try:
+        got = model.read_elbo_host(model.launch_elbo_host(), poll_seconds=0.02)
+    finally:
+        del os.environ["ASVGP_DEBUG_NO_ASSEMBLY"], os.environ["ASVGP_SPIN_LIMIT"]
+        _reload_env()
+    assert getattr(model, "fused_launch_fallbacks", 0) >= 1
+    np.testing.assert_allclose(got, dev2, rtol=1e-7)
+    assert model.elbo_and_grad_host() == dev2                       # re-armed
+
+
+def test_non_positive_definite_data_chain_is_reported_through_the_mirror_path(A):
+    """A band buffer that makes P = Kuu + KufKfu / sigma2 indefinite must raise from the host-read path exactly as from elbo_and_grad()."""
+    from asvgp_amd import banded
+    rng = np.random.default_rng(6)
+    N, M = 5000, 512
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = np.sin(20 * x).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    assert np.isfinite(model.elbo_and_grad_host()).all()
+    model._stats[100] = -1.0e9                                      # diagonal entry 100 of the KufKfu band
+    for fn in (model.elbo_and_grad, model.elbo_and_grad_host):
+        with pytest.raises(banded.NotPositiveDefiniteError) as ei:
+            fn()
+        assert "P = Kuu" in str(ei.value)

@@ -4,6 +4,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import asvgp_amd as A
+from asvgp_amd import _lib
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 N = 1_000_000
 rng = np.random.default_rng(1234)
@@ -25,10 +26,12 @@ for algo in (0, 2):
     print("band algorithm %d: ELBO + gradient launch %.1f us per call (host enqueue %.1f us)  -> %s" % (algo, us, enq, model._out[:4].tolist()))
 A.set_band_algorithm(0)
 os.environ["ASVGP_CHAIN_STAMPS"] = "1"
+_lib.get_lib().asvgp_debug_reload_env()
 for _ in range(3):
     model._launch_elbo()
 torch.cuda.synchronize()
 del os.environ["ASVGP_CHAIN_STAMPS"]
+_lib.get_lib().asvgp_debug_reload_env()
 k, D = 4, 1
 ws = model._elbo_ws.cpu().numpy()
 off = 9 * (k + 1) * M + 2 * M * D
