@@ -102,6 +102,8 @@ bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hip
 
 using namespace asvgp;
 
+extern "C" int asvgp_host_mantissa_bits(void) { return prior_plan_mantissa_bits(); }
+
 extern "C" int asvgp_debug_reload_env(void) {
   asvgp::debug_env_load();
   return ASVGP_OK;

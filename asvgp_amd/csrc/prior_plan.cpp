@@ -17,6 +17,7 @@
 // MAX_CLASSES classes on some level) has no plan and the library falls back to the all-GPU chain.
 #include "prior_plan.hpp"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -33,6 +34,9 @@ constexpr int MAXB = 6;            // ASVGP_MAX_ORDER
 constexpr int MAX_CLASSES = 24;    // per level
 
 typedef long double ld;
+// The forward pass owes its accuracy (|bound - exact| ~ 3e-11 |bound| at the headline configuration, cond(Kuu) = 3.5e7) to the 64-bit
+// mantissa of the x87 extended format.  A toolchain where long double is plain fp64 (or a software quad) must not build this silently.
+static_assert(LDBL_MANT_DIG == 64, "prior_plan.cpp needs the 80-bit x87 long double (64-bit mantissa)");
 struct Blk { ld v[MAXB][MAXB]; double d[MAXB][MAXB]; };   // value (long double) + tangent d / d lengthscale (double)
 
 struct Level {
@@ -143,6 +147,7 @@ PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, in
 }
 
 void prior_plan_destroy(PriorPlan* p) { delete p; }
+int prior_plan_mantissa_bits() { return LDBL_MANT_DIG; }
 int prior_plan_nrec(const PriorPlan* p) { return p->n_rec; }
 int prior_plan_nb(const PriorPlan* p) { return p->nb; }
 long prior_plan_M(const PriorPlan* p) { return p->M; }

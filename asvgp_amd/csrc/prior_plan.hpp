@@ -27,6 +27,7 @@ ASVGP_HD constexpr int prior_f_GBT(int B) { return 4 * B * B + B; }
 ASVGP_HD constexpr int prior_f_DINV(int B) { return 5 * B * B + B; }
 ASVGP_HD constexpr int prior_rec_fields(int B) { return 6 * B * B + B; }
 
+int prior_plan_mantissa_bits();                               // mantissa width of the host forward pass's arithmetic (64: x87 extended)
 struct PriorPlan;
 PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, int k, char* err, size_t errlen);
 void prior_plan_destroy(PriorPlan* p);

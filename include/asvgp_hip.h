@@ -81,6 +81,8 @@ int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double
  *       numpy.linspace.  Sums follow arrival order: reproducible to rounding, not bit for bit (5 and 3 are).
  * Same statistics to <= 1e-12 of the band's largest entry. */
 int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
+/* Mantissa width of the arithmetic the host forward pass of the planned prior chain runs in: 64 (x87 extended; the build refuses any other). */
+int asvgp_host_mantissa_bits(void);
 /* The library reads its debug / measurement switches (ASVGP_SPIN_LIMIT, ASVGP_DEBUG_NO_ASSEMBLY, ASVGP_CHAIN_STAMPS, ASVGP_BCR_STAMPS,
  * ASVGP_HOST_TIMES, ASVGP_PLAN_FIRST) from the environment once; call this after changing them in a running process. */
 int asvgp_debug_reload_env(void);

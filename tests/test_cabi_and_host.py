@@ -242,6 +242,13 @@ def _bcr_forward_long_double(K, B):
     return fac, L0, logdet
 
 
+def test_host_forward_pass_runs_in_x87_extended_precision(lib):
+    """VERDICT r2 #1d: prior_plan.cpp static_asserts LDBL_MANT_DIG == 64; the library reports the width it was built with, and numpy's
+    longdouble on this host - the oracle's extended evaluation - is the same format."""
+    assert lib.asvgp_host_mantissa_bits() == 64
+    assert np.finfo(np.longdouble).nmant == 63          # (numpy counts the stored fraction bits: 64-bit mantissa with its explicit leading bit)
+
+
 @pytest.mark.parametrize("order,M,kind,l", [(4, 2048, 1, 0.05), (4, 2047, 1, 0.05), (4, 1024, 0, 0.1), (3, 333, 2, 0.03), (5, 129, 2, 0.1),
                                             (6, 90, 1, 0.08), (1, 37, 0, 0.08), (2, 64, 1, 0.08), (4, 13, 0, 0.3)])
 def test_prior_plan_host_forward_vs_long_double_bcr(lib, order, M, kind, l):

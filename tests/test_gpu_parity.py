@@ -1306,8 +1306,8 @@ def test_headline_config_parity_n10m(A):
     """BASELINE.json north star, exactly as bench.py runs it: N = 10M, M = 2048, B4, Matern-3/2, theta = (1, 0.05, 0.01),
     default_rng(1234).  Statistics <= 1e-12 of the largest entry against the oracle's direct accumulation; ELBO and gradient
     against the oracle (fp64, reference elimination order) AND the oracle's long-double evaluation of the same recurrences.
-    Gate for the bound: 1e-9 |ELBO| + 5 x |oracle - long double| - cond(Kuu) = 3.5e7 costs the reference's own
-    fp64 order 0.018 here, and a path that is more than 5x further from the truth than that does not "match"."""
+    Gate for the bound: |GPU - long double| <= 1e-9 |ELBO|, no allowance for the fp64 oracle's own distance from the
+    long-double value (0.018 here, cond(Kuu) = 3.5e7), which is printed as information only."""
     import bench
     N, M = 10_000_000, 2048
     v, l, s = 1.0, 0.05, 0.01
@@ -1324,8 +1324,10 @@ def test_headline_config_parity_n10m(A):
     oe, og, _ = O.elbo_grad_1d(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
     ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
     assert abs(oe - ee) <= 0.05                     # the reference order itself: 0.018 (6e-9 relative)
-    gate = 1e-9 * abs(ee) + 5 * abs(oe - ee)
+    gate = 1e-9 * abs(ee)                           # VERDICT r2 #1b: against the long-double value, no allowance (measured: 3e-11 |ELBO|)
     assert abs(r[0] - ee) <= gate, ("ELBO vs long double", r[0], ee, oe, gate)
+    print("headline: |GPU - long double| = %.3g (%.2g rel), |fp64 oracle - long double| = %.3g (information)" % (
+        abs(r[0] - ee), abs(r[0] - ee) / abs(ee), abs(oe - ee)))
     assert abs(r[0] - oe) <= gate + abs(oe - ee), ("ELBO vs oracle", r[0], oe)
     np.testing.assert_allclose(r[1:4], ge, rtol=1e-6)
     np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
@@ -1356,8 +1358,10 @@ def test_config3_n10m_m4096_matern52_single_gpu(A):
     r = model.elbo_and_grad().cpu().numpy()
     oe, og, _ = O.elbo_grad_1d(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
     ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
-    gate = 1e-9 * abs(ee) + 5 * abs(oe - ee)
+    gate = 1e-9 * abs(ee)                           # VERDICT r2 #1b: against the long-double value, no allowance
     assert abs(r[0] - ee) <= gate, (r[0], ee, oe, gate)
+    print("config 3: |GPU - long double| = %.3g (%.2g rel), |fp64 oracle - long double| = %.3g (information)" % (
+        abs(r[0] - ee), abs(r[0] - ee) / abs(ee), abs(oe - ee)))
     np.testing.assert_allclose(r[1:4], ge, rtol=5e-6)       # (1.6e-6 for every elimination order, the sequential one included: cond 1e9)
 
 
@@ -1571,3 +1575,64 @@ def test_non_positive_definite_data_chain_is_reported_through_the_mirror_path(A)
         with pytest.raises(banded.NotPositiveDefiniteError) as ei:
             fn()
         assert "P = Kuu" in str(ei.value)
+
+
+def test_config2_n1m_m1024_bound_and_gradient_vs_oracle(A):
+    """BASELINE config 2 (1D synthetic N = 1M, Matern-3/2, M = 1024, band k = 4, fp64, one GPU): statistics, bound and gradient
+    against the oracle and its long-double evaluation (VERDICT r2 #1c)."""
+    N, M = 1_000_000, 1024
+    v, l, s = 1.0, 0.05, 0.01
+    rng = np.random.default_rng(2)
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+    model = A.GPR_1d((dev(x).reshape(-1, 1), dev(y).reshape(-1, 1)), A.Matern32(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(s)
+    ob = O.Basis(4, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+    ref = np.concatenate([Ab.reshape(-1), b.reshape(-1), [yy]])
+    assert np.max(np.abs(model._stats.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    r = model.elbo_and_grad().cpu().numpy()
+    oe, og, _ = O.elbo_grad_1d(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
+    ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
+    assert abs(r[0] - ee) <= 1e-9 * abs(ee), (r[0], ee, oe)
+    np.testing.assert_allclose(r[1:4], ge, rtol=1e-6)
+    np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
+    assert model.elbo_and_grad_host() == r[:4].tolist()
+    mean, var = model.predict_f(np.linspace(0.01, 0.99, 500).reshape(-1, 1))
+    assert np.sqrt(np.mean((mean[:, 0] - np.sin(20 * np.linspace(0.01, 0.99, 500))) ** 2)) < 0.02 and (var > 0).all()
+
+
+def test_config5_enatl60_stand_in_at_full_size_on_one_gpu(A):
+    """BASELINE config 5 at its full size on ONE GPU (VERDICT r2 #1a): GPR_kron with B4Spline(-80,-25,100) x B4Spline(15,55,100)
+    (eNATL60.py:84) over N = 14M synthetic sea-surface points.  Size-independent properties: partition of unity, linearity over
+    eight contiguous N-shards (exactly what the 8-GPU all-reduce relies on) to 1e-11, invariance of the bound under a point
+    shuffle; the 200k-point oracle comparison lives in test_kron_full_size_properties_config4_and_config5_shapes."""
+    from asvgp_amd import experiments as E
+    N = 14_000_000
+    Xh, yh = E.synthetic_ssh(N)
+    X, y = dev(Xh), dev(yh)
+    bases = [A.B4Spline(-80, -25, 100), A.B4Spline(15, 55, 100)]
+    kerns = lambda: [A.Matern32(variance=0.1, lengthscales=8.0), A.Matern32(variance=1.0, lengthscales=8.0)]
+    model = A.GPR_kron((X, y), kerns(), bases)
+    model.likelihood.variance.assign(1e-3)
+    assert model.order == 4 and model.Mtot == 10_000 and model.true_bandwidth == 4 * 101
+    blk = model.KufKfu_blockband
+    assert abs((blk[0].sum() + 2 * blk[1:].sum()).item() - N) <= 1e-9 * N
+    assert abs(model.Kuf_y.sum().item() - y.sum().item()) <= 1e-9 * y.abs().sum().item()
+    assert abs(model.tr_yTy.item() - (y * y).sum().item()) <= 1e-12 * (y * y).sum().item()
+    full = model._stats.clone()
+    acc = torch.zeros_like(full)
+    for r in range(8):
+        lo, hi = r * N // 8, (r + 1) * N // 8
+        acc += A.GPR_kron((X[lo:hi], y[lo:hi]), kerns(), bases)._stats
+    assert (acc - full).abs().max().item() <= 1e-11 * full.abs().max().item()
+    e, g = model.elbo_and_grad()
+    assert np.isfinite(e) and np.isfinite(np.asarray(g)).all()
+    perm = torch.randperm(N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    shuffled = A.GPR_kron((X[perm].contiguous(), y[perm].contiguous()), kerns(), bases)
+    shuffled.likelihood.variance.assign(1e-3)
+    assert (shuffled._stats - full).abs().max().item() <= 1e-11 * full.abs().max().item()
+    e2 = shuffled.elbo().item()
+    assert abs(e2 - e) <= 1e-9 * abs(e) + 5e-10 * (0.5 * N * 0.1 / 1e-3), (e, e2)
+    mean, var = model.predict_f(X[:5000])
+    assert E.MSE(y[:5000], mean) < 2e-3 and (var > 0).all()
