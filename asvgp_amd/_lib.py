@@ -156,8 +156,11 @@ class Handle:
     def set_phi_workgroups(self, n):
         check(self._lib.asvgp_set_phi_workgroups(self.ptr, int(n)), "set_phi_workgroups")
 
+    deferred = False
+
     def set_phi_deferred_reduce(self, on):
         check(self._lib.asvgp_set_phi_deferred_reduce(self.ptr, int(on)), "set_phi_deferred_reduce")
+        self.deferred = bool(on)
 
     def chain_sync(self, on):
         check(self._lib.asvgp_elbo_chain_sync(self.ptr, int(on)), "elbo_chain_sync")
@@ -170,14 +173,15 @@ class Handle:
         return bool(ok.value)
 
     def close(self):
+        """asvgp_destroy: waits for the handle's OWN last launch to have consumed its pinned table / written its mirror (no device-wide
+        synchronisation), then frees.  Called by model.close() and, best effort, from __del__."""
         if getattr(self, "ptr", None) is not None and self.ptr:
             try:
-                if torch.cuda.is_available():
-                    torch.cuda.synchronize()
                 self._lib.asvgp_destroy(self.ptr)
             except Exception:
                 pass
             self.ptr = None
+            self._mirror = None
 
     def __del__(self):
         self.close()

@@ -956,6 +956,7 @@ extern "C" int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, co
                         workspace_bytes, info, "elbo_grad_1d");
   if (rc) return rc;
   Handle* h = as_handle(handle);
+  { const int rcf = handle_flush_phi_reduce(h, stats, as_stream(stream)); if (rcf) return rcf; }   // (a deferred Phi reduce into THIS buffer goes first)
   hipStream_t st = as_stream(stream);
 #define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 0);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
@@ -985,6 +986,7 @@ extern "C" int asvgp_elbo_data_chain_1d(asvgp_handle_t handle, const double* sta
                         workspace_bytes, info, "elbo_data_chain_1d");
   if (rc) return rc;
   Handle* h = as_handle(handle);
+  { const int rcf = handle_flush_phi_reduce(h, stats, as_stream(stream)); if (rcf) return rcf; }   // (a deferred Phi reduce into THIS buffer goes first)
   hipStream_t st = as_stream(stream);
 #define ELBO_CASE(KK) case KK: return ElboLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)N, (long)M, (long)D, out, info, workspace, st, 2);
   switch (k) { ELBO_CASE(1) ELBO_CASE(2) ELBO_CASE(3) ELBO_CASE(4) ELBO_CASE(5) ELBO_CASE(6) }
@@ -1018,6 +1020,7 @@ extern "C" int asvgp_posterior_prepare_1d(asvgp_handle_t handle, const double* s
   if (rc) return rc;
   if (!W) { set_error("posterior_prepare_1d: bad argument"); return ASVGP_ERR_BAD_ARG; }
   Handle* h = as_handle(handle);
+  { const int rcf = handle_flush_phi_reduce(h, stats, as_stream(stream)); if (rcf) return rcf; }   // (a deferred Phi reduce into THIS buffer goes first)
   hipStream_t st = as_stream(stream);
 #define POST_CASE(KK) case KK: return PostLauncher<KK>::run(h, stats, static_bands, kind, variance, lengthscale, noise_variance, (long)M, (long)D, alpha, W, info, workspace, st);
   switch (k) { POST_CASE(1) POST_CASE(2) POST_CASE(3) POST_CASE(4) POST_CASE(5) POST_CASE(6) }

@@ -40,7 +40,28 @@ Handle* as_handle(asvgp_handle_t h) {
   return g_default;
 }
 
+// Wait until the GPU has consumed the last factor table handed to it (its kernel stores the table's sequence number into done[slot]
+// once the table sits in LDS) and, when the result mirror is armed, until the last launch has written it: after that nothing in
+// flight reads the pinned ring or writes the mirror.  Bounded; a launch that gave up waiting never reports, so the fallback is a
+// device synchronisation.  This replaces a device-wide synchronisation on every model teardown.
+static void handle_quiesce(Handle* h) {
+  bool need_sync = false;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  auto expired = [&]() { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); return (t1.tv_sec - t0.tv_sec) > 2; };
+  if (h->done_host && h->seq > 0) {
+    volatile unsigned long long* flag = h->done_host + (h->seq % TAB_SLOTS);
+    while (*flag < h->seq) { sched_yield(); if (expired()) { need_sync = true; break; } }
+  }
+  if (!need_sync && h->mirror_host && h->mirror_pending) {
+    volatile double* m = h->mirror_host + 10;
+    while (*m != (double)h->mirror_pending) { sched_yield(); if (expired()) { need_sync = true; break; } }
+  }
+  if (need_sync) (void)hipDeviceSynchronize();
+}
+
 static void plan_release(Handle* h) {
+  handle_quiesce(h);
   if (h->plan) { prior_plan_destroy(h->plan); h->plan = nullptr; }
   if (h->node_rec_dev) { (void)hipFree(h->node_rec_dev); h->node_rec_dev = nullptr; }
   if (h->tab_host) { (void)hipHostFree(h->tab_host); h->tab_host = nullptr; h->tab_dev = nullptr; }
@@ -176,7 +197,7 @@ extern "C" int asvgp_result_mirror(asvgp_handle_t handle, int enable, const doub
     memset(h->mirror_host, 0, sizeof(double) * 16);
   }
   if (!enable && h->mirror_host) {
-    (void)hipDeviceSynchronize();            // (a launch in flight may still write it)
+    handle_quiesce(h);                       // (a launch in flight may still write it)
     (void)hipHostFree(h->mirror_host);
     h->mirror_host = nullptr; h->mirror_dev = nullptr; h->mirror_pending = 0;
   }

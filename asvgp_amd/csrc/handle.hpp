@@ -63,6 +63,11 @@ Handle* as_handle(asvgp_handle_t h);      // NULL -> the process-wide default ha
 // model); the kernel instantiation that generates its knots on the VALU re-checks the table and reports a mismatch loudly.
 bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hipStream_t st, double* step_out, double* first_out, double* last_out);
 
+// A deferred cross-workgroup reduce (asvgp_set_phi_deferred_reduce) that is still pending is enqueued on `st` (phi_pass.hip).  Called by
+// asvgp_phi_reduce_1d, by every consumer of the statistics buffer (so a bound is never built from the zeroed buffer) and by the next
+// accumulate call on the handle (so the parked partials are never overwritten).  stats != NULL: only when the pending reduce targets it.
+int handle_flush_phi_reduce(Handle* h, const double* stats, hipStream_t st);
+
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);
 

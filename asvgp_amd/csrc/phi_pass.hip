@@ -647,7 +647,9 @@ static int launch_phi_sort(Handle* h, const double* x, const double* y, long N, 
 template <int K>
 static int launch_phi(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh,
                       double delta, long M, double* stats, double* partials, hipStream_t st) {
-  h->pend.valid = false;
+  // a reduce still parked on this handle (deferred mode, e.g. the per-dimension calls of an additive model share one handle and one
+  // partials workspace) goes out now, stream-ordered before this pass overwrites the partials
+  { const int rcf = handle_flush_phi_reduce(h, nullptr, st); if (rcf) return rcf; }
   const int ncells = (int)n_mesh - 1;
   if (h->phi_algo == 0 || h->phi_algo == 6) {
     const int rc = launch_phi_sort<K>(h, x, y, N, D, mesh, n_mesh, delta, M, stats, partials, st);
@@ -790,16 +792,21 @@ extern "C" int asvgp_stream_probe(const double* x, const double* y, int64_t N, d
   return check_launch("stream_probe");
 }
 
-extern "C" int asvgp_phi_reduce_1d(asvgp_handle_t handle, asvgp_stream_t stream) {
-  Handle* h = as_handle(handle);
+namespace asvgp {
+int handle_flush_phi_reduce(Handle* h, const double* stats, hipStream_t st) {
   if (!h->pend.valid) return ASVGP_OK;                 // nothing deferred (the accumulate call has reduced already)
+  if (stats && stats != h->pend.stats) return ASVGP_OK;
   const Handle::PendingReduce p = h->pend;
   h->pend.valid = false;
   const int E1 = (p.K + 2) * p.M + 1;
   const int gsplit = p.G >= 64 ? 16 : (p.G >= 8 ? 4 : 1);
-  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, as_stream(stream), p.partials, p.G, p.M, p.K, 0, (long)p.M, 1L, 0,
-                     1, p.stats);
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, p.partials, p.G, p.M, p.K, 0, (long)p.M, 1L, 0, 1, p.stats);
   return check_launch("phi_reduce_1d");
+}
+}  // namespace asvgp
+
+extern "C" int asvgp_phi_reduce_1d(asvgp_handle_t handle, asvgp_stream_t stream) {
+  return handle_flush_phi_reduce(as_handle(handle), nullptr, as_stream(stream));
 }
 
 extern "C" int asvgp_phi_index_1d(const double* x, int64_t N, const double* mesh, int64_t n_mesh, double delta,

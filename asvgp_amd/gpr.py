@@ -60,8 +60,24 @@ class _ShardedStats:
         in place (bench.py times the collective separately)."""
         self._phi_pass_local(**kw)
         if allreduce:
+            h = getattr(self, "_h", None)
+            if h is not None and h.deferred and self._distributed:
+                # deferred mode parks the workgroup partials; the collective must see the reduced LOCAL statistics (ADVICE r2)
+                check(get_lib().asvgp_phi_reduce_1d(h.ptr, stream_ptr()), "phi_reduce_1d")
             self._allreduce_stats()
         return self._stats
+
+
+class HostArray(np.ndarray):
+    """numpy array with the one tensor method the reference's scripts call on model outputs: `.numpy()` (electricity.py:132-138:
+    `model.predict_y(X)[0].numpy()`, `model.predict_log_density((X, y)).numpy()`)."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def _host(a):
+    return np.asarray(a).view(HostArray)
 
 
 class _GPModelSurface:
@@ -74,13 +90,28 @@ class _GPModelSurface:
 
     def predict_y(self, Xnew):
         mean, var = self.predict_f(Xnew)
-        return mean, var + float(self.likelihood.variance)
+        return _host(mean), _host(var + float(self.likelihood.variance))
 
     def predict_log_density(self, data):
+        """gpflow GPModel.predict_log_density with the Gaussian likelihood: log N(y | mean, var_f + sigma2) summed over the output
+        dimension - shape (N,) (gpflow/likelihoods/scalar_continuous.py Gaussian._predict_log_density: reduce_sum over the last axis)."""
         Xnew, Ynew = data
         mean, var = self.predict_y(Xnew)
         Ynew = np.asarray(Ynew.cpu() if isinstance(Ynew, torch.Tensor) else Ynew, dtype=np.float64).reshape(mean.shape)
-        return -0.5 * (np.log(2 * np.pi * var) + (Ynew - mean) ** 2 / var)
+        return _host(np.sum(-0.5 * (np.log(2 * np.pi * var) + (Ynew - mean) ** 2 / var), axis=-1))
+
+    def close(self):
+        """Release the model's library handle now (pinned table ring, result mirror, plan) instead of at garbage collection."""
+        h = getattr(self, "_h", None)
+        if h is not None:
+            h.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 class GPR_1d(_GPModelSurface, _ShardedStats):
@@ -362,6 +393,7 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
     def __init__(self, data, kernels, bases, process_group=None, distributed=None):
         dev = bases[0].device
         self.X, self.y = _to_device(data[0], dev), _to_device(data[1], dev)
+        require_cuda(self.X, self.y)                         # (both routes below hand raw device pointers to the library)
         self.n, self.d = self.X.shape[0], self.X.shape[1]
         assert len(kernels) == len(bases) == self.d          # gpr.py:247
         assert self.y.shape[1] == 1                          # gpr.py:248
@@ -551,6 +583,38 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         """gpr.py:269 kron.make_kvs_sparse(Kuf): sparse (m1*m2, N) Khatri-Rao design matrix."""
         from . import kronecker
         return kronecker.make_kvs_sparse(self.bases, self.X)
+
+    # gpr.py:271-273: the three views of Kuf Kuf^T the reference stores as attributes.  Here they are lazy (the model itself works on the
+    # block band): built from KufKfu_blockband on first access, never from Kuf @ Kuf.T.
+    @property
+    def KufKfu_sparse(self):
+        """gpr.py:271: symmetric sparse (M_tot, M_tot) Kuf @ Kuf.T (torch sparse COO)."""
+        if self._dense_mode:
+            return self.KufKfu.to_sparse()
+        k, m1, m2 = self.order, self.bases[0].m, self.bases[1].m
+        dev = self._stats.device
+        offs = [(0, d2) for d2 in range(k + 1)] + [(d1, d2) for d1 in range(1, k + 1) for d2 in range(-k, k + 1)]
+        i1 = torch.arange(m1, device=dev).repeat_interleave(m2)
+        i2 = torch.arange(m2, device=dev).repeat(m1)
+        col = i1 * m2 + i2
+        r, c, v = [], [], []
+        for o, (d1, d2) in enumerate(offs):
+            ok = (i1 + d1 < m1) & (i2 + d2 >= 0) & (i2 + d2 < m2)
+            rows, cols, vals = (col + d1 * m2 + d2)[ok], col[ok], self.KufKfu_blockband[o][ok]
+            r.append(rows); c.append(cols); v.append(vals)
+            if (d1, d2) != (0, 0):
+                r.append(cols); c.append(rows); v.append(vals)
+        return torch.sparse_coo_tensor(torch.stack([torch.cat(r), torch.cat(c)]), torch.cat(v), (self.Mtot, self.Mtot)).coalesce()
+
+    @property
+    def KufKfu_dense(self):
+        """gpr.py:272: dense (M_tot, M_tot) Kuf @ Kuf.T."""
+        return self.KufKfu if self._dense_mode else self.KufKfu_sparse.to_dense()
+
+    @property
+    def KufKfu_band(self):
+        """gpr.py:273: utils.sparse_to_band(KufKfu_sparse, self.bandwidth) with the reference's own bandwidth attribute (gpr.py:262)."""
+        return utils.sparse_to_band(self.KufKfu_sparse, min(self.bandwidth, self.Mtot - 1))
 
     def theta(self):
         return [(float(k.variance), float(k.lengthscales)) for k in self.kernels], float(self.likelihood.variance)
@@ -829,6 +893,9 @@ class GPR_additive(_GPModelSurface, _ShardedStats):
             check(lib.asvgp_phi_accumulate_1d(self._h.ptr, self._cols[i].data_ptr(), self.y.data_ptr(), self.n, 1, bs.mesh.data_ptr(),
                                               bs.mesh.shape[0], bs.delta_np, k, bs.m, out.data_ptr(), self._ws.data_ptr(),
                                               self._wsb, stream_ptr()), "phi_accumulate_1d")
+        # deferred-reduce mode is a GPR_1d scheduling aid; here the last dimension's parked reduce goes out before the cross blocks
+        # (the earlier ones were flushed by the next accumulate call on the shared handle)
+        check(lib.asvgp_phi_reduce_1d(self._h.ptr, stream_ptr()), "phi_reduce_1d")
         for (i, j), o in self._cross_off.items():
             bi, bj = self.bases[i], self.bases[j]
             check(lib.asvgp_phi_cross_2d(self._cols[i].data_ptr(), self._cols[j].data_ptr(), self.n, bi.mesh.data_ptr(),

@@ -22,8 +22,15 @@ def make_kvs_coo(bases, X):
     return rows, cols, data
 
 
-def make_kvs_sparse(bases, X):
-    """kronecker.py:32-33 for d = 2: torch sparse CSR (m1*m2, N)."""
+def make_kvs_sparse(bases, X=None):
+    """kronecker.py:32-33.  Two call forms:
+      make_kvs_sparse(A_list)   - the reference's signature: a list of sparse per-dimension design matrices (m_i, N), reduced with
+                                  make_kvs_two_sparse (any d);
+      make_kvs_sparse(bases, X) - the fused form the model uses for d = 2: one kernel evaluates both bases at X (N, 2).
+    Returns a torch sparse CSR (prod m_i, N)."""
+    if X is None:
+        from functools import reduce
+        return reduce(make_kvs_two_sparse, list(bases))
     rows, cols, data = make_kvs_coo(bases, X)
     n = cols.shape[0] // (bases[0].order + 1) ** 2
     coo = torch.sparse_coo_tensor(torch.stack([rows, cols]), data, (bases[0].m * bases[1].m, n)).coalesce()
@@ -60,6 +67,6 @@ def sparse_tile(A, repeats):
 def make_kvs_two_sparse(A, B):
     """kronecker.py:27-30: column-wise Kronecker product of two sparse design matrices (generic route; the fused kernel
     behind make_kvs_sparse(bases, X) is what the model uses)."""
-    M1 = sparse_repeats(A, B.shape[0]).to_dense()
-    M2 = sparse_tile(B, A.shape[0]).to_dense()
-    return (M1 * M2).to_sparse_csr()
+    M1 = _coo(sparse_repeats(A, B.shape[0]))
+    M2 = _coo(sparse_tile(B, A.shape[0]))
+    return _coo(M1 * M2).to_sparse_csr()                       # (sparse .multiply, as the reference: nothing is densified)

@@ -449,6 +449,20 @@ def test_predict_vs_oracle_and_survey_values(A, S, golden_dir):
     np.testing.assert_allclose(v2[sel], v3, atol=1e-13)
 
 
+def test_kron_and_dense_models_refuse_cpu_tensors(A):
+    """GPR_kron (d = 2 and the dense d = 3 route) must raise the library's error for host tensors, not pass raw pointers."""
+    from asvgp_amd._lib import AsvgpError
+    rng = np.random.default_rng(0)
+    for d in (2, 3):
+        X = torch.from_numpy(rng.uniform(0.05, 0.95, (100, d)))
+        y = torch.from_numpy(rng.normal(size=(100, 1)))
+        bases = [A.B3Spline(0, 1, 8) for _ in range(d)]
+        assert A.GPR_kron((X, y), [A.Matern32() for _ in range(d)], bases).X.is_cuda      # host tensors are moved to the basis' device
+        bases[0].device = torch.device("cpu")                                              # a basis that lives on the host: refuse
+        with pytest.raises(AsvgpError):
+            A.GPR_kron((X, y), [A.Matern32() for _ in range(d)], bases)
+
+
 def test_cpu_tensors_are_refused(A):
     from asvgp_amd import banded, _lib
     with pytest.raises(_lib.AsvgpError):
@@ -1270,7 +1284,9 @@ def test_gpmodel_surface_on_every_model_class(A):
         np.testing.assert_allclose(my, mf)
         np.testing.assert_allclose(vy, vf + 0.05, rtol=1e-12)
         ld = m.predict_log_density((Xs, ys))
-        np.testing.assert_allclose(ld, norm.logpdf(ys, loc=my, scale=np.sqrt(vy)), rtol=1e-10, atol=1e-12)
+        assert ld.shape == (50,)                                   # gpflow's Gaussian likelihood sums over the output dimension
+        np.testing.assert_allclose(ld, norm.logpdf(ys, loc=my, scale=np.sqrt(vy)).sum(-1), rtol=1e-10, atol=1e-12)
+        assert isinstance(ld.numpy(), np.ndarray) and isinstance(my.numpy(), np.ndarray)   # electricity.py:132-138 calls .numpy() on both
 
 
 def test_predict_paths_odd_counts_unaligned_and_staged(A, S):
@@ -1636,3 +1652,70 @@ def test_config5_enatl60_stand_in_at_full_size_on_one_gpu(A):
     assert abs(e2 - e) <= 1e-9 * abs(e) + 5e-10 * (0.5 * N * 0.1 / 1e-3), (e, e2)
     mean, var = model.predict_f(X[:5000])
     assert E.MSE(y[:5000], mean) < 2e-3 and (var > 0).all()
+
+
+def test_kron_boundary_attributes_and_reference_make_kvs_signature(A):
+    """GPR_kron exposes Kuf / KufKfu_sparse / KufKfu_dense / KufKfu_band (gpr.py:269-273) as lazy views built from the block
+    band, and kronecker.make_kvs_sparse accepts the reference's own signature - a list of per-dimension sparse design matrices."""
+    rng = np.random.default_rng(21)
+    N, k, m1, m2 = 700, 3, 9, 11
+    X = rng.uniform(0.02, 0.98, (N, 2))
+    y = np.sin(4 * X[:, :1]) * X[:, 1:] + 0.05 * rng.normal(size=(N, 1))
+    bases = [A.B3Spline(0, 1, m1), A.B3Spline(0, 1, m2)]
+    model = A.GPR_kron((X, y), [A.Matern32(), A.Matern32()], bases)
+    Kuf = model.Kuf.to_dense()
+    ref = (Kuf @ Kuf.T).cpu().numpy()
+    dense = model.KufKfu_dense.cpu().numpy()
+    np.testing.assert_allclose(dense, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(dense, _blockband_to_dense(model.KufKfu_blockband.cpu().numpy(), k, m1, m2), rtol=0, atol=0)
+    sp = model.KufKfu_sparse
+    assert sp.layout == torch.sparse_coo and sp.shape == (m1 * m2, m1 * m2)
+    np.testing.assert_array_equal(sp.to_dense().cpu().numpy(), dense)
+    band = model.KufKfu_band.cpu().numpy()
+    assert band.shape == (model.bandwidth + 1, m1 * m2)
+    for d in (0, 1, k, m2, m2 + k, model.bandwidth):
+        np.testing.assert_array_equal(band[d, :m1 * m2 - d], np.diagonal(dense, -d))
+    # the reference's call form: make_kvs_sparse([Kuf_1, Kuf_2]) (gpr.py:268-269)
+    A_list = [model.inducing_features[i].make_Kuf(dev(X[:, i:i + 1])) for i in range(2)]
+    KR = A.kronecker.make_kvs_sparse(A_list).to_dense().cpu().numpy()
+    np.testing.assert_allclose(KR, Kuf.cpu().numpy(), rtol=0, atol=1e-15)
+    # three factors through the same reduce
+    B3 = A.B3Spline(0, 1, 8)
+    A3 = A.SplineFeatures1D(A.Matern32(), B3).make_Kuf(dev(rng.uniform(0.02, 0.98, (N, 1))))
+    KR3 = A.kronecker.make_kvs_sparse(A_list + [A3]).to_dense().cpu().numpy()
+    a, b, c = (t.to_dense().cpu().numpy() for t in A_list + [A3])
+    np.testing.assert_allclose(KR3, np.einsum("in,jn,kn->ijkn", a, b, c).reshape(-1, N), rtol=0, atol=1e-15)
+
+
+def test_deferred_reduce_is_flushed_by_every_consumer_of_the_statistics(A):
+    """with the reduce deferred, a bound must never be built from the zeroed statistics buffer and an additive model's
+    per-dimension passes (one handle, one partials workspace) must not overwrite each other's parked partials: the ELBO / posterior
+    entry points flush a reduce that targets their buffer, the next accumulate on the handle flushes the previous one."""
+    rng = np.random.default_rng(12)
+    N, M = 200_000, 512
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+    m = A.GPR_1d((x.reshape(-1, 1), y.reshape(-1, 1)), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    m.likelihood.variance.assign(0.01)
+    ref_stats = m._stats.clone()
+    ref = m.elbo_and_grad().tolist()
+    m._h.set_phi_deferred_reduce(1)
+    m.phi_pass()                                          # partials parked, statistics buffer zeroed
+    np.testing.assert_allclose(m.elbo_and_grad().tolist(), ref, rtol=1e-9)   # the ELBO entry point flushed the reduce first
+    assert (m._stats - ref_stats).abs().max().item() <= 1e-12 * ref_stats.abs().max().item()   # (tile sort: reproducible to rounding)
+    m.phi_pass()
+    mean, var = m.predict_f(np.array([[0.3], [0.6]]))     # posterior_prepare flushes too
+    m._h.set_phi_deferred_reduce(0)
+    m.phi_pass()
+    mean2, var2 = m.predict_f(np.array([[0.3], [0.6]]))
+    np.testing.assert_allclose(mean, mean2, rtol=1e-10)
+    np.testing.assert_allclose(var, var2, rtol=1e-8)
+    # additive model: d accumulate calls on one handle
+    Xa = rng.uniform(0.01, 0.99, (20_000, 2))
+    ya = np.sin(5 * Xa[:, :1]) + Xa[:, 1:] + 0.1 * rng.normal(size=(20_000, 1))
+    add = A.GPR_additive((Xa, ya), [A.Matern32(), A.Matern32()], [A.B3Spline(0, 1, 24), A.B3Spline(0, 1, 20)])
+    s_ref = add._stats.clone()
+    add._h.set_phi_deferred_reduce(1)
+    add.phi_pass()                                        # every per-dimension reduce is out before the cross blocks
+    torch.cuda.synchronize()
+    assert (add._stats - s_ref).abs().max().item() <= 1e-12 * s_ref.abs().max().item()
