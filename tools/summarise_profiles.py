@@ -1,10 +1,11 @@
-"""Summarise gpurun_out/prof_r02 (tools/collect_profiles.sh) into profiles/ (tracked).  usage: python tools/summarise_profiles.py [tag]"""
+"""Summarise gpurun_out/prof_<tag> (tools/collect_profiles.sh) into profiles/ (tracked).  usage: python tools/summarise_profiles.py [tag=r03]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r02")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-KERNEL = "phi_moment_kernel"
+KERNEL = "phi_sort_kernel"
+PHI_ALGORITHM = 6
 
 
 def newest(pattern):
@@ -21,20 +22,36 @@ def counters(sub):
                 out.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
+
+def copy(name_in, name_out):
+    p = os.path.join(src, name_in)
+    if os.path.exists(p):
+        if name_in.endswith(".txt") or name_in.endswith(".log"):
+            lines = [ln for ln in open(p).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2")]
+            open(os.path.join(dst, name_out), "w").write("\n".join(lines) + "\n")
+        else:
+            shutil.copy(p, os.path.join(dst, name_out))
+
+
 ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, tag + "_bench.json"))
-shutil.copy(os.path.join(src, "bench_sorted.json"), os.path.join(dst, tag + "_bench_sorted.json"))
-if os.path.exists(os.path.join(src, "bench_one_at_a_time.json")):
-    shutil.copy(os.path.join(src, "bench_one_at_a_time.json"), os.path.join(dst, tag + "_bench_one_at_a_time.json"))
+copy("bench_default.json", tag + "_bench.json")
+copy("bench_sorted.json", tag + "_bench_sorted.json")
+copy("trace_bench.json", tag + "_bench_under_tracer.json")
+copy("dependent_timeline.txt", tag + "_dependent_timeline.txt")
+copy("phi_ablation.json", tag + "_phi_ablation.json")
+copy("mside_probe.txt", tag + "_mside_probe.txt")
+copy("bcr_mfma_bench.txt", tag + "_bcr_mfma_levels.txt")
+copy("phi_probe_10m.txt", tag + "_phi_probe_n10m.txt")
+copy("phi_probe_1250k.txt", tag + "_phi_probe_n1250k.txt")
 for sub in ("kron", "predict"):          # kernel-trace stats of tools/kron_probe.py / tools/predict_probe.py + the probes' own output
     fs = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if fs:
         shutil.copy(fs[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, sub)))
         log = [ln for ln in open(os.path.join(src, sub + ".log")).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2")]
         open(os.path.join(dst, "%s_%s_probe.txt" % (tag, sub)), "w").write("\n".join(log[-12:]) + "\n")
-# the bench runs BOTH schedules in one process: split the Phi kernel's launches by grid size (256 workgroups = one step at a time,
-# fewer = steps in flight) so that each average can be held against the matching figure of the bench line
+# the bench runs its schedules in one process: split the Phi kernel's launches by grid size (256 workgroups = one step at a time and
+# construction, fewer = the overlapped schedules) so that each average can be held against the matching figure of the bench line
 kt = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if kt:
     by_grid = {}
@@ -42,10 +59,11 @@ if kt:
         if KERNEL in row["Kernel_Name"]:
             wgs = int(row["Grid_Size_X"]) // max(int(row["Workgroup_Size_X"]), 1)
             by_grid.setdefault(wgs, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-    json.dump({"kernel": KERNEL, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline",
+    json.dump({"kernel": KERNEL, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 3 --repeats 5 --no-cpu-baseline",
                "launches_by_workgroups": {str(k): {"launches": len(v), "average_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
                                           for k, v in sorted(by_grid.items())},
-               "note": "256 workgroups = one-step-at-a-time schedule (and warm-up / construction), 240 = steps-in-flight schedule"},
+               "note": "256 workgroups = one-step-at-a-time schedule (and warm-up / construction): compare with roofline.kernel_us; 240 = dependent and "
+                       "independent-evaluation schedules (the launch shares the device with the chain workgroups)"},
               open(os.path.join(dst, tag + "_phi_kernel_by_schedule.json"), "w"), indent=1)
 fetch, nf = counters("fetch")
 write, nw = counters("write")
@@ -54,7 +72,7 @@ for row in csv.DictReader(open(ks)):
     if KERNEL in row["Name"]:
         name, avg_ns = row["Name"].split("(")[0].replace("void asvgp::", ""), float(row["AverageNs"])
 traffic = {
-    "kernel": name, "points_per_launch": 10_000_000,
+    "kernel": name, "phi_algorithm": PHI_ALGORITHM, "points_per_launch": 10_000_000,
     "FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
     "correction": "gfx950 tallies 128-B streaming reads at 64 B: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); units KiB",
     "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024,
@@ -67,6 +85,11 @@ json.dump(traffic, open(os.path.join(dst, tag + "_phi_traffic.json"), "w"), inde
 sq, _ = counters("sq")
 sq2, _ = counters("sq2")
 sq.update(sq2)
-json.dump({name: sq, "note": "rocprofv3 --pmc, two passes of 8 SQ counters each, averaged over the launches of tools/phi_pmc.py (chip totals)"},
+sqs, _ = counters("sq_sorted")
+sqs2, _ = counters("sq2_sorted")
+sqs.update(sqs2)
+json.dump({"kernel": name, "unsorted": sq, "sorted": sqs,
+           "note": "rocprofv3 --pmc, two passes of 8 SQ counters each per input order, averaged over the launches of tools/phi_pmc.py (chip totals; "
+                   "PHI_SORTED=1 for the sorted input)"},
           open(os.path.join(dst, tag + "_phi_pmc_counters.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1)); print(sq)
+print(json.dumps(traffic, indent=1)); print(sq); print(sqs)
