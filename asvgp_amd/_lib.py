@@ -24,6 +24,7 @@ SIGNATURES = {
     "asvgp_stream_probe": (_I, [_P, _P, _L, _P, _P]),
     "asvgp_debug_reload_env": (_I, []),
     "asvgp_host_mantissa_bits": (_I, []),
+    "asvgp_prior_interior_kuu_host": (_I, [_P, _I, _L, _I, _P, _P, _c.POINTER(_L), _c.POINTER(_L), _P]),
     "asvgp_result_mirror": (_I, [_P, _I, _c.POINTER(_P)]),
     "asvgp_result_mirror_pending": (_c.c_uint64, [_P]),
     "asvgp_set_phi_workgroups": (_I, [_P, _I]),

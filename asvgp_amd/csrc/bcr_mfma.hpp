@@ -71,6 +71,14 @@ __device__ __forceinline__ double bm_chol_linv(const double (&d)[10], int hi, in
   return hi == 0 ? z0 : (hi == 1 ? z1 : (hi == 2 ? z2 : z3));
 }
 
+// Band source access by (diagonal, column): sources that know the matrix structure (elbo.hip's BandSumToep: Kuu constant per diagonal on
+// its Toeplitz interior) provide load_dc; the plain ones are read through load(offset).
+template <typename Src> __device__ __forceinline__ auto bm_src_load(const Src& A, int dd, long col, long M, int) -> decltype(A.load_dc(dd, col, M)) {
+  return A.load_dc(dd, col, M);
+}
+template <typename Src> __device__ __forceinline__ double bm_src_load(const Src& A, int dd, long col, long M, long) {
+  return A.load((long)dd * M + col, true);
+}
 // running log of a product without a logarithm on the dependent chain: mantissa in [1, 2) and a separate exponent sum
 struct BmLog {
   double m; int e;
@@ -117,14 +125,14 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   auto bandD = [&](int n, int rr, int cc) -> double {             // D_n[rr][cc], rr >= cc
     const int col = n * B + cc, row = n * B + rr;
     const bool pad = row >= M;
-    const double v = A.load((long)(rr - cc) * M + (pad ? 0 : col), true);
+    const double v = bm_src_load(A, rr - cc, pad ? 0 : col, (long)M, 0);
     return pad ? ((rr == cc) ? 1.0 : 0.0) : v;
   };
   auto bandE = [&](int n, int rr, int cc) -> double {             // A[(n+1) B + rr, n B + cc]  (upper-triangular block)
     if (rr > cc) return 0.0;
     const int col = n * B + cc, row = (n + 1) * B + rr;
     const bool pad = row >= M;
-    const double v = A.load((long)(B + rr - cc) * M + (pad ? 0 : col), true);
+    const double v = bm_src_load(A, B + rr - cc, pad ? 0 : col, (long)M, 0);
     return pad ? 0.0 : v;
   };
   // ---- pre-pass: rhs -> xs.  (The even nodes' D blocks reach the LDS in level 0, from the band slab of their odd neighbour; only a last
@@ -158,7 +166,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
           m = m < ne ? m : ne - 1;
           const int kk = ev + 16 * t3, dd = kk >> 3, col = m * 2 * B + (kk & 7);
           const bool in = kk < 40 && col + dd < M;
-          const double v = A.load(in ? (long)dd * M + col : 0, true);   // (unconditional, clamped)
+          const double v = bm_src_load(A, in ? dd : 0, in ? col : 0, (long)M, 0);   // (unconditional, clamped)
           sl[u][t3] = in ? v : ((dd == 0) ? 1.0 : 0.0);
         }
       }

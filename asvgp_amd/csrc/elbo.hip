@@ -79,6 +79,29 @@ template <int K> struct PostLauncher {
 #ifdef ASVGP_ELBO_ONLY_K
 struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]; int n; };
 
+// P = A / s + Kuu for the matrix-core P chain WITHOUT waiting for the helper workgroups' Kuu (~4.5 us at the head of the launch): on the
+// Toeplitz interior of the static bands (prior_plan.cpp: columns [lo, hi), found by exact comparison) diagonal d of Kuu is ONE number,
+// and the few boundary columns' entries are a 2 x 8 x 16 table; both are formed on the host with the reference's rounding sequence and
+// travel as the FIRST kernel argument.  Branch-free: every lane loads its A entry and one table entry (index 0 when interior) - a branch
+// around the boundary case made the compiler wait for every A load separately (12 dependent round trips in level 0, +4 us).
+struct KuuInterior { double k[8]; long lo, hi; double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND]; };
+typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;
+struct BandSumToep {
+  const double* A; double inv_s;
+  lds_cdouble_ptr kl;                     // the interior diagonal values, in the LDS (a five-way select between struct members by a run-time
+  const double* bnd;                      // diagonal was turned into address arithmetic on a scratch copy of the struct); bnd: kernarg segment
+  long lo, hi;
+  __device__ __forceinline__ double load_dc(int dd, long col, long M) const {
+#pragma clang fp contract(off)
+    const double t2 = A[(long)dd * M + col] * inv_s;
+    const bool left = col < lo, right = col >= hi;
+    const long bi = left ? (long)dd * PRIOR_BND + col : (right ? (long)(PRIOR_BND_DIAGS + dd) * PRIOR_BND + (col - hi) : 0);
+    const double bv = bnd[bi];
+    const double kv = kl[dd];
+    return t2 + ((left || right) ? bv : kv);
+  }
+};
+
 static __global__ void elbo_prepare_kernel(const double* __restrict__ S, KuuCoefs2 cf, long E, const double* __restrict__ A,
                                     double s, double* __restrict__ Kuu, double* __restrict__ dK,
                                     double* __restrict__ P) {
@@ -438,7 +461,7 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
 // or to draw a ticket - nothing later overwrites the flag - and the host re-arms the workspace and re-issues the step through the
 // multi-launch sweeps (gpr.py).
 template <int K>
-__global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(const double* S_static, KuuCoefs2 cf, double* Kuu, double* dK, const double* A, const double* b, int M,
+__global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterior ki, const double* S_static, KuuCoefs2 cf, double* Kuu, double* dK, const double* A, const double* b, int M,
                                                                       double* wsP, double* SP, double* x, double* logdets, int* info,
                                                                       double s, const double* tab, int n_rec, const int* node_rec,
                                                                       double* wsK, double* SK, double* dSK,
@@ -485,11 +508,15 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(const doub
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   if (blockIdx.x == 0) {
-    wait_assembled();
-    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
     rstamp(1);
-    bcr_mfma_solve<BandSumP>(BandSumP{A, Kuu, 1.0 / s}, b, M, wsP, lds, SP, x, logdets + 2, info + 1);
-    __syncthreads();                                           // (the band of P^-1 and x are re-read below by other lanes of this workgroup)
+    __shared__ double kdl[8];
+    if (threadIdx.x == 0) { kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4]; }
+    __syncthreads();
+    // (ki is kernel argument 0: its boundary table is read in place, from the kernel-argument segment)
+    const double* bnd = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
+    bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1);
+    wait_assembled();                                          // (the helpers' Kuu / dKuu: needed from here on, long there; its barrier also orders SP, x)
+    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
     if (fin.finalize) {
       for (long j = threadIdx.x; j < M; j += blockDim.x) {
 #pragma unroll
@@ -699,6 +726,11 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
       // matrix-core chains: k = 4, one output column, the whole tree in one workgroup's LDS, no explicit request for the older kernel
       use_mfma = (algo == 0 || algo == 4) && D == 1 && nb <= 512 && TANGENT && fin != nullptr &&
                  sizeof(double) * bcr_mfma_lds_doubles(nb) <= 160 * 1024 && sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec) <= 160 * 1024;
+      KuuInterior ki;
+      if (use_mfma) {
+        prior_plan_interior_kuu(h->plan, cf.c, ki.k, &ki.lo, &ki.hi, ki.bnd);   // Kuu in closed form for the P chain's level-0 loads
+        use_mfma = ki.hi > ki.lo;                                                // (no Toeplitz interior: the older kernel, which waits for the assembled band)
+      }
       if (use_mfma) {
         size_t lb = sizeof(double) * bcr_mfma_lds_doubles(nb), lk = sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec);
         if (lk > lb) lb = lk;
@@ -719,7 +751,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
         const double t0 = host_times ? now_us() : 0.0;
         if (plan_first) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
-        hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BM_THREADS), lb, st, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
+        hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                            h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
                            plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
         const double t1 = host_times ? now_us() : 0.0;

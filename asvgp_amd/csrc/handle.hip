@@ -123,6 +123,22 @@ bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hip
 
 using namespace asvgp;
 
+// Host-only: Kuu for one theta in closed form (interior diagonal values + boundary-column table), as the matrix-core ELBO launch receives it.
+extern "C" int asvgp_prior_interior_kuu_host(const double* static_bands_host, int n_terms, int64_t M, int k, const double* coef_host,
+                                             double* kuu_diag8, int64_t* lo, int64_t* hi, double* bnd256) {
+  if (!coef_host || !kuu_diag8 || !lo || !hi || !bnd256) { set_error("prior_interior_kuu_host: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  char err[256] = "";
+  PriorPlan* p = prior_plan_create(static_bands_host, n_terms, (long)M, k, err, sizeof(err));
+  if (!p) { set_error("%s", err); return strstr(err, "bad argument") ? ASVGP_ERR_BAD_ARG : ASVGP_ERR_UNSUPPORTED; }
+  long l = 0, h = 0;
+  for (int i = 0; i < 8; ++i) kuu_diag8[i] = 0.0;
+  for (int i = 0; i < 2 * PRIOR_BND_DIAGS * PRIOR_BND; ++i) bnd256[i] = 0.0;
+  prior_plan_interior_kuu(p, coef_host, kuu_diag8, &l, &h, bnd256);
+  *lo = l; *hi = h;
+  prior_plan_destroy(p);
+  return ASVGP_OK;
+}
+
 extern "C" int asvgp_host_mantissa_bits(void) { return prior_plan_mantissa_bits(); }
 
 extern "C" int asvgp_debug_reload_env(void) {

@@ -57,6 +57,8 @@ struct PriorPlan {
   std::vector<int> lvl_off;                  // record offset of every level (+ the root record at the end)
   std::vector<int> node_rec;                 // per block node: record index
   int n_rec = 0;
+  long int_lo = 0, int_hi = 0;               // columns [int_lo, int_hi) on which EVERY diagonal of every static term is constant (Toeplitz interior)
+  std::vector<double> int_val;               // (n_terms, B + 1): that constant
 };
 
 // value of band entry (row, col), row >= col, of static term t; identity padding beyond M (as bcr.hpp band_D / band_E)
@@ -86,6 +88,26 @@ PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, in
   p->S.assign(statics_host, statics_host + (size_t)n_terms * (k + 1) * M);
   const int nb = p->nb;
   while ((1 << p->levels) < nb) ++p->levels;
+  // ---- Toeplitz interior: the longest column range around the middle on which every (term, diagonal) is one constant, bit for bit
+  {
+    const long mid = M / 2;
+    long lo = 0, hi = M - k;                  // (columns whose whole band column lies inside the matrix)
+    p->int_val.assign((size_t)n_terms * (k + 1), 0.0);
+    if (hi > mid && mid >= 0) {
+      for (int t = 0; t < n_terms; ++t)
+        for (int d = 0; d <= k; ++d) {
+          const double* row = p->S.data() + ((size_t)t * (k + 1) + d) * M;
+          const double v = row[mid];
+          p->int_val[(size_t)t * (k + 1) + d] = v;
+          long a = mid, b = mid + 1;
+          while (a > 0 && memcmp(&row[a - 1], &v, sizeof(double)) == 0) --a;
+          while (b < M - k && memcmp(&row[b], &v, sizeof(double)) == 0) ++b;
+          lo = a > lo ? a : lo;
+          hi = b < hi ? b : hi;
+        }
+      if (hi > lo) { p->int_lo = lo; p->int_hi = hi; }
+    }
+  }
   // ---- level-0 classes by exact comparison of the static blocks
   std::vector<int> cur(nb), dcls(nb), ecls(nb > 1 ? nb - 1 : 0);
   {
@@ -148,6 +170,33 @@ PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, in
 
 void prior_plan_destroy(PriorPlan* p) { delete p; }
 int prior_plan_mantissa_bits() { return LDBL_MANT_DIG; }
+// Kuu for one theta in closed form: kuu_diag[d] = the value of diagonal d on the Toeplitz interior, columns [*lo, *hi); bnd = the
+// entries of the boundary columns - left part bnd[d * PRIOR_BND + col] (col < lo), right part bnd[(B + 1) * PRIOR_BND + d * PRIOR_BND +
+// (col - hi)] (col >= hi; entries below the matrix are 0).  All formed with the rounding sequence of inducing_features.py:12-44 (this
+// file is compiled with -ffp-contract=off): bit for bit what the device assembly writes.  *hi <= *lo: no usable interior (a boundary
+// wider than PRIOR_BND columns, or no Toeplitz structure) - the caller keeps the assembled band.
+void prior_plan_interior_kuu(const PriorPlan* p, const double* coef, double* kuu_diag, long* lo, long* hi, double* bnd) {
+  const int B = p->B;
+  const long M = p->M;
+  *lo = 0; *hi = 0;
+  if (p->int_hi <= p->int_lo || p->int_lo > PRIOR_BND || M - p->int_hi > PRIOR_BND || B + 1 > PRIOR_BND_DIAGS) return;
+  auto entry = [&](int d, long col) -> double {
+    if (col + d >= M) return 0.0;
+    const double* S = p->S.data();
+    double acc = coef[0] * S[((size_t)0 * (B + 1) + d) * M + col];
+    for (int t = 1; t < p->n_terms; ++t) acc = acc + coef[t] * S[((size_t)t * (B + 1) + d) * M + col];
+    return acc;
+  };
+  for (int d = 0; d <= B; ++d) {
+    kuu_diag[d] = entry(d, p->int_lo);
+    for (long col = 0; col < PRIOR_BND; ++col) {
+      bnd[(size_t)d * PRIOR_BND + col] = col < p->int_lo ? entry(d, col) : 0.0;
+      const long cr = p->int_hi + col;
+      bnd[(size_t)(PRIOR_BND_DIAGS + d) * PRIOR_BND + col] = cr < M ? entry(d, cr) : 0.0;
+    }
+  }
+  *lo = p->int_lo; *hi = p->int_hi;
+}
 int prior_plan_nrec(const PriorPlan* p) { return p->n_rec; }
 int prior_plan_nb(const PriorPlan* p) { return p->nb; }
 long prior_plan_M(const PriorPlan* p) { return p->M; }

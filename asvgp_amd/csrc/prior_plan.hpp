@@ -31,6 +31,10 @@ int prior_plan_mantissa_bits();                               // mantissa width 
 struct PriorPlan;
 PriorPlan* prior_plan_create(const double* statics_host, int n_terms, long M, int k, char* err, size_t errlen);
 void prior_plan_destroy(PriorPlan* p);
+// Kuu for one theta without the band: B + 1 interior diagonal values on columns [*lo, *hi) and the boundary columns' entries
+// (bnd: 2 * PRIOR_BND_DIAGS * PRIOR_BND doubles; layout in prior_plan.cpp); *hi <= *lo: not available
+constexpr int PRIOR_BND = 16, PRIOR_BND_DIAGS = 8;
+void prior_plan_interior_kuu(const PriorPlan* p, const double* coef, double* kuu_diag, long* lo, long* hi, double* bnd);
 int prior_plan_nrec(const PriorPlan* p);
 int prior_plan_nb(const PriorPlan* p);
 long prior_plan_M(const PriorPlan* p);

@@ -81,6 +81,11 @@ int asvgp_phi_accumulate_1d(asvgp_handle_t handle, const double* x, const double
  *       numpy.linspace.  Sums follow arrival order: reproducible to rounding, not bit for bit (5 and 3 are).
  * Same statistics to <= 1e-12 of the band's largest entry. */
 int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo);
+/* Host-only (tests): Kuu for one theta in closed form, as the matrix-core launch of asvgp_elbo_grad_1d receives it instead of waiting for
+ * the assembled band: kuu_diag8[d] = diagonal d on the Toeplitz interior, columns [*lo, *hi); bnd256 = the boundary columns' entries,
+ * left part [d * 16 + col] (col < lo), right part [(8 + d) * 16 + (col - hi)] (col >= hi).  *hi <= *lo: no usable interior. */
+int asvgp_prior_interior_kuu_host(const double* static_bands_host, int n_terms, int64_t M, int k, const double* coef_host,
+                                  double* kuu_diag8, int64_t* lo, int64_t* hi, double* bnd256);
 /* Mantissa width of the arithmetic the host forward pass of the planned prior chain runs in: 64 (x87 extended; the build refuses any other). */
 int asvgp_host_mantissa_bits(void);
 /* The library reads its debug / measurement switches (ASVGP_SPIN_LIMIT, ASVGP_DEBUG_NO_ASSEMBLY, ASVGP_CHAIN_STAMPS, ASVGP_BCR_STAMPS,
