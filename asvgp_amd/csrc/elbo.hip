@@ -473,8 +473,8 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   // diagnostic (ASVGP_CHAIN_STAMPS): 100 MHz wall-clock stamps per role into logdets[8 + 4 * min(block, 2) ..]: start, chain done, end
   const unsigned long long t_start = fin.debug_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   auto rstamp = [&](int slot) {
-    if (fin.debug_stamps && threadIdx.x == 0 && blockIdx.x <= 2)
-      logdets[8 + 4 * (int)blockIdx.x + slot] = (slot == 0) ? (double)(t_start & 0xffffffffull) : (double)((__builtin_amdgcn_s_memrealtime() - t_start) & 0xffffffffull);
+    if (fin.debug_stamps && threadIdx.x == 0 && blockIdx.x <= 2)   // (slots 4..7: extra marks of the P workgroup's tail)
+      logdets[(slot < 4 ? 8 + 4 * (int)blockIdx.x : 24) + slot] = (slot == 0) ? (double)(t_start & 0xffffffffull) : (double)((__builtin_amdgcn_s_memrealtime() - t_start) & 0xffffffffull);
   };
   rstamp(0);
   if (blockIdx.x >= 2) {                                       // helpers: Kuu, dKuu/dl (theta-only), then gone
@@ -515,8 +515,10 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
     // (ki is kernel argument 0: its boundary table is read in place, from the kernel-argument segment)
     const double* bnd = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
     bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1);
+    rstamp(3);
     wait_assembled();                                          // (the helpers' Kuu / dKuu: needed from here on, long there; its barrier also orders SP, x)
     if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
+    rstamp(4);
     if (fin.finalize) {
       for (long j = threadIdx.x; j < M; j += blockDim.x) {
 #pragma unroll
@@ -557,35 +559,47 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
     }
   }
   if (!fin.finalize) { rstamp(2); return; }
+  if (blockIdx.x == 0) rstamp(5);
   // ---- workgroup sums -> this chain's own slots (agent-scope stores: two writers, disjoint slots, no atomic adds) -> ticket; the last
   // ticket evaluates the bound (elbo_finalize_body's formulas).  Only the accumulators this chain owns are reduced.
-  double (*part)[8] = reinterpret_cast<double (*)[8]>(lds);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double* part0 = lds;                                         // [wave][8] wave totals
+  const int lane = threadIdx.x & 63;
   const bool isP = blockIdx.x == 0;
-  double mine[7];
+  double mine[8];
   mine[0] = isP ? acc[SPDK] : acc[TRKA];
   mine[1] = isP ? acc[SPK] : acc[DTRKA];
   mine[2] = isP ? acc[SPA] : acc[SKDK];
   mine[3] = isP ? acc[AKA] : acc[SKK];
-  mine[4] = acc[ADKA]; mine[5] = acc[AAA]; mine[6] = acc[BA];
+  mine[4] = acc[ADKA]; mine[5] = acc[AAA]; mine[6] = acc[BA]; mine[7] = 0.0;
   const int nmine = isP ? 7 : 4;                               // (workgroup-uniform)
   __syncthreads();                                             // (the chains' LDS images are dead)
+  // Eight sums over 64 lanes as a reduce-scatter butterfly: each exchange halves the values a lane still carries (4 + 2 + 1 exchanges),
+  // three more finish the one that is left - 10 shuffles instead of 8 x 6 (the separate wave reductions were 3.9 us of the launch's tail).
+  // The 16 wave results meet in a fixed order (no atomics): the same inputs give the same bits.
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  double s4[4], s2[2];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    if (i < nmine) {
-      const double v = wave_sum_dpp(mine[i]);
-      if (lane == 0) part[wv][i] = v;
-    }
-  }
+  for (int i = 0; i < 4; ++i) { const double keep = b0 ? mine[4 + i] : mine[i], send = b0 ? mine[i] : mine[4 + i]; s4[i] = keep + __shfl_xor(send, 1, 64); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const double keep = b1 ? s4[2 + i] : s4[i], send = b1 ? s4[i] : s4[2 + i]; s2[i] = keep + __shfl_xor(send, 2, 64); }
+  double s1 = (b2 ? s2[1] : s2[0]) + __shfl_xor(b2 ? s2[0] : s2[1], 4, 64);
+  s1 += __shfl_xor(s1, 8, 64); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  // lane l < 8 now holds the wave total of accumulator idx(l) = 4 bit0 + 2 bit1 + bit2; it files it under its OWN lane number
+  const int wv = threadIdx.x >> 6;
+  if (lane < 8) part0[wv * 8 + lane] = s1;
   __syncthreads();
   if (threadIdx.x >= 64) return;
+  double t2 = part0[(2 * (lane >> 3)) * 8 + (lane & 7)] + part0[(2 * (lane >> 3) + 1) * 8 + (lane & 7)];   // waves 2j, 2j + 1
+  t2 += __shfl_xor(t2, 8, 64); t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+  double red[7];                                               // accumulator i sits in lane rev3(i): 0, 4, 2, 6, 1, 5, 3
+  red[0] = __shfl(t2, 0, 64); red[1] = __shfl(t2, 4, 64); red[2] = __shfl(t2, 2, 64); red[3] = __shfl(t2, 6, 64);
+  red[4] = __shfl(t2, 1, 64); red[5] = __shfl(t2, 5, 64); red[6] = __shfl(t2, 3, 64);
+  (void)nmine;
   double tot[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
-  double red[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) red[i] = (i < nmine) ? wave_sum_dpp(lane < nw ? part[lane][i] : 0.0) : 0.0;
   if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) rstamp(6);
   double* slot = fin.gacc + (isP ? 0 : 8);                     // P: gacc[0..6], Kuu: gacc[8..11]
 #pragma unroll
   for (int i = 0; i < 7; ++i)

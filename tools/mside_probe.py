@@ -38,8 +38,12 @@ off = 9 * (k + 1) * M + 2 * M * D
 st = ws[off + 8: off + 8 + 12].reshape(3, 4)
 t0 = st[:, 0].min()
 for name, row in zip(("P chain (workgroup 0)", "Kuu backward (workgroup 1)", "helper 0 (assemble, wait, finalize)"), st):
-    print("%-38s start +%.2f us | phase mark +%.2f us | end +%.2f us (100 MHz wall clock, relative to the earliest start)" % (
-        name, (row[0] - t0) / 100, (row[0] - t0 + row[1]) / 100, (row[0] - t0 + row[2]) / 100))
+    print("%-38s start +%.2f us | phase mark +%.2f us | end +%.2f us (100 MHz wall clock, relative to the earliest start)%s" % (
+        name, (row[0] - t0) / 100, (row[0] - t0 + row[1]) / 100, (row[0] - t0 + row[2]) / 100,
+        (" | solve done +%.2f us" % ((row[0] - t0 + row[3]) / 100)) if row[3] > 0 else ""))
+ex = ws[off + 24 + 4: off + 24 + 7]
+print("P workgroup tail (relative to its start): helpers' bands acquired +%.2f us | trace / quadratic-form loop done +%.2f us | workgroup sums done +%.2f us" % tuple(
+    (st[0][0] - t0 + v) / 100 for v in ex))
 feat = model.inducing_features
 us, enq = timed(lambda: feat.inverse_band(model.kernel))
 print("Kuu chain alone (asvgp_kuu_inverse_band_1d: assemble + planned backward pass): %.1f us per call (host enqueue %.1f us)" % (us, enq))
