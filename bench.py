@@ -290,41 +290,49 @@ def main():
     out4 = model._out.cpu().numpy()
     stats_host = stats.cpu().numpy()
 
-    # ---- schedule C (`value`): dependent steps.  Two sets of buffers (lanes) alternate.  Per step, in host order:
-    #   ELBO + gradient launch of step i with theta_i on the M stream (behind the statistics event of lane i; the launch goes out before
-    #   the host's long-double forward pass of the prior chain, which the Kuu workgroup waits for) -> Phi pass, cross-workgroup reduce and
-    #   [all-reduce] of step i+1 on the N stream into the OTHER lane (they need no theta) -> the host polls the pinned result mirror of
-    #   step i -> theta_{i+1} = theta_0 (1 + 1e-6 delta(result_i)).  Nothing of step i+1 that needs theta can start earlier.
-    dep, dep_error = None, None
-    try:
-        lanes = [new_model(N, overlapped=True, defer=False) for _ in range(2)]
+    # ---- schedule C (`value`): dependent steps.  theta_{i+1} = theta_0 (1 + 1e-6 delta(result_i)) is computed on the host from the result of
+    # step i that the host has read, so nothing of step i+1 that needs theta (ELBO launch, host forward pass) can start earlier.  The Phi
+    # pass, its cross-workgroup reduce and the [all-reduce] need no theta and run on a second stream into another buffer set:
+    #   two buffer sets (`value`): per step, in host order - Phi KERNEL of step i+1 (N stream; its buffer set was released by the result
+    #     just read) -> theta_i, ELBO + gradient launch of step i (M stream, behind the statistics event of its set; the launch goes out
+    #     before the host's long-double forward pass, which the Kuu workgroup waits for) -> reduce, [all-reduce], event of step i+1 (N
+    #     stream) -> the host polls the pinned result mirror of step i.
+    #   three buffer sets (extra `dependent_steps_phi_two_ahead`): ELBO launch of step i first, then the whole N side of step i+2.
+    def dependent_schedule(n_sets):
+        lanes = [new_model(N, overlapped=True, defer=(n_sets == 2)) for _ in range(n_sets)]
         s_n = torch.cuda.Stream()
         s_m = torch.cuda.Stream(priority=-1)
-        ev_stats = [torch.cuda.Event(), torch.cuda.Event()]
-        state = {"i": 0, "theta": theta0, "primed": False, "last": None, "t_m": 0.0, "t_n": 0.0, "t_poll": 0.0, "n": 0}
+        ev_stats = [torch.cuda.Event() for _ in range(n_sets)]
+        ahead = n_sets - 1
+        state = {"i": 0, "theta": theta0, "primed": False, "last": None, "t_a": 0.0, "t_b": 0.0, "t_poll": 0.0, "n": 0}
 
-        def phi_into(lane_idx):
-            # N stream: Phi pass, cross-workgroup reduce, [all-reduce] - none of it needs theta
+        def n_side_kernel(k):                                      # Phi pass (two sets: the streaming kernel alone, its reduce parked)
+            _lib.set_stream(s_n)
+            lanes[k].phi_pass(allreduce=False)
+
+        def n_side_rest(k):                                        # reduce (if parked), [all-reduce], "statistics complete"
+            _lib.set_stream(s_n)
+            lanes[k].phi_reduce()                                  # (a no-op when nothing is parked)
             if world > 1:
                 with torch.cuda.stream(s_n):
-                    lanes[lane_idx].phi_pass(allreduce=False)
-                    dist.all_reduce(lanes[lane_idx]._stats, op=dist.ReduceOp.SUM)
-            else:
-                _lib.set_stream(s_n)
-                lanes[lane_idx].phi_pass(allreduce=False)
-            ev_stats[lane_idx].record(s_n)
+                    dist.all_reduce(lanes[k]._stats, op=dist.ReduceOp.SUM)
+            ev_stats[k].record(s_n)
 
-        def dependent_block(k):
+        def block(k):
             if not state["primed"]:
-                phi_into(state["i"] % 2)
+                for j in range(ahead):
+                    n_side_kernel((state["i"] + j) % n_sets)
+                    n_side_rest((state["i"] + j) % n_sets)
                 state["primed"] = True
             for _ in range(k):
                 i = state["i"]
-                ln = lanes[i % 2]
+                ln, nxt = lanes[i % n_sets], (i + ahead) % n_sets
                 t0 = time.perf_counter()
+                if n_sets == 2:
+                    n_side_kernel(nxt)
                 set_theta(ln, state["theta"])
-                if not ev_stats[i % 2].query():                     # (normally long finished: the host has seen it, no stream-side wait needed)
-                    s_m.wait_event(ev_stats[i % 2])
+                if not ev_stats[i % n_sets].query():                # (complete unless the N side is the slower one: then the launch waits in-stream)
+                    s_m.wait_event(ev_stats[i % n_sets])
                 _lib.set_stream(s_m)
                 if args.no_mirror:
                     ln._launch_elbo()
@@ -332,7 +340,9 @@ def main():
                 else:
                     tok = ln.launch_elbo_host()
                 t1 = time.perf_counter()
-                phi_into((i + 1) % 2)
+                if n_sets != 2:
+                    n_side_kernel(nxt)
+                n_side_rest(nxt)
                 t2 = time.perf_counter()
                 if tok is None:
                     with torch.cuda.stream(s_m):
@@ -346,23 +356,38 @@ def main():
                 state["last"] = r
                 state["i"] = i + 1
                 if k == K_steps:                                    # (timed blocks only: the warm-up carries one-time allocations)
-                    state["t_m"] += t1 - t0; state["t_n"] += t2 - t1; state["t_poll"] += t3 - t2; state["n"] += 1
+                    state["t_a"] += t1 - t0; state["t_b"] += t2 - t1; state["t_poll"] += t3 - t2; state["n"] += 1
             _lib.set_stream(None)
 
-        dep_ms, dep_kern_us, dep_launches = timed_blocks(dependent_block, lanes[0]._h)
+        ms, kern_us, launches = timed_blocks(block, lanes[0]._h)
         n_acc = max(state["n"], 1)
-        dep = {"ms": dep_ms, "kern_us": dep_kern_us, "launches": dep_launches, "last": state["last"],
+        out = {"ms": ms, "kern_us": kern_us, "launches": launches, "last": state["last"],
                "fallbacks": sum(getattr(ln, "fused_launch_fallbacks", 0) for ln in lanes),
-               "host_us": {"theta_and_elbo_launch_incl_forward_pass": state["t_m"] / n_acc * 1e6, "phi_enqueue": state["t_n"] / n_acc * 1e6,
+               "host_us": {("phi_kernel_enqueue_theta_and_elbo_launch_incl_forward_pass" if n_sets == 2 else "theta_and_elbo_launch_incl_forward_pass"): state["t_a"] / n_acc * 1e6,
+                           ("reduce_and_event_enqueue" if n_sets == 2 else "n_side_enqueue"): state["t_b"] / n_acc * 1e6,
                            "wait_for_result": state["t_poll"] / n_acc * 1e6}}
         torch.cuda.synchronize()
         del lanes
-    except Exception as exc:   # the contract line must come out: fall back to the one-at-a-time figures and say why
-        dep, dep_error = None, repr(exc)[:300]
+        return out
+
+    dep, dep_error, dep3, dep3_error = None, None, None, None
+    for n_sets in (2, 3):
         try:
-            torch.cuda.synchronize()
-        except Exception:
-            pass
+            res = dependent_schedule(n_sets)
+            if n_sets == 2:
+                dep = res
+            else:
+                dep3 = res
+        except Exception as exc:   # the contract line must come out: fall back to the one-at-a-time figures and say why
+            if n_sets == 2:
+                dep_error = repr(exc)[:300]
+            else:
+                dep3_error = repr(exc)[:300]
+            _lib.set_stream(None)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
 
     # ---- schedule B (extra): L steps with the SAME theta in flight - a throughput of independent evaluations.  N-side stream: Phi pass of
     # step i+1; M-side streams in turn: reduce, [all-reduce], ELBO launch of steps i, i-1.  Every step is a complete evaluation from the raw
@@ -438,7 +463,7 @@ def main():
             dsp = spread(dep["ms"])
             schedule = ("dependent steps: theta_{i+1} computed on the host from the host-read result of step i (pinned result mirror%s); "
                         "ELBO + gradient launch of step i on one stream, the theta-free part of step i+1 (Phi pass, reduce, [all-reduce]) on a "
-                        "second stream under it; two buffer sets alternate; Phi grid %d workgroups"
+                        "second stream under it (host order: Phi kernel of i+1, ELBO launch of i, reduce of i+1); two buffer sets alternate; Phi grid %d workgroups"
                         % (" off: D2H copy + synchronise" if args.no_mirror else "", args.phi_workgroups))
         else:
             dsp = ser
@@ -483,6 +508,14 @@ def main():
                                           "last_result": dep["last"], "rel_diff_elbo_vs_fixed_theta": abs(dep["last"][0] - out4[0]) / abs(out4[0])}
         if dep_error is not None:
             line["dependent_schedule_error"] = dep_error
+        if dep3 is not None:
+            d3 = spread(dep3["ms"])
+            line["dependent_steps_phi_two_ahead"] = {"value": mp(d3["median"]), "unit": "Mpoints/s", "ms_per_step": d3, "host_us_per_step": dep3["host_us"],
+                                                     "fused_launch_fallbacks": dep3["fallbacks"],
+                                                     "note": "the same dependent steps with THREE buffer sets: the theta-free part of step i+2 runs under the ELBO launch of "
+                                                             "step i, so the N side never sits between two ELBO launches; reported beside `value`, which keeps to step i+1"}
+        if dep3_error is not None:
+            line["dependent_steps_phi_two_ahead_error"] = dep3_error
         if ind is not None:
             isp = spread(ind["ms"])
             line["independent_evaluations"] = {"value": mp(isp["median"]), "unit": "Mpoints/s", "ms_per_step": isp, "in_flight": args.in_flight,

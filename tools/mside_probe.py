@@ -24,6 +24,8 @@ for algo in (0, 2):
     A.set_band_algorithm(algo)
     us, enq = timed(model._launch_elbo)
     print("band algorithm %d: ELBO + gradient launch %.1f us per call (host enqueue %.1f us)  -> %s" % (algo, us, enq, model._out[:4].tolist()))
+    if algo == 0:
+        us0 = us
 A.set_band_algorithm(0)
 os.environ["ASVGP_CHAIN_STAMPS"] = "1"
 _lib.get_lib().asvgp_debug_reload_env()
@@ -47,3 +49,17 @@ print("P workgroup tail (relative to its start): helpers' bands acquired +%.2f u
 feat = model.inducing_features
 us, enq = timed(lambda: feat.inverse_band(model.kernel))
 print("Kuu chain alone (asvgp_kuu_inverse_band_1d: assemble + planned backward pass): %.1f us per call (host enqueue %.1f us)" % (us, enq))
+
+# a dependent loop without any Phi pass: launch, poll the pinned result mirror, repeat (what an optimiser does per evaluation)
+model.elbo_and_grad_host()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(300):
+    r = model.elbo_and_grad_host()
+dt = (time.perf_counter() - t0) / 300 * 1e6
+print("elbo_and_grad_host() back to back: %.1f us per evaluation (kernel %.1f us -> %.1f us of launch path, dispatch latency and mirror round trip)" % (dt, us0, dt - us0))
+t0 = time.perf_counter()
+for _ in range(300):
+    r = model.elbo_and_grad().tolist()
+dt2 = (time.perf_counter() - t0) / 300 * 1e6
+print("elbo_and_grad().tolist() back to back (stream path: two device-to-host copies): %.1f us per evaluation" % dt2)
