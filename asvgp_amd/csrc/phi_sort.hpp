@@ -149,14 +149,14 @@ __device__ __forceinline__ void ps_own_cell(const double2* buf, unsigned l, unsi
 // their 3k+1 partial moments to the cell's slot of a small LDS table with ds_add_f64; the owner lane then takes the slot.  Rounds of
 // PS_HROUND cells.
 template <int K>
-__device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn, unsigned ho, int first, int lane, double* slot) {
+__device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn, unsigned ho, int first, int stride, int lane, double* slot) {
   constexpr int NS = 2 * K;
   const unsigned nsl = (hn + 63u) >> 6;
   {
     double S2[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) S2[q] = 0.0;
-    for (unsigned sl = (unsigned)first; sl < nsl; sl += 4) {
+    for (unsigned sl = (unsigned)first; sl < nsl; sl += (unsigned)stride) {
       const unsigned j = sl * 64 + lane;
       if (j < hn) {
         const double sv = buf[ho + j].x;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn,
     double T2[K + 1];
 #pragma unroll
     for (int q = 0; q <= K; ++q) T2[q] = 0.0;
-    for (unsigned sl = (unsigned)first; sl < nsl; sl += 4) {
+    for (unsigned sl = (unsigned)first; sl < nsl; sl += (unsigned)stride) {
       const unsigned j = sl * 64 + lane;
       if (j < hn) {
         const double2 pt = buf[ho + j];
@@ -466,11 +466,14 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
           if (tid < PS_HROUND * NSTAT) hacc[tid] = 0.0;
           ps_lds_barrier();
           const unsigned rn = nheavy - r0 < (unsigned)PS_HROUND ? nheavy - r0 : (unsigned)PS_HROUND;
+          // waves per cell: all 16 on a single heavy cell (sorted input: one or two cells hold the whole tile), 8 each on two, else groups
+          // of four waves (group g takes the cells hh = g mod 4); a wave takes slices first, first + per, ...
+          const int per = rn == 1 ? 16 : (rn == 2 ? 8 : 4), sh_per = rn == 1 ? 4 : (rn == 2 ? 3 : 2);
           for (unsigned hh = 0; hh < rn; ++hh) {
             const unsigned hn = hlist[3 * (r0 + hh) + 1], ho = hlist[3 * (r0 + hh) + 2];
-            // waves 4 g + i (i = 0..3) of group g = hh mod 4 take slices i, i + 4, ...
-            if ((wv >> 2) == (int)(hh & 3u) && (unsigned)(wv & 3) < ((hn + 63u) >> 6))
-              ps_heavy_slices<K>(buf, hn, ho, wv & 3, lane, hacc + hh * NSTAT);
+            const bool mine = rn <= 2 ? (wv >> sh_per) == (int)hh : (wv >> 2) == (int)(hh & 3u);
+            if (mine && (unsigned)(wv & (per - 1)) < ((hn + 63u) >> 6))
+              ps_heavy_slices<K>(buf, hn, ho, wv & (per - 1), per, lane, hacc + hh * NSTAT);
           }
           ps_lds_barrier();
           if (hvA && slA >= r0 && slA < r0 + PS_HROUND) {
