@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=5, choices=tuple(range(0, 25)), help="extra `independent_evaluations`: steps in flight (0 = skip)")
     ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the independent-evaluations extra")
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the overlapped schedules (the chain workgroups need free CUs)")
+    ap.add_argument("--no-three-sets", action="store_true", help="skip the extra dependent schedule with three buffer sets")
     ap.add_argument("--no-mirror", action="store_true", help="dependent schedule: read results through the stream (D2H copy + sync) instead of the pinned mirror")
     ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
     ap.add_argument("--phase-events", type=int, default=25, help="one-at-a-time schedule: per-phase events on every n-th step (0 = never)")
@@ -371,7 +372,7 @@ def main():
         return out
 
     dep, dep_error, dep3, dep3_error = None, None, None, None
-    for n_sets in (2, 3):
+    for n_sets in ((2,) if args.no_three_sets else (2, 3)):
         try:
             res = dependent_schedule(n_sets)
             if n_sets == 2:
