@@ -23,6 +23,8 @@ SIGNATURES = {
     "asvgp_phi_last_algorithm": (_I, [_P]),
     "asvgp_stream_probe": (_I, [_P, _P, _L, _P, _P]),
     "asvgp_debug_reload_env": (_I, []),
+    "asvgp_set_deferred_forward_pass": (_I, [_P, _I]),
+    "asvgp_prior_publish": (_I, [_P]),
     "asvgp_host_mantissa_bits": (_I, []),
     "asvgp_prior_interior_kuu_host": (_I, [_P, _I, _L, _I, _P, _P, _c.POINTER(_L), _c.POINTER(_L), _P]),
     "asvgp_result_mirror": (_I, [_P, _I, _c.POINTER(_P)]),
@@ -150,6 +152,13 @@ class Handle:
             return None
         self._mirror = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(_D)), shape=(16,))
         return self._mirror
+
+    def set_deferred_forward_pass(self, on):
+        check(self._lib.asvgp_set_deferred_forward_pass(self.ptr, int(bool(on))), "set_deferred_forward_pass")
+
+    def publish_forward(self):
+        """asvgp_prior_publish: run the host forward pass a deferred launch is waiting for (a no-op when none is pending)."""
+        self._lib.asvgp_prior_publish(self.ptr)
 
     def result_mirror_pending(self):
         return int(self._lib.asvgp_result_mirror_pending(self.ptr))

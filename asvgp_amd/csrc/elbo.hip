@@ -769,6 +769,12 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
                            h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
                            plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
         const double t1 = host_times ? now_us() : 0.0;
+        if (!plan_first && h->defer_forward) {                  // the caller runs the forward pass later (asvgp_prior_publish): e.g. after
+          h->fwd.valid = true;                                   // enqueueing other work that should not wait 19 us behind it
+          for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) { h->fwd.coef[t] = cf.c[t]; h->fwd.dcoef[t] = cf.dc[t]; }
+          h->fwd.tab = tab; h->fwd.slot = slot; h->fwd.seq = seq;
+          return check_launch("elbo chains (matrix cores, forward pass deferred)");
+        }
         if (!plan_first) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);   // a non-positive pivot is reported through `info` by the kernel
         if (host_times) {
           static double acc_launch = 0.0, acc_plan = 0.0, acc_pre = 0.0, acc_acq = 0.0, acc_a = 0.0;

@@ -45,6 +45,7 @@ Handle* as_handle(asvgp_handle_t h) {
 // flight reads the pinned ring or writes the mirror.  Bounded; a launch that gave up waiting never reports, so the fallback is a
 // device synchronisation.  This replaces a device-wide synchronisation on every model teardown.
 static void handle_quiesce(Handle* h) {
+  handle_publish_forward(h);
   bool need_sync = false;
   struct timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -70,7 +71,15 @@ static void plan_release(Handle* h) {
   h->slot_doubles = 0;
 }
 
+void handle_publish_forward(Handle* h) {
+  if (!h->fwd.valid) return;
+  h->fwd.valid = false;
+  if (h->plan) (void)prior_plan_eval(h->plan, h->fwd.coef, h->fwd.dcoef, h->fwd.tab);   // a non-positive pivot is reported through `info` by the kernel
+  __atomic_store_n(h->ready_host + h->fwd.slot, h->fwd.seq, __ATOMIC_RELEASE);
+}
+
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out) {
+  handle_publish_forward(h);                 // (a launch still waiting for its table goes first)
   const unsigned long long seq = ++h->seq;
   const int slot = (int)(seq % TAB_SLOTS);
   if (seq > TAB_SLOTS) {   // the slot's previous table (sequence seq - TAB_SLOTS) must have been read by its kernel
@@ -197,6 +206,18 @@ extern "C" int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo) {
     return ASVGP_ERR_BAD_ARG;
   }
   as_handle(handle)->band_algo = algo;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_set_deferred_forward_pass(asvgp_handle_t handle, int on) {
+  Handle* h = as_handle(handle);
+  if (!on) handle_publish_forward(h);
+  h->defer_forward = on != 0;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_prior_publish(asvgp_handle_t handle) {
+  handle_publish_forward(as_handle(handle));
   return ASVGP_OK;
 }
 

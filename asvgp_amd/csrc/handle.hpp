@@ -40,6 +40,10 @@ struct Handle {
   size_t slot_doubles = 0;
   unsigned long long seq = 0;
   int plan_terms = 0;
+  // deferred forward pass (asvgp_set_deferred_forward_pass): the matrix-core launch returns at once; asvgp_prior_publish runs the host
+  // forward pass for it and sets the slot's ready word (the next ELBO call or the handle's teardown does it if the caller did not)
+  bool defer_forward = false;
+  struct PendingForward { bool valid; double coef[ASVGP_MAX_KUU_TERMS], dcoef[ASVGP_MAX_KUU_TERMS]; double* tab; int slot; unsigned long long seq; } fwd = {false, {0}, {0}, nullptr, 0, 0};
   // result mirror (asvgp_result_mirror): 16 pinned doubles the fused launch's last ticket writes [out[0..7], info[0], info[1], sequence]
   double* mirror_host = nullptr;
   double* mirror_dev = nullptr;
@@ -67,6 +71,9 @@ bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hip
 // asvgp_phi_reduce_1d, by every consumer of the statistics buffer (so a bound is never built from the zeroed buffer) and by the next
 // accumulate call on the handle (so the parked partials are never overwritten).  stats != NULL: only when the pending reduce targets it.
 int handle_flush_phi_reduce(Handle* h, const double* stats, hipStream_t st);
+
+// run a pending deferred forward pass (no-op when none): prior_plan_eval into the slot, then the ready word
+void handle_publish_forward(Handle* h);
 
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);

@@ -225,6 +225,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         return self._out
 
     def _check_pd(self, relaunch=None, _retry=True):
+        self._h.publish_forward()
         info = self._info.tolist()
         if info[0] < 0 or info[1] < 0:
             # The fused launch gave up waiting for its helper workgroups (they never became resident next to other work on the device).
@@ -281,6 +282,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         word of host memory (no device-to-host copy, no stream synchronisation); otherwise, or when nothing arrives within poll_seconds
         (a launch that gave up waiting never writes the mirror), read through the stream (and through _check_pd's re-issue)."""
         m = self._mirror
+        self._h.publish_forward()              # (deferred-forward-pass mode: the launch must not be left waiting for its table; else a no-op)
         if token:
             want = float(token)
             t_end = time.perf_counter() + poll_seconds

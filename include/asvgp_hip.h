@@ -91,6 +91,12 @@ int asvgp_host_mantissa_bits(void);
 /* The library reads its debug / measurement switches (ASVGP_SPIN_LIMIT, ASVGP_DEBUG_NO_ASSEMBLY, ASVGP_CHAIN_STAMPS, ASVGP_BCR_STAMPS,
  * ASVGP_HOST_TIMES, ASVGP_PLAN_FIRST) from the environment once; call this after changing them in a running process. */
 int asvgp_debug_reload_env(void);
+/* Deferred forward pass.  With on = 1 the matrix-core launch of asvgp_elbo_grad_1d returns right after the kernel launch; the host's
+ * forward pass of the prior chain for that launch (~19 us, long double) runs in asvgp_prior_publish - which the caller issues after
+ * enqueueing whatever should not wait behind it (bench.py: the theta-free Phi pass of the next step).  The launch's Kuu workgroup waits
+ * (bounded) for the table; the next ELBO call, asvgp_set_deferred_forward_pass(h, 0) and asvgp_destroy publish a forgotten one. */
+int asvgp_set_deferred_forward_pass(asvgp_handle_t handle, int on);
+int asvgp_prior_publish(asvgp_handle_t handle);
 /* Result mirror: 16 pinned host doubles owned by the handle.  While enabled, the fused ELBO + gradient launch (band algorithm 0 / 4 where
  * the matrix-core chains apply) also writes [out[0..7], info[0], info[1], sequence, sum of the first ten] there, the sequence number
  * last (after the other stores have been acknowledged; check the sum after seeing it), so a host that has to read every result - an optimiser: the next theta depends on it, the reference's example.py:31-32 -

@@ -1719,3 +1719,34 @@ def test_deferred_reduce_is_flushed_by_every_consumer_of_the_statistics(A):
     add.phi_pass()                                        # every per-dimension reduce is out before the cross blocks
     torch.cuda.synchronize()
     assert (add._stats - s_ref).abs().max().item() <= 1e-12 * s_ref.abs().max().item()
+
+
+def test_deferred_forward_pass_gives_the_same_numbers(A):
+    """asvgp_set_deferred_forward_pass / asvgp_prior_publish: the matrix-core launch returns before the host's forward pass of the prior chain;
+    the caller publishes it later (bench.py: after enqueueing the next Phi pass).  Same bits as the ordinary call; a forgotten publish is
+    made up by the read / the next launch / the teardown, never left to the kernel's bounded wait."""
+    rng = np.random.default_rng(9)
+    N, M = 40000, 2048
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    ref = model.elbo_and_grad_host()
+    model._h.set_deferred_forward_pass(1)
+    tok = model.launch_elbo_host()
+    model.phi_pass()                                   # other work between launch and publish
+    model._h.publish_forward()
+    np.testing.assert_allclose(model.read_elbo_host(tok), ref, rtol=1e-9)      # (the Phi pass in between re-sums the statistics: rounding)
+    tok = model.launch_elbo_host()                     # publish forgotten: the read makes up for it
+    got = model.read_elbo_host(tok)
+    assert got == model.elbo_and_grad_host()           # and so does an ordinary call in deferred mode
+    tok = model.launch_elbo_host()
+    tok2 = model.launch_elbo_host()                    # ... and the next launch
+    assert model.read_elbo_host(tok2) == got
+    model._h.set_deferred_forward_pass(0)
+    assert model.elbo_and_grad_host() == got
+    assert getattr(model, "fused_launch_fallbacks", 0) == 0
+    model.kernel.lengthscales.assign(0.06)
+    model._h.set_deferred_forward_pass(1)
+    model.launch_elbo_host()
+    model.close()                                      # teardown with a launch still waiting for its table
