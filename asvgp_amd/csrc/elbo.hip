@@ -715,14 +715,30 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
   if (planned) {
     // ---- host: forward pass of the Kuu chain for this theta (prior_plan.cpp, ~20 us) into the next slot of the pinned ring.
     // Kuu / dKuu (finalize traces, P = A/s + Kuu in the P chain's gathers) are assembled by the chain workgroups themselves.
-    if (!fits) { set_error("BCR needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
+    // matrix-core chains: k = 4, one output column, the whole tree in one workgroup's LDS, a Toeplitz interior for the closed-form Kuu;
+    // decided BEFORE a table slot is taken (a refused call must not leave a slot whose kernel never reports)
+    const int n_rec = prior_plan_nrec(h->plan);
+    bool use_mfma = false;
+    KuuInterior ki;
+    if constexpr (K == BM_B) {
+      use_mfma = (algo == 0 || algo == 4) && D == 1 && nb <= 512 && TANGENT && fin != nullptr &&
+                 sizeof(double) * bcr_mfma_lds_doubles(nb) <= 160 * 1024 && sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec) <= 160 * 1024;
+      if (use_mfma) {
+        prior_plan_interior_kuu(h->plan, cf.c, ki.k, &ki.lo, &ki.hi, ki.bnd);   // Kuu in closed form for the P chain's level-0 loads
+        use_mfma = ki.hi > ki.lo;                                                // (none: the older kernel, which waits for the assembled band)
+      }
+    }
+    if (algo == 4 && !use_mfma) {
+      set_error("band algorithm 4 (matrix-core chains) needs k = 4, D = 1, M <= 2048, Toeplitz static bands and the ELBO + gradient entry point");
+      return ASVGP_ERR_UNSUPPORTED;
+    }
+    if (!use_mfma && !fits) { set_error("BCR needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
     unsigned long long seq = 0;
     int slot = 0;
     double t_acq0 = 0.0, t_acq1 = 0.0;
     if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_acq0 = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
     double* tab = handle_table_acquire(h, &seq, &slot);
     if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_acq1 = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
-    const int n_rec = prior_plan_nrec(h->plan);
     size_t lds_pre = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
     if (lds_pre > lds_bytes) lds_bytes = lds_pre;
     FusedFin ff{};
@@ -735,16 +751,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     ff.debug_no_assembly = debug_env().no_assembly;
     ff.debug_stamps = debug_env().chain_stamps;   // test hook: the helpers never report -> the P chain gives up waiting
     const long spin_limit = debug_env().spin_limit;
-    bool use_mfma = false;
     if constexpr (K == BM_B) {
-      // matrix-core chains: k = 4, one output column, the whole tree in one workgroup's LDS, no explicit request for the older kernel
-      use_mfma = (algo == 0 || algo == 4) && D == 1 && nb <= 512 && TANGENT && fin != nullptr &&
-                 sizeof(double) * bcr_mfma_lds_doubles(nb) <= 160 * 1024 && sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec) <= 160 * 1024;
-      KuuInterior ki;
-      if (use_mfma) {
-        prior_plan_interior_kuu(h->plan, cf.c, ki.k, &ki.lo, &ki.hi, ki.bnd);   // Kuu in closed form for the P chain's level-0 loads
-        use_mfma = ki.hi > ki.lo;                                                // (no Toeplitz interior: the older kernel, which waits for the assembled band)
-      }
       if (use_mfma) {
         size_t lb = sizeof(double) * bcr_mfma_lds_doubles(nb), lk = sizeof(double) * bcr_mfma_pre_lds_doubles(nb, n_rec);
         if (lk > lb) lb = lk;
@@ -793,7 +800,6 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         __atomic_store_n(h->ready_host + slot, seq, __ATOMIC_RELEASE);
       }
     }
-    if (algo == 4 && !use_mfma) { set_error("band algorithm 4 (matrix-core chains) needs k = 4, D = 1, M <= 2048 and the ELBO + gradient entry point"); return ASVGP_ERR_UNSUPPORTED; }
     if (!use_mfma) {
     (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);     // a non-positive pivot is reported through `info` by the kernel
     __atomic_store_n(h->ready_host + slot, seq, __ATOMIC_RELEASE);

@@ -1750,3 +1750,25 @@ def test_deferred_forward_pass_gives_the_same_numbers(A):
     model._h.set_deferred_forward_pass(1)
     model.launch_elbo_host()
     model.close()                                      # teardown with a launch still waiting for its table
+
+
+def test_matrix_core_chains_forced_where_they_do_not_apply_are_refused_cleanly(A):
+    """Band algorithm 4 outside its domain (k != 4, M > 2048) is ASVGP_ERR_UNSUPPORTED with a message that says why - decided before a
+    factor-table slot is taken, so the handle keeps working (17 more launches: every slot of the ring is reused)."""
+    from asvgp_amd._lib import AsvgpError
+    rng = np.random.default_rng(4)
+    N = 20000
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    for basis in (A.B3Spline(0, 1, 300), A.B4Spline(0, 1, 3000)):
+        model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.02), basis)
+        model.likelihood.variance.assign(0.05)
+        ref = model.elbo_and_grad().cpu().numpy()
+        model._h.set_band_algorithm(4)
+        with pytest.raises(AsvgpError) as ei:
+            model.elbo_and_grad()
+        assert "UNSUPPORTED" in str(ei.value) and "matrix-core" in str(ei.value)
+        model._h.set_band_algorithm(0)
+        for _ in range(17):
+            got = model.elbo_and_grad().cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-9)
