@@ -148,6 +148,26 @@ __device__ __forceinline__ void ps_own_cell(const double2* buf, unsigned l, unsi
 // owner accumulators -, reduce on the VALU (DPP: ~700 cycles per wave and cell, which is why not all 16 waves take part) and add
 // their 3k+1 partial moments to the cell's slot of a small LDS table with ds_add_f64; the owner lane then takes the slot.  Rounds of
 // PS_HROUND cells.
+// Sum each of up to 8 per-lane values over the 64 lanes as a reduce-scatter butterfly: after the exchanges with lanes ^1, ^2, ^4 a lane
+// carries ONE of the values summed over its group of 8, three more exchanges finish it - 10 shuffles instead of 8 x 6 DPP steps (the
+// separate wave reductions were 83 K of the 164 K cycles a workgroup spends on sorted input).  Returns the total of value `idx`.
+template <int NV>
+__device__ __forceinline__ double ps_reduce_scatter8(const double (&v)[NV], int lane, int& idx) {
+  static_assert(NV <= 8, "at most eight values");
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  double a8[8], s4[4], s2[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a8[i] = i < NV ? v[i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const double keep = b0 ? a8[4 + i] : a8[i], send = b0 ? a8[i] : a8[4 + i]; s4[i] = keep + __shfl_xor(send, 1, 64); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const double keep = b1 ? s4[2 + i] : s4[i], send = b1 ? s4[i] : s4[2 + i]; s2[i] = keep + __shfl_xor(send, 2, 64); }
+  double s1 = (b2 ? s2[1] : s2[0]) + __shfl_xor(b2 ? s2[0] : s2[1], 4, 64);
+  s1 += __shfl_xor(s1, 8, 64); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  idx = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+  return s1;
+}
+
 template <int K>
 __device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn, unsigned ho, int first, int stride, int lane, double* slot) {
   constexpr int NS = 2 * K;
@@ -170,8 +190,14 @@ __device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn,
         for (int q = K + 1; q <= NS; ++q) S2[q - 1] = fma(pw[K], pw[q - K], S2[q - 1]);
       }
     }
+    if constexpr (NS <= 8) {
+      int idx;
+      const double t = ps_reduce_scatter8<NS>(S2, lane, idx);
+      if (lane < 8 && idx < NS) lds_add(slot + idx, t);
+    } else {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { const double t = wave_sum_dpp(S2[q]); if (lane == 0) lds_add(slot + q, t); }
+      for (int q = 0; q < NS; ++q) { const double t = wave_sum_dpp(S2[q]); if (lane == 0) lds_add(slot + q, t); }
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   {
@@ -188,8 +214,11 @@ __device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn,
         for (int q = 1; q <= K; ++q) { pw *= pt.x; T2[q] = fma(pt.y, pw, T2[q]); }
       }
     }
-#pragma unroll
-    for (int q = 0; q <= K; ++q) { const double t = wave_sum_dpp(T2[q]); if (lane == 0) lds_add(slot + NS + q, t); }
+    {
+      int idx;
+      const double t = ps_reduce_scatter8<K + 1>(T2, lane, idx);
+      if (lane < 8 && idx <= K) lds_add(slot + NS + idx, t);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -492,6 +521,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
         }
       }
       n0A += nA; n0B += nB;
+      if constexpr (ABL == 9) { __builtin_amdgcn_sched_barrier(0); ph[7] += __builtin_amdgcn_s_memtime() - tprev; __builtin_amdgcn_sched_barrier(0); }   // heavy-cell pass
       // ---- the next tile's loads fly under the owner loops (issued behind the heavy-cell pass: its temporaries and the 4 TP prefetch
       // registers do not fit the register file together)
       if constexpr (PF == 1) load_tile(tile + 1);                 // (clamped: the last one re-reads the final pair)

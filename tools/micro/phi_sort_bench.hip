@@ -159,8 +159,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(st.data(), dstamps, G * 8 * 8, hipMemcpyDeviceToHost));
     double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = 0; g < G; ++g) for (int i = 0; i < 8; ++i) m[i] += (double)st[g * 8 + i] / G;
-    printf("%s wave %2d cycles over all tiles: P1 %.0f (landed+search %.0f, ranks back %.0f, rest = barrier) | P2 scan %.0f | P3 scatter %.0f | P4 owners %.0f | epilogue %.0f | total %.0f\n",
-           tag, wave, m[0], m[5], m[6], m[1], m[2], m[3], m[4], m[0] + m[1] + m[2] + m[3] + m[4]);
+    printf("%s wave %2d cycles over all tiles: P1 %.0f (landed+search %.0f, ranks back %.0f, rest = barrier) | P2 scan %.0f | P3 scatter %.0f | P4 owners %.0f (of which heavy-cell pass %.0f) | epilogue %.0f | total %.0f\n",
+           tag, wave, m[0], m[5], m[6], m[1], m[2], m[3], m[7], m[4], m[0] + m[1] + m[2] + m[3] + m[4]);
   };
   for (int w : {0, 5, 15}) stamps(phi_sort_kernel<K, 4, 9, 0>, std::max(ps_lds_bytes<K, 4>(), ps_epilogue_bytes<K>()), "TP=4 early", w);
 #ifndef PS_QUICK
