@@ -28,3 +28,14 @@ def set_phi_algorithm(algo):
     if int(algo) not in (0, 1, 3, 5, 6):
         raise AsvgpError("set_phi_algorithm: 0, 1, 3, 5 or 6")
     set_default_algorithms(phi=int(algo))
+
+
+def set_prior_forward(mode):
+    """Where the forward (elimination) half of the Kuu chain runs: 0 = on the host in x87 long double (default; prior_plan.cpp), 1 = on the
+    GPU in double-double arithmetic (prior_dd.hip: no host stage, no dependence on the host's long double) - asvgp_set_prior_forward,
+    applied to every live model handle and to models created later."""
+    from ._lib import AsvgpError, get_lib, set_default_algorithms
+    get_lib()
+    if int(mode) not in (0, 1):
+        raise AsvgpError("set_prior_forward: 0 (host, long double) or 1 (GPU, double-double)")
+    set_default_algorithms(prior_forward=int(mode))

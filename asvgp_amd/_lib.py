@@ -53,6 +53,8 @@ SIGNATURES = {
     "asvgp_prior_plan_1d": (_I, [_P, _P, _I, _L, _I, _c.POINTER(_I)]),
     "asvgp_prior_table_doubles": (_Z, [_P, _I, _L, _I]),
     "asvgp_prior_forward_host": (_I, [_P, _I, _L, _I, _P, _P, _P, _Z, _P]),
+    "asvgp_set_prior_forward": (_I, [_P, _I]),
+    "asvgp_prior_forward_device": (_I, [_P, _P, _P, _P, _Z, _P]),
     "asvgp_elbo_grad_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "asvgp_kuu_inverse_band_1d": (_I, [_P, _P, _I, _D, _D, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "asvgp_elbo_chain_sync": (_I, [_P, _I]),
@@ -115,7 +117,7 @@ def check(status, what=""):
 class Handle:
     """asvgp_create / asvgp_destroy: the library state of ONE model (algorithm choices, Phi workgroup count, chain events,
     timing ring, prior-chain plan).  Models own one each, so two models may step on two streams / host threads."""
-    _defaults = {"band": 0, "phi": 0}
+    _defaults = {"band": 0, "phi": 0, "prior_forward": 0}
     _live = None
 
     def __init__(self):
@@ -132,6 +134,22 @@ class Handle:
             self.set_band_algorithm(Handle._defaults["band"])
         if Handle._defaults["phi"]:
             self.set_phi_algorithm(Handle._defaults["phi"])
+        if Handle._defaults["prior_forward"]:
+            self.set_prior_forward(Handle._defaults["prior_forward"])
+
+    def set_prior_forward(self, mode):
+        """asvgp_set_prior_forward: 0 = the Kuu chain's forward pass on the host (x87 long double), 1 = on the GPU (double-double)."""
+        check(self._lib.asvgp_set_prior_forward(self.ptr, int(mode)), "set_prior_forward")
+
+    def prior_forward_device(self, coef, dcoef, n_doubles):
+        """asvgp_prior_forward_device: the GPU forward pass alone for one theta; returns the factor table as a numpy array."""
+        import numpy as np
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        dcoef = np.ascontiguousarray(dcoef, dtype=np.float64)
+        tab = np.zeros(int(n_doubles), dtype=np.float64)
+        check(self._lib.asvgp_prior_forward_device(self.ptr, coef.ctypes.data, dcoef.ctypes.data, tab.ctypes.data, tab.size, stream_ptr()),
+              "prior_forward_device")
+        return tab
 
     def set_band_algorithm(self, algo):
         check(self._lib.asvgp_set_band_algorithm(self.ptr, int(algo)), "set_band_algorithm")
@@ -197,8 +215,13 @@ class Handle:
         self.close()
 
 
-def set_default_algorithms(band=None, phi=None):
-    """Algorithm choice for every live handle and for handles created later (asvgp_amd.set_band_algorithm / set_phi_algorithm)."""
+def set_default_algorithms(band=None, phi=None, prior_forward=None):
+    """Algorithm choice for every live handle and for handles created later (asvgp_amd.set_band_algorithm / set_phi_algorithm /
+    set_prior_forward)."""
+    if prior_forward is not None:
+        Handle._defaults["prior_forward"] = int(prior_forward)
+        for h in list(Handle._live or ()):
+            h.set_prior_forward(prior_forward)
     if band is not None:
         Handle._defaults["band"] = int(band)
     if phi is not None:

@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libasvgp_hip.so")
-SOURCES = ["phi_pass.hip", "band_ops.hip", "elbo.hip", "kron.hip", "additive.hip", "handle.hip"]
+SOURCES = ["phi_pass.hip", "band_ops.hip", "elbo.hip", "kron.hip", "additive.hip", "handle.hip", "prior_dd.hip"]
+EXTRA = {"prior_dd.hip": ["-ffp-contract=off"]}   # error-free transforms: nothing may be fused or re-associated
 HOST_SOURCES = ["prior_plan.cpp"]   # plain C++ (host planner of the prior chain): no FMA contraction, see prior_plan.cpp
 ELBO_KS = (1, 2, 3, 4, 5, 6)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics"]
@@ -34,7 +35,7 @@ def _units():
     units = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        units.append((os.path.join(OBJ, s.replace(".hip", ".o")), src, [], hdrs + [src]))
+        units.append((os.path.join(OBJ, s.replace(".hip", ".o")), src, EXTRA.get(s, []), hdrs + [src]))
     for s in HOST_SOURCES:
         src = os.path.join(CSRC, s)
         units.append((os.path.join(OBJ, s.replace(".cpp", ".o")), src, ["-ffp-contract=off", "-x", "c++"], hdrs + [src]))

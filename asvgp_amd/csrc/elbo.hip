@@ -739,6 +739,16 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_acq0 = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
     double* tab = handle_table_acquire(h, &seq, &slot);
     if (debug_env().host_times) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_acq1 = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+    // asvgp_set_prior_forward(h, 1): the forward pass runs on the GPU in double-double (prior_dd.hip), enqueued here in front of the
+    // chains' launch; the table then sits in the handle's device ring and no launch waits for the host
+    const bool gpu_fwd = h->prior_forward_gpu;
+    const double* tab_k = h->tab_dev + (size_t)slot * h->slot_doubles;
+    if (gpu_fwd) {
+      double* t = nullptr;
+      rc = handle_prior_dd_forward(h, cf.c, cf.dc, slot, st, &t);
+      if (rc) return rc;
+      tab_k = t;
+    }
     size_t lds_pre = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
     if (lds_pre > lds_bytes) lds_bytes = lds_pre;
     FusedFin ff{};
@@ -771,10 +781,11 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         const bool host_times = debug_env().host_times != 0;   // (measurement aid: where this call's host time goes)
         auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
         const double t0 = host_times ? now_us() : 0.0;
-        if (plan_first) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
+        if (plan_first && !gpu_fwd) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
         hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
-                           h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
-                           plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
+                           tab_k, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
+                           (plan_first || gpu_fwd) ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
+        if (gpu_fwd) return check_launch("elbo chains (matrix cores, forward pass on the GPU)");
         const double t1 = host_times ? now_us() : 0.0;
         if (!plan_first && h->defer_forward) {                  // the caller runs the forward pass later (asvgp_prior_publish): e.g. after
           h->fwd.valid = true;                                   // enqueueing other work that should not wait 19 us behind it
@@ -801,14 +812,16 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
       }
     }
     if (!use_mfma) {
-    (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);     // a non-positive pivot is reported through `info` by the kernel
-    __atomic_store_n(h->ready_host + slot, seq, __ATOMIC_RELEASE);
+    if (!gpu_fwd) {
+      (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);   // a non-positive pivot is reported through `info` by the kernel
+      __atomic_store_n(h->ready_host + slot, seq, __ATOMIC_RELEASE);
+    }
     auto kern = big ? elbo_chains_kernel<K, HAS_BIG> : elbo_chains_kernel<K, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BCR_THREADS), lds_bytes, st, S, cf, w.Kuu, TANGENT ? w.dK : (double*)nullptr, A, b,
                        (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
-                       h->tab_dev + (size_t)slot * h->slot_doubles, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK,
+                       tab_k, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK,
                        h->done_dev + slot, seq, (int)D, (int)(lds_bytes / sizeof(double)), ff);
     }
     if (scale_alpha) {
@@ -952,12 +965,20 @@ int KuuInvLauncher<K>::run(Handle* h, const double* S, int kind, double v, doubl
     unsigned long long seq = 0;
     int slot = 0;
     double* tab = handle_table_acquire(h, &seq, &slot);
-    (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
+    const double* tab_k = h->tab_dev + (size_t)slot * h->slot_doubles;
+    if (h->prior_forward_gpu) {
+      double* t = nullptr;
+      rc = handle_prior_dd_forward(h, cf.c, cf.dc, slot, st, &t);
+      if (rc) return rc;
+      tab_k = t;
+    } else {
+      (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
+    }
     const int n_rec = prior_plan_nrec(h->plan);
     const size_t lds_bytes = sizeof(double) * bcr_pre_lds_doubles(K, n_rec);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kuu_inverse_pre_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-    hipLaunchKernelGGL(kuu_inverse_pre_kernel<K>, dim3(1), dim3(BCR_THREADS), lds_bytes, st, h->tab_dev + (size_t)slot * h->slot_doubles, n_rec,
+    hipLaunchKernelGGL(kuu_inverse_pre_kernel<K>, dim3(1), dim3(BCR_THREADS), lds_bytes, st, tab_k, n_rec,
                        h->node_rec_dev, (int)M, w.bcrK, SK, dSK, logdet2, info, h->done_dev + slot, seq);
     return check_launch("kuu_inverse_band_1d (planned)");
   }

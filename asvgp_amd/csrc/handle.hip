@@ -64,6 +64,7 @@ static void handle_quiesce(Handle* h) {
 static void plan_release(Handle* h) {
   handle_quiesce(h);
   if (h->plan) { prior_plan_destroy(h->plan); h->plan = nullptr; }
+  handle_prior_dd_release(h);
   if (h->node_rec_dev) { (void)hipFree(h->node_rec_dev); h->node_rec_dev = nullptr; }
   if (h->tab_host) { (void)hipHostFree(h->tab_host); h->tab_host = nullptr; h->tab_dev = nullptr; }
   if (h->done_host) { (void)hipHostFree(h->done_host); h->done_host = nullptr; h->done_dev = nullptr; }

@@ -44,6 +44,11 @@ struct Handle {
   // forward pass for it and sets the slot's ready word (the next ELBO call or the handle's teardown does it if the caller did not)
   bool defer_forward = false;
   struct PendingForward { bool valid; double coef[ASVGP_MAX_KUU_TERMS], dcoef[ASVGP_MAX_KUU_TERMS]; double* tab; int slot; unsigned long long seq; } fwd = {false, {0}, {0}, nullptr, 0, 0};
+  // forward pass on the GPU in double-double (asvgp_set_prior_forward(h, 1); prior_dd.hip): device image of the plan, device table ring
+  bool prior_forward_gpu = false;
+  int* dd_img_i = nullptr;
+  double* dd_img_d = nullptr;
+  double* dd_tab = nullptr;               // TAB_SLOTS x slot_doubles, device memory (slot numbering shared with the pinned ring)
   // result mirror (asvgp_result_mirror): 16 pinned doubles the fused launch's last ticket writes [out[0..7], info[0], info[1], sequence]
   double* mirror_host = nullptr;
   double* mirror_dev = nullptr;
@@ -74,6 +79,12 @@ int handle_flush_phi_reduce(Handle* h, const double* stats, hipStream_t st);
 
 // run a pending deferred forward pass (no-op when none): prior_plan_eval into the slot, then the ready word
 void handle_publish_forward(Handle* h);
+
+// all-GPU forward pass (prior_dd.hip): enqueue the double-double forward pass for one theta on `st` into slot `slot` of the handle's
+// device table ring (*tab_out); the consumer is launched behind it on the same stream and needs no ready word
+int handle_prior_dd_prepare(Handle* h);
+void handle_prior_dd_release(Handle* h);
+int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out);
 
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);

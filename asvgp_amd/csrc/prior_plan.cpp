@@ -31,7 +31,7 @@ namespace asvgp {
 namespace {
 
 constexpr int MAXB = 6;            // ASVGP_MAX_ORDER
-constexpr int MAX_CLASSES = 24;    // per level
+constexpr int MAX_CLASSES = PRIOR_MAX_CLASSES;    // per level
 
 typedef long double ld;
 // The forward pass owes its accuracy (|bound - exact| ~ 3e-11 |bound| at the headline configuration, cond(Kuu) = 3.5e7) to the 64-bit
@@ -205,6 +205,64 @@ int prior_plan_terms(const PriorPlan* p) { return p->n_terms; }
 const int* prior_plan_node_rec(const PriorPlan* p) { return p->node_rec.data(); }
 size_t prior_plan_table_doubles(const PriorPlan* p) {
   return PRIOR_TAB_HEADER + (size_t)2 * p->n_rec * prior_rec_fields(p->B);
+}
+
+// Device image of the plan for the all-GPU forward pass (prior_dd.hip): the symbolic class maps as ints, the static-band entries of
+// the level-0 representative blocks as doubles.  ints: [0] B, [1] n_terms, [2] levels, [3] n_rec, [4] level-0 D classes, [5] level-0 E
+// classes, [6] offset of the per-level headers, [7] total ints, [8] offset of the D entry codes, [9] of the E entry codes; a level
+// header is 8 ints [node classes, D classes of the next level, offset of node_in (4 ints per class: D class, E class (a, i), E class
+// (i, b) or -1, node count), offset of the representative nodes, offset of d_next (3 ints per class), first record, 0, 0].
+// Entry codes (per level-0 class, B x B, row-major): 0 = sum of coef[t] * entry[t], 1 = the constant 1 (identity padding), 2 = 0.
+// doubles: D entries [class][r][c][term] (lower triangle filled), then E entries [class][r][c][term] (r <= c filled).
+size_t prior_plan_image_ints(const PriorPlan* p) {
+  size_t n = 16 + (size_t)8 * p->levels;
+  for (const Level& L : p->lv) n += L.node_in.size() * 5 + L.d_next.size() * 3;
+  n += (p->d0_rep.size() + p->e0_rep.size()) * (size_t)p->B * p->B;
+  return n;
+}
+size_t prior_plan_image_doubles(const PriorPlan* p) { return (p->d0_rep.size() + p->e0_rep.size()) * (size_t)p->B * p->B * p->n_terms; }
+void prior_plan_image(const PriorPlan* pp, int* ints, double* dbls) {
+  const PriorPlan& p = *pp;
+  const int B = p.B, BB = B * B, nt = p.n_terms;
+  size_t at = 16 + (size_t)8 * p.levels;
+  for (int i = 0; i < 16; ++i) ints[i] = 0;
+  ints[0] = B; ints[1] = nt; ints[2] = p.levels; ints[3] = p.n_rec; ints[4] = (int)p.d0_rep.size(); ints[5] = (int)p.e0_rep.size(); ints[6] = 16;
+  for (int l = 0; l < p.levels; ++l) {
+    const Level& L = p.lv[l];
+    int* h = ints + 16 + 8 * l;
+    h[0] = (int)L.node_in.size(); h[1] = (int)L.d_next.size(); h[5] = p.lvl_off[l]; h[6] = h[7] = 0;
+    h[2] = (int)at;
+    for (size_t q = 0; q < L.node_in.size(); ++q) { for (int i = 0; i < 3; ++i) ints[at++] = L.node_in[q][i]; ints[at++] = L.node_count[q]; }
+    h[3] = (int)at;
+    for (size_t q = 0; q < L.node_rep.size(); ++q) ints[at++] = L.node_rep[q];
+    h[4] = (int)at;
+    for (size_t q = 0; q < L.d_next.size(); ++q) for (int i = 0; i < 3; ++i) ints[at++] = L.d_next[q][i];
+  }
+  ints[8] = (int)at;
+  size_t dat = 0;
+  for (size_t q = 0; q < p.d0_rep.size(); ++q) {
+    const int n = p.d0_rep[q];
+    for (int r = 0; r < B; ++r)
+      for (int c = 0; c < B; ++c) {
+        const long row = (long)n * B + r, col = (long)n * B + c;
+        const bool use = c <= r && row < p.M;
+        ints[at++] = use ? 0 : ((r == c) ? 1 : 2);                 // (c > r: the device reads the mirrored entry)
+        for (int t = 0; t < nt; ++t) dbls[dat++] = use ? sband(p, t, row, col) : 0.0;
+      }
+  }
+  ints[9] = (int)at;
+  for (size_t q = 0; q < p.e0_rep.size(); ++q) {
+    const int n = p.e0_rep[q];
+    for (int r = 0; r < B; ++r)
+      for (int c = 0; c < B; ++c) {
+        const long row = (long)(n + 1) * B + r, col = (long)n * B + c;
+        const bool use = r <= c && row < p.M;
+        ints[at++] = use ? 0 : 2;
+        for (int t = 0; t < nt; ++t) dbls[dat++] = use ? sband(p, t, row, col) : 0.0;
+      }
+  }
+  ints[7] = (int)at;
+  (void)BB;
 }
 
 // Kuu / dKuu entry in fp64 with the reference's rounding sequence (inducing_features.py:16-44; the same sequence as

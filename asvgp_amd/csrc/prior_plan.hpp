@@ -42,6 +42,11 @@ int prior_plan_k(const PriorPlan* p);
 int prior_plan_terms(const PriorPlan* p);
 const int* prior_plan_node_rec(const PriorPlan* p);          // nb ints: record index of every block node (root: n_rec - 1)
 size_t prior_plan_table_doubles(const PriorPlan* p);
+// device image of the plan for the all-GPU (double-double) forward pass of prior_dd.hip; layout in prior_plan.cpp
+constexpr int PRIOR_MAX_CLASSES = 24;                         // node / block classes per level a plan may have
+size_t prior_plan_image_ints(const PriorPlan* p);
+size_t prior_plan_image_doubles(const PriorPlan* p);
+void prior_plan_image(const PriorPlan* p, int* ints, double* dbls);
 // numeric pass for one theta: coef / dcoef = asvgp_matern_coeffs; fills `tab` (host memory); returns the failing column + 1 or 0
 int prior_plan_eval(const PriorPlan* p, const double* coef, const double* dcoef, double* tab);
 

@@ -220,6 +220,16 @@ int asvgp_prior_plan_1d(asvgp_handle_t handle, const double* static_bands_host, 
 size_t asvgp_prior_table_doubles(const double* static_bands_host, int n_terms, int64_t M, int k);
 int asvgp_prior_forward_host(const double* static_bands_host, int n_terms, int64_t M, int k, const double* coef_host,
                              const double* dcoef_dl_host, double* table_host, size_t table_doubles, int* node_rec_host);
+/* Where the forward (elimination) half of the planned Kuu chain runs.  mode 0 (default): on the host in x87 long double, handed over
+ * through the pinned table ring.  mode 1: on the GPU in double-double arithmetic (two-fp64 error-free transforms, ~106 bits; one
+ * small launch in front of the chains' launch on the same stream, table in device memory) - no host stage, no PCIe-mapped table, no
+ * dependence on the host's long double format.  Replaces the factorisation half of gpr.py:56-59 (banded.cholesky_band(Kuu)) either
+ * way; same table (asvgp_prior_forward_host), same consumers.  Needs a plan (asvgp_prior_plan_1d) when an ELBO entry point runs. */
+int asvgp_set_prior_forward(asvgp_handle_t handle, int mode);
+/* The GPU forward pass alone (tests, parity with asvgp_prior_forward_host): the table of the handle's plan for one theta, computed on
+ * `stream` and copied to table_host (asvgp_prior_table_doubles entries); synchronises the stream. */
+int asvgp_prior_forward_device(asvgp_handle_t handle, const double* coef_host, const double* dcoef_dl_host, double* table_host,
+                               size_t table_doubles, void* stream);
 int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                        double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
