@@ -84,7 +84,10 @@ struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]
 // and the few boundary columns' entries are a 2 x 8 x 16 table; both are formed on the host with the reference's rounding sequence and
 // travel as the FIRST kernel argument.  Branch-free: every lane loads its A entry and one table entry (index 0 when interior) - a branch
 // around the boundary case made the compiler wait for every A load separately (12 dependent round trips in level 0, +4 us).
-struct KuuInterior { double k[8]; long lo, hi; double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND]; };
+// dk / dkb: the same for dKuu / dl (the P chain's own traces): interior values and a 2 x (k + 1 = 5) x 8 table of the boundary columns
+// (dk_tab = 1; wider boundaries: dk_tab = 0 and the kernel sums the static bands for those columns) - kernel arguments end at 4 KB
+constexpr int KI_DKB = 8;
+struct KuuInterior { double k[8]; long lo, hi; double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND]; double dk[8]; double dkb[2 * 5 * KI_DKB]; int dk_tab; };
 typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;
 struct BandSumToep {
   const double* A; double inv_s;
@@ -509,31 +512,64 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   if (blockIdx.x == 0) {
     rstamp(1);
-    __shared__ double kdl[8];
-    if (threadIdx.x == 0) { kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4]; }
+    __shared__ double kdl[16];
+    if (threadIdx.x == 0) {
+      kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4];
+      kdl[8] = ki.dk[0]; kdl[9] = ki.dk[1]; kdl[10] = ki.dk[2]; kdl[11] = ki.dk[3]; kdl[12] = ki.dk[4];
+    }
     __syncthreads();
     // (ki is kernel argument 0: its boundary table is read in place, from the kernel-argument segment)
     const double* bnd = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
+    const double* dkb = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, dkb));
     bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1);
     rstamp(3);
-    wait_assembled();                                          // (the helpers' Kuu / dKuu: needed from here on, long there; its barrier also orders SP, x)
-    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
+    __syncthreads();                                           // (orders SP, the solve's last global stores, for the loop below)
     rstamp(4);
     if (fin.finalize) {
-      for (long j = threadIdx.x; j < M; j += blockDim.x) {
+      // The P chain's traces and quadratic forms WITHOUT the helpers' bands (no wait, no loads from another XCD's L2): Kuu and dKuu / dl in
+      // closed form (interior: one number per diagonal, kdl; the few boundary columns: the kernel-argument table for Kuu, a sum over the
+      // static bands for dKuu), x from the solve's LDS image.  Loads left per column: SP (5), the A band (5), b (1).
+      const double* xs_l = lds + (size_t)2 * ((((M + K - 1) / K) + 1) / 2 + 1) * 16;   // bcr_mfma_solve's xs (rows beyond M: 0)
+      // (M <= 2048: two columns per thread, tid and tid + 1024; ALL their loads are issued before the first use - as a plain loop the
+      //  second column's round trip started after the first column's arithmetic)
+      static_assert(BM_THREADS == 1024, "two columns per thread");
+      double sp[2][K + 1], av[2][K + 1], bj[2];
+#pragma unroll
+      for (int cI = 0; cI < 2; ++cI) {
+        const long j = (long)threadIdx.x + cI * BM_THREADS, jc = j < M ? j : M - 1;
+#pragma unroll
+        for (int r = 0; r <= K; ++r) { sp[cI][r] = SP[(long)r * M + jc]; av[cI][r] = stats[(long)r * M + jc]; }
+        bj[cI] = stats[(long)(K + 1) * M + jc];
+      }
+#pragma unroll
+      for (int cI = 0; cI < 2; ++cI) {
+        const long j = (long)threadIdx.x + cI * BM_THREADS;
+        if (j >= M) continue;
+        const bool left = j < ki.lo, right = j >= ki.hi;
+        const double xj = xs_l[j];
 #pragma unroll
         for (int r = 0; r <= K; ++r) {
           const long o = (long)r * M + j;
           const double w2 = (r == 0) ? 1.0 : 2.0;
-          const double sp = SP[o];
-          acc[SPDK] = fma(w2 * sp, dK[o], acc[SPDK]);
-          acc[SPK] = fma(w2 * sp, Kuu[o], acc[SPK]);
-          acc[SPA] = fma(w2 * sp, stats[o], acc[SPA]);
+          double kv = kdl[r], dkv = kdl[8 + r];
+          if (left || right) {                                 // (rare: at most PRIOR_BND columns on either side)
+            kv = bnd[left ? (long)r * PRIOR_BND + j : (long)(PRIOR_BND_DIAGS + r) * PRIOR_BND + (j - ki.hi)];
+            if (ki.dk_tab) {
+              dkv = dkb[left ? (long)r * KI_DKB + j : (long)(5 + r) * KI_DKB + (j - ki.hi)];
+            } else {                                           // (five dependent trips to the static bands: ~5 us on the launch's tail)
+              dkv = 0.0;
+              for (int t = 0; t < cf.n; ++t) dkv = fma(cf.dc[t], S_static[(long)t * E + o], dkv);
+            }
+          }
+          const double xx = (j + r < M) ? w2 * xj * xs_l[j + r] : 0.0;   // (below the matrix: the band entries there are 0 as well)
+          acc[SPDK] = fma(w2 * sp[cI][r], dkv, acc[SPDK]);
+          acc[SPK] = fma(w2 * sp[cI][r], kv, acc[SPK]);
+          acc[SPA] = fma(w2 * sp[cI][r], av[cI][r], acc[SPA]);
+          acc[AKA] = fma(kv, xx, acc[AKA]);
+          acc[ADKA] = fma(dkv, xx, acc[ADKA]);
+          acc[AAA] = fma(av[cI][r], xx, acc[AAA]);
         }
-        acc[AKA] += quad_col<K>(Kuu, M, j, x, 1, 0);
-        acc[ADKA] += quad_col<K>(dK, M, j, x, 1, 0);
-        acc[AAA] += quad_col<K>(stats, M, j, x, 1, 0);
-        acc[BA] = fma(stats[(long)(K + 1) * M + j], x[j], acc[BA]);
+        acc[BA] = fma(bj[cI], xj, acc[BA]);
       }
     }
   } else {
@@ -726,6 +762,16 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
       if (use_mfma) {
         prior_plan_interior_kuu(h->plan, cf.c, ki.k, &ki.lo, &ki.hi, ki.bnd);   // Kuu in closed form for the P chain's level-0 loads
         use_mfma = ki.hi > ki.lo;                                                // (none: the older kernel, which waits for the assembled band)
+        if (use_mfma) {                                                          // dKuu / dl on the interior, for the P chain's own traces
+          double bnd2[2 * PRIOR_BND_DIAGS * PRIOR_BND];
+          long lo2 = 0, hi2 = 0;
+          prior_plan_interior_kuu(h->plan, cf.dc, ki.dk, &lo2, &hi2, bnd2);
+          ki.dk_tab = (ki.lo <= KI_DKB && M - ki.hi <= KI_DKB) ? 1 : 0;
+          for (int sd = 0; sd < 2; ++sd)
+            for (int d = 0; d <= K; ++d)
+              for (int cI = 0; cI < KI_DKB; ++cI)
+                ki.dkb[(sd * 5 + d) * KI_DKB + cI] = bnd2[(size_t)(sd * PRIOR_BND_DIAGS + d) * PRIOR_BND + cI];
+        }
       }
     }
     if (algo == 4 && !use_mfma) {

@@ -47,6 +47,7 @@ struct Handle {
   // forward pass on the GPU in double-double (asvgp_set_prior_forward(h, 1); prior_dd.hip): device image of the plan, device table ring
   bool prior_forward_gpu = false;
   int* dd_img_i = nullptr;
+  int dd_n_img = 0;
   double* dd_img_d = nullptr;
   double* dd_tab = nullptr;               // TAB_SLOTS x slot_doubles, device memory (slot numbering shared with the pinned ring)
   // result mirror (asvgp_result_mirror): 16 pinned doubles the fused launch's last ticket writes [out[0..7], info[0], info[1], sequence]
@@ -84,7 +85,7 @@ void handle_publish_forward(Handle* h);
 // device table ring (*tab_out); the consumer is launched behind it on the same stream and needs no ready word
 int handle_prior_dd_prepare(Handle* h);
 void handle_prior_dd_release(Handle* h);
-int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out);
+int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out, unsigned long long* stamps = nullptr);
 
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);

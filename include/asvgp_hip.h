@@ -230,6 +230,8 @@ int asvgp_set_prior_forward(asvgp_handle_t handle, int mode);
  * `stream` and copied to table_host (asvgp_prior_table_doubles entries); synchronises the stream. */
 int asvgp_prior_forward_device(asvgp_handle_t handle, const double* coef_host, const double* dcoef_dl_host, double* table_host,
                                size_t table_doubles, void* stream);
+/* Diagnostics: s_memtime stamps of thread 0 along one GPU forward pass (out64: 64 values, [63] = how many; tools/prior_dd_probe.py). */
+int asvgp_prior_forward_stamps(asvgp_handle_t handle, const double* coef_host, const double* dcoef_dl_host, uint64_t* out64, void* stream);
 int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                        double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);

@@ -41,6 +41,12 @@ for _ in range(200):
     h.prior_forward_device(cn, dcn, 20000)
 dt = (time.perf_counter() - t0) / 200 * 1e6
 print("asvgp_prior_forward_device (kernel + 13 KB copy back + stream synchronise): %.1f us per call" % dt)
+st = np.zeros(64, dtype=np.uint64)
+lib.asvgp_prior_forward_stamps(h.ptr, cn.ctypes.data, dcn.ctypes.data, st.ctypes.data, _lib.stream_ptr())
+lib.asvgp_prior_forward_stamps(h.ptr, cn.ctypes.data, dcn.ctypes.data, st.ctypes.data, _lib.stream_ptr())
+ns = int(st[63]); t = (st[:ns] - st[0]).astype(np.int64)
+print("stamps (100 MHz ticks -> us) of thread 0, %d of them: %s" % (ns, " ".join("%.2f" % (v / 100) for v in t)))
+print("  [0 start, 1 class maps in the LDS, 2 level-0 blocks, then per level: classes done, barrier, next-level blocks; level 1 adds 4 inner stamps (loaded, factored, solved, products); last two: before the log-det reduce, end]")
 for mode in (0, 1):
     h.set_prior_forward(mode)
     us, enq = timed(model._launch_elbo)
