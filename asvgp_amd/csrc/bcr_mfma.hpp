@@ -90,12 +90,31 @@ struct BmLog {
   }
 };
 
+// TWO workgroups on one matrix (the fused ELBO launch at nb >= 128).  The last level's node ht = 2^(levels - 1) separates the elimination
+// tree into the nodes below it (left) and above it (right), which meet nowhere else: workgroup `half` = 0 eliminates the left nodes of
+// the levels below the top, workgroup 1 the right ones - half the rounds on the wide, throughput-bound levels 0..2 -, each keeping its
+// own share of the separator's pivot block and right-hand side (left: minus the updates from its side, starting from zero; right: the
+// band's block minus the updates from its side).  Right hands its share over (22 doubles, with its log-det part and first bad column),
+// left adds it, eliminates the separator and the root, runs the top backward level and hands the separator's backward record and
+// solution back (52 doubles); both then walk their halves down.  Same arithmetic as one workgroup, node by node.  Payloads and flags
+// are agent-scope accesses (no fences: the two workgroups sit in different XCDs); the waits are bounded (*gave_up, then return).
+struct BmSplit {
+  int half = -1;                 // -1: the whole matrix in this workgroup
+  double* xchg = nullptr;        // 96 doubles
+  unsigned* flag_rl = nullptr;   // right -> left   (re-armed by the caller after both workgroups are through)
+  unsigned* flag_lr = nullptr;   // left -> right
+  long spin_limit = 0;
+  int* gave_up = nullptr;        // LDS word of the caller
+};
+constexpr int BM_XCHG = 96;
+
 // The whole solve for one matrix, called by all BM_THREADS threads of one workgroup.
 //   A: lower band (5, M) source (BandPtr<double> or BandSumP);  rhs: (M) with stride rhs_stride;  ws: bcr_mfma_ws_doubles;
 //   lds: bcr_mfma_lds_doubles.  Out: S lower band of A^-1 (5, M), x = A^-1 rhs, logdet[0], info (first bad column + 1).
 template <typename Src>
 __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const double* rhs, int M, double* ws, double* lds, double* Sband, double* x,
-                                                              double* logdet, int* info, int rhs_stride = 1, double* stamps = nullptr) {
+                                                              double* logdet, int* info, int rhs_stride = 1, double* stamps = nullptr,
+                                                              BmSplit sp = BmSplit{}) {
   constexpr int B = BM_B;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,6 +132,33 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   double* Sl = lds;                                               // backward records (Sigma_ii, C_a^T, C_b^T) of nodes i = 4 j (levels >= 2): [j][48]
   int levels = 0;
   while ((1 << levels) < nb) ++levels;
+  const bool split = sp.half >= 0;                                // (the caller splits only trees of >= 7 levels)
+  const int top = levels - 1, ht = 1 << (top > 0 ? top : 0);      // the separator: the last level's only node
+  double s_other = 0.0;                                           // left: the right workgroup's log-det part and first bad column
+  int bad_other = 0x7fffffff;
+  // members of the level l for this workgroup: nodes i = h + (m0 + m) 2 h, m < ne_h
+  auto level_share = [&](int l, int ne, int& m0, int& ne_h) {
+    m0 = 0; ne_h = ne;
+    if (!split) return;
+    if (l < top) {
+      const int mL = ht >> (l + 1);
+      if (sp.half == 0) ne_h = ne < mL ? ne : mL;
+      else { m0 = mL; ne_h = ne > mL ? ne - mL : 0; }
+    } else {
+      ne_h = sp.half == 0 ? ne : 0;
+    }
+  };
+  auto wait_flag = [&](unsigned* flag) -> bool {                 // all threads; false: gave up
+    if (tid == 0) {
+      long spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > sp.spin_limit) { *sp.gave_up = 1; break; }
+      }
+    }
+    __syncthreads();
+    return *sp.gave_up == 0;
+  };
   int bad = 0;
   BmLog ld{1.0, 0};
   unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -137,11 +183,15 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   };
   // ---- pre-pass: rhs -> xs.  (The even nodes' D blocks reach the LDS in level 0, from the band slab of their odd neighbour; only a last
   // even node without one - nb odd - is fetched here.)
-  if ((nb & 1) && tid < 16) {
+  if ((nb & 1) && tid < 16 && !(split && sp.half == 0)) {
     const int rr = tid >> 2, cc = tid & 3;
     Dl[(size_t)((nb - 1) >> 1) * 16 + tid] = bandD(nb - 1, rr > cc ? rr : cc, rr > cc ? cc : rr);
   }
-  for (int row = tid; row < nb * B; row += BM_THREADS) xs[row] = (row < M) ? rhs[(long)row * rhs_stride] : 0.0;
+  if (split && sp.half == 0 && tid < 16) Dl[(size_t)(ht >> 1) * 16 + tid] = 0.0;   // left's share of the separator: only the updates
+  for (int row = tid; row < nb * B; row += BM_THREADS) {
+    const bool sep_left = split && sp.half == 0 && row >= ht * B && row < (ht + 1) * B;
+    xs[row] = (row < M && !sep_left) ? rhs[(long)row * rhs_stride] : 0.0;
+  }
   __syncthreads();
   stamp();
 
@@ -150,6 +200,42 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   for (int l = 0; l < levels; ++l) {
     const int h = 1 << l;
     const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
+    int m0, ne_h;
+    level_share(l, ne, m0, ne_h);
+    if (split && l == top) {
+      // ---- right -> left: the separator's pivot block and right-hand side as the right half leaves them, its log-det part, its bad column
+      if (sp.half == 1) {
+        // (the record stores of the levels 0..2 are long done: the barrier's vmcnt drain costs nothing here)
+        if (tid < 16) __hip_atomic_store(sp.xchg + tid, Dl[(size_t)(ht >> 1) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= 16 && tid < 20) __hip_atomic_store(sp.xchg + tid, xs[ht * B + tid - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                          // (drains the stores: hipcc waits on vmcnt before the barrier)
+        if (tid == 0) __hip_atomic_store(sp.flag_rl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // behind the flag, off the left workgroup's critical path (it reads them at its very end, flag value 2): log-det part, bad column
+        const double mine = (r == 0 && c == 0) ? (log(ld.m) + (double)ld.e * 0.6931471805599453094) : 0.0;
+        const double tot = wave_sum_dpp(mine);
+        int bm = bad ? bad : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(bm, off, 64); bm = o < bm ? o : bm; }
+        int* sbad = reinterpret_cast<int*>(red + 32);
+        if (lane == 0) { red[wv] = tot; sbad[wv] = bm; }
+        __syncthreads();
+        if (tid == 0) {
+          double s = 0.0;
+          int bmin = 0x7fffffff;
+          for (int w2 = 0; w2 < BM_THREADS / 64; ++w2) { s += red[w2]; bmin = sbad[w2] < bmin ? sbad[w2] : bmin; }
+          __hip_atomic_store(sp.xchg + 20, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp.xchg + 21, (double)bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(sp.flag_rl, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        if (!wait_flag(sp.flag_rl)) return;
+        if (tid < 16) Dl[(size_t)(ht >> 1) * 16 + tid] += __hip_atomic_load(sp.xchg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= 16 && tid < 20) xs[ht * B + tid - 16] += __hip_atomic_load(sp.xchg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+      stamp();
+    }
     double updb[RMAXR], ybu[RMAXR];
     int qv = q, ev = e;                                           // (opaque per level: the slab addresses are then recomputed here instead of being
     asm volatile("" : "+v"(qv), "+v"(ev));                        //  hoisted out of the level loop as 64-bit pointers and spilled)
@@ -163,7 +249,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
         for (int t3 = 0; t3 < 3; ++t3) {
           sl[u][t3] = 0.0;
           int m = (rd0 + u) * 64 + wv * 4 + qv;
-          m = m < ne ? m : ne - 1;
+          m = m0 + (m < ne_h ? m : ne_h - 1);
           const int kk = ev + 16 * t3, dd = kk >> 3, col = m * 2 * B + (kk & 7);
           const bool in = kk < 40 && col + dd < M;
           const double v = bm_src_load(A, in ? dd : 0, in ? col : 0, (long)M, 0);   // (unconditional, clamped)
@@ -176,13 +262,13 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
       __builtin_amdgcn_sched_barrier(0);                          // (rounds one after the other: interleaved they do not fit 128 registers)
       if (l == 0 && (rd & 1) == 0) slab_loads(rd);                // two rounds' slabs per memory round trip
       updb[rd] = 0.0; ybu[rd] = 0.0;
-      if (rd * 64 + wv * 4 >= ne) continue;                       // (wave-uniform) a wave without a node goes straight to the barrier:
+      if (rd * 64 + wv * 4 >= ne_h) continue;                     // (wave-uniform) a wave without a node goes straight to the barrier:
                                                                   // on dummy data it would take three of four issue slots from the working wave of its SIMD
-      const int m = rd * 64 + wv * 4 + q;
-      const bool act = m < ne;
+      const int ml = rd * 64 + wv * 4 + q;
+      const bool act = ml < ne_h;
       // a slot without a node repeats the level's last node (unconditional loads, no per-value predication - as branches around every
       // load they cost more scalar instructions than the arithmetic) and keeps its results to itself
-      const int i = h + (act ? m : ne - 1) * 2 * h, a = i - h, b = i + h;
+      const int i = h + (m0 + (act ? ml : ne_h - 1)) * 2 * h, a = i - h, b = i + h;
       const bool hasb = b < nb;
       const int bsafe = hasb ? b : a;
       // every lane of the node: the whole pivot block
@@ -257,10 +343,10 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
     bcr_lds_barrier();                                            // (LDS traffic only: the record stores are re-read by the same lanes, much later)
 #pragma unroll
     for (int rd = 0; rd < RMAXR; ++rd) {                           // phase B: right neighbour
-      if (rd * 64 + wv * 4 >= ne) continue;
-      const int m = rd * 64 + wv * 4 + q;
-      const int i = h + m * 2 * h, b = i + h;
-      if (m < ne && b < nb) {
+      if (rd * 64 + wv * 4 >= ne_h) continue;
+      const int ml = rd * 64 + wv * 4 + q;
+      const int i = h + (m0 + ml) * 2 * h, b = i + h;
+      if (ml < ne_h && b < nb) {
         Dl[(size_t)(b >> 1) * 16 + e] -= updb[rd];
         if (c == 0) xs[b * B + r] -= ybu[rd];
       }
@@ -269,7 +355,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
     stamp();
   }
   // ---------------- root (node 0) ----------------
-  if (wv == 0) {
+  if (wv == 0 && !(split && sp.half == 1)) {
     const bool act = q == 0;
     double d[10];
     int kk = 0;
@@ -300,13 +386,15 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   for (int l = levels - 1; l >= 0; --l) {
     const int h = 1 << l;
     const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
+    int m0, ne_h;
+    level_share(l, ne, m0, ne_h);
 #pragma unroll
     for (int rd = 0; rd < RMAXR; ++rd) {
       __builtin_amdgcn_sched_barrier(0);
-      if (rd * 64 + wv * 4 >= ne) continue;
-      const int m = rd * 64 + wv * 4 + q;
-      const bool act = m < ne;
-      const int i = h + (act ? m : ne - 1) * 2 * h, a = i - h, b = i + h;   // (a slot without a node repeats the last node, as in the forward pass)
+      if (rd * 64 + wv * 4 >= ne_h) continue;
+      const int ml = rd * 64 + wv * 4 + q;
+      const bool act = ml < ne_h;
+      const int i = h + (m0 + (act ? ml : ne_h - 1)) * 2 * h, a = i - h, b = i + h;   // (a slot without a node repeats the last node, as in the forward pass)
       const bool hasb = b < nb;
       const int bs = hasb ? b : a;
       const bool e_is_a = ((a / (2 * h)) & 1) != 0;               // which of a, b was eliminated at level l + 1
@@ -367,16 +455,43 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
       }
     }
     if (l == 1) __syncthreads(); else bcr_lds_barrier();           // level 0 reads the workspace records of the levels above: drained here
+    if (split && l == top) {
+      // ---- left -> right: the separator's backward record (Sigma_ii, C_a^T, C_b^T) and solution
+      double* Rs = Sl + (size_t)(ht >> 2) * 48;
+      if (sp.half == 0) {
+        if (tid < 48) __hip_atomic_store(sp.xchg + 32 + tid, Rs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= 48 && tid < 52) __hip_atomic_store(sp.xchg + 32 + tid, xs[ht * B + tid - 48], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sp.flag_lr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (!wait_flag(sp.flag_lr)) return;
+        if (tid < 48) {
+          const double v = __hip_atomic_load(sp.xchg + 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          Rs[tid] = v;
+          rec(ht)[BM_SD + tid] = v;                               // (its level-0 neighbour reads the workspace record: this workgroup's own copy)
+          if (tid < 16) {                                         // ... and this workgroup's traces read the separator's diagonal block of the band
+            const int rr = tid >> 2, cc = tid & 3;
+            if (rr >= cc && ht * B + rr < M) Sband[(long)(rr - cc) * M + ht * B + cc] = v;
+          }
+        }
+        if (tid >= 48 && tid < 52) xs[ht * B + tid - 48] = __hip_atomic_load(sp.xchg + 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+    }
     stamp();
   }
   // ---------------- outputs ----------------
-  for (int col = M - B + tid; col < M; col += BM_THREADS)
-    if (col >= 0)
+  if (!(split && sp.half == 0))
+    for (int col = M - B + tid; col < M; col += BM_THREADS)
+      if (col >= 0)
 #pragma unroll
-      for (int dd = 1; dd <= B; ++dd)
-        if (col + dd >= M) Sband[(long)dd * M + col] = 0.0;
-  for (int row = tid; row < M; row += BM_THREADS) x[(long)row * rhs_stride] = xs[row];
+        for (int dd = 1; dd <= B; ++dd)
+          if (col + dd >= M) Sband[(long)dd * M + col] = 0.0;
   {
+    const int row0 = (split && sp.half == 1) ? (ht + 1) * B : 0, row1 = (split && sp.half == 0) ? (ht + 1) * B : M;
+    for (int row = row0 + tid; row < row1 && row < M; row += BM_THREADS) x[(long)row * rhs_stride] = xs[row];
+  }
+  if (!(split && sp.half == 1)) {
     // log|A| = 2 sum log diag(L): every node's lanes carried the same product; lane (0, q, 0) of each wave speaks for its nodes
     const double mine = (r == 0 && c == 0) ? (log(ld.m) + (double)ld.e * 0.6931471805599453094) : 0.0;
     const double tot = wave_sum_dpp(mine);
@@ -390,6 +505,15 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
       double s = 0.0;
       int bmin = 0x7fffffff;
       for (int w2 = 0; w2 < BM_THREADS / 64; ++w2) { s += red[w2]; bmin = sbad[w2] < bmin ? sbad[w2] : bmin; }
+      if (split) {                                                // the right workgroup's part (published tens of microseconds ago: flag value 2)
+        long spins = 0;
+        while (__hip_atomic_load(sp.flag_rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u && ++spins <= sp.spin_limit) __builtin_amdgcn_s_sleep(1);
+        if (spins > sp.spin_limit) *sp.gave_up = 1;
+        s_other = __hip_atomic_load(sp.xchg + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad_other = (int)__hip_atomic_load(sp.xchg + 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s += s_other;                                               // (the right workgroup's nodes)
+      bmin = bad_other < bmin ? bad_other : bmin;
       // (agent-scope stores: the fused launch's last ticket may read them from another XCD, where a plain store would still be a dirty L2 line)
       __hip_atomic_store(logdet + 0, 2.0 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(logdet + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -92,7 +92,9 @@ typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;
 struct BandSumToep {
   const double* A; double inv_s;
   lds_cdouble_ptr kl;                     // the interior diagonal values, in the LDS (a five-way select between struct members by a run-time
-  const double* bnd;                      // diagonal was turned into address arithmetic on a scratch copy of the struct); bnd: kernarg segment
+  lds_cdouble_ptr bnd;                    // diagonal was turned into address arithmetic on a scratch copy of the struct); bnd: the boundary table,
+                                          // copied from the kernel-argument segment to the LDS once (a vector load from that segment in front of
+                                          // level 0 cost ~3 us: it is not device memory)
   long lo, hi;
   __device__ __forceinline__ double load_dc(int dd, long col, long M) const {
 #pragma clang fp contract(off)
@@ -378,7 +380,10 @@ struct FusedFin {
   const double* stats; ElboScalars th; double alpha_scale; double* gacc; unsigned* ticket; unsigned* arrived; unsigned* assembled; double* out;
   long D; int n_helpers; int finalize; int debug_no_assembly; int debug_stamps;
   double* mirror; unsigned long long mirror_seq;   // asvgp_result_mirror (matrix-core launch only)
+  // matrix-core launch, P chain on TWO workgroups (bcr_mfma.hpp BmSplit): workgroup 2 is the right half, the helpers start at 3
+  int split; double* xchg; unsigned* flag_rl; unsigned* flag_lr;
 };
+constexpr int FIN_GACC_PR = 21;                    // the right P workgroup's seven partial sums: gacc[21..27]
 __device__ __forceinline__ void assemble_band_slice(const double* __restrict__ S, const double* __restrict__ coef, const double* __restrict__ dcoef, int n_terms,
                                                     long E, long e, double* __restrict__ Kuu, double* __restrict__ dK) {
 #pragma clang fp contract(off)
@@ -480,8 +485,9 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       logdets[(slot < 4 ? 8 + 4 * (int)blockIdx.x : 24) + slot] = (slot == 0) ? (double)(t_start & 0xffffffffull) : (double)((__builtin_amdgcn_s_memrealtime() - t_start) & 0xffffffffull);
   };
   rstamp(0);
-  if (blockIdx.x >= 2) {                                       // helpers: Kuu, dKuu/dl (theta-only), then gone
-    for (long e = (long)(blockIdx.x - 2) * blockDim.x + threadIdx.x; e < E; e += (long)fin.n_helpers * blockDim.x)
+  const int nsplit = fin.split ? 1 : 0;
+  if ((int)blockIdx.x >= 2 + nsplit) {                         // helpers: Kuu, dKuu/dl (theta-only), then gone
+    for (long e = (long)((int)blockIdx.x - 2 - nsplit) * blockDim.x + threadIdx.x; e < E; e += (long)fin.n_helpers * blockDim.x)
       assemble_band_slice(S_static, cf.c, cf.dc, cf.n, E, e, Kuu, dK);
     __syncthreads();
     if (threadIdx.x == 0 && fin.debug_no_assembly == 0) {
@@ -510,20 +516,30 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  if (blockIdx.x == 0) {
+  const bool isP = blockIdx.x == 0 || (fin.split && blockIdx.x == 2);
+  const bool isPR = fin.split && blockIdx.x == 2;
+  if (isP) {
     rstamp(1);
     __shared__ double kdl[16];
+    __shared__ double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND], dkb[2 * 5 * KI_DKB];
     if (threadIdx.x == 0) {
       kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4];
       kdl[8] = ki.dk[0]; kdl[9] = ki.dk[1]; kdl[10] = ki.dk[2]; kdl[11] = ki.dk[3]; kdl[12] = ki.dk[4];
     }
+    {   // (ki is kernel argument 0: its tables are read in place, from the kernel-argument segment, ONCE)
+      const double* bnd_g = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
+      const double* dkb_g = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, dkb));
+      if (threadIdx.x < 2 * PRIOR_BND_DIAGS * PRIOR_BND) bnd[threadIdx.x] = bnd_g[threadIdx.x];
+      else if (threadIdx.x < 2 * PRIOR_BND_DIAGS * PRIOR_BND + 2 * 5 * KI_DKB) dkb[threadIdx.x - 2 * PRIOR_BND_DIAGS * PRIOR_BND] = dkb_g[threadIdx.x - 2 * PRIOR_BND_DIAGS * PRIOR_BND];
+    }
     __syncthreads();
-    // (ki is kernel argument 0: its boundary table is read in place, from the kernel-argument segment)
-    const double* bnd = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
-    const double* dkb = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, dkb));
-    bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1);
+    BmSplit bsp;
+    if (fin.split) { bsp.half = isPR ? 1 : 0; bsp.xchg = fin.xchg; bsp.flag_rl = fin.flag_rl; bsp.flag_lr = fin.flag_lr; bsp.spin_limit = spin_limit; bsp.gave_up = &gave_up; }
+    bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, (lds_cdouble_ptr)bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1, 1,
+                                fin.debug_stamps ? (isPR ? fin.xchg + 128 : logdets + 32) : (double*)nullptr, bsp);   // (per-level cycle stamps: tools/mside_probe.py)
     rstamp(3);
     __syncthreads();                                           // (orders SP, the solve's last global stores, for the loop below)
+    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }   // (the other half never answered: sticky, like the helpers' case)
     rstamp(4);
     if (fin.finalize) {
       // The P chain's traces and quadratic forms WITHOUT the helpers' bands (no wait, no loads from another XCD's L2): Kuu and dKuu / dl in
@@ -533,18 +549,23 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       // (M <= 2048: two columns per thread, tid and tid + 1024; ALL their loads are issued before the first use - as a plain loop the
       //  second column's round trip started after the first column's arithmetic)
       static_assert(BM_THREADS == 1024, "two columns per thread");
+      // two P workgroups: the left one takes the columns below the separator node's (it holds x up to the separator), the right one the rest
+      int nbl = (M + K - 1) / K, lv = 0;
+      while ((1 << lv) < nbl) ++lv;
+      const long jsep = (long)(1 << (lv > 0 ? lv - 1 : 0)) * K;
+      const long j0 = isPR ? jsep : 0, j1 = (fin.split && !isPR) ? jsep : (long)M;
       double sp[2][K + 1], av[2][K + 1], bj[2];
 #pragma unroll
       for (int cI = 0; cI < 2; ++cI) {
-        const long j = (long)threadIdx.x + cI * BM_THREADS, jc = j < M ? j : M - 1;
+        const long j = j0 + threadIdx.x + cI * BM_THREADS, jc = j < j1 ? j : j1 - 1;
 #pragma unroll
         for (int r = 0; r <= K; ++r) { sp[cI][r] = SP[(long)r * M + jc]; av[cI][r] = stats[(long)r * M + jc]; }
         bj[cI] = stats[(long)(K + 1) * M + jc];
       }
 #pragma unroll
       for (int cI = 0; cI < 2; ++cI) {
-        const long j = (long)threadIdx.x + cI * BM_THREADS;
-        if (j >= M) continue;
+        const long j = j0 + threadIdx.x + cI * BM_THREADS;
+        if (j >= j1) continue;
         const bool left = j < ki.lo, right = j >= ki.hi;
         const double xj = xs_l[j];
 #pragma unroll
@@ -595,12 +616,11 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
     }
   }
   if (!fin.finalize) { rstamp(2); return; }
-  if (blockIdx.x == 0) rstamp(5);
+  if (isP) rstamp(5);
   // ---- workgroup sums -> this chain's own slots (agent-scope stores: two writers, disjoint slots, no atomic adds) -> ticket; the last
   // ticket evaluates the bound (elbo_finalize_body's formulas).  Only the accumulators this chain owns are reduced.
   double* part0 = lds;                                         // [wave][8] wave totals
   const int lane = threadIdx.x & 63;
-  const bool isP = blockIdx.x == 0;
   double mine[8];
   mine[0] = isP ? acc[SPDK] : acc[TRKA];
   mine[1] = isP ? acc[SPK] : acc[DTRKA];
@@ -635,21 +655,23 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
 #pragma unroll
   for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
   if (threadIdx.x != 0) return;
-  if (blockIdx.x == 0) rstamp(6);
-  double* slot = fin.gacc + (isP ? 0 : 8);                     // P: gacc[0..6], Kuu: gacc[8..11]
+  if (isP) rstamp(6);
+  double* slot = fin.gacc + (isPR ? FIN_GACC_PR : (isP ? 0 : 8));   // P (left / whole): gacc[0..6], Kuu: gacc[8..11], P right: gacc[21..27]
 #pragma unroll
   for (int i = 0; i < 7; ++i)
     if (i < nmine) __hip_atomic_store(slot + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drained before the ticket; agent-scope accesses on both sides: no fences)
   const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t != 1u) { rstamp(2); return; }
-  tot[SPDK] = __hip_atomic_load(fin.gacc + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[SPK] = __hip_atomic_load(fin.gacc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[SPA] = __hip_atomic_load(fin.gacc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[AKA] = __hip_atomic_load(fin.gacc + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[ADKA] = __hip_atomic_load(fin.gacc + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[AAA] = __hip_atomic_load(fin.gacc + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[BA] = __hip_atomic_load(fin.gacc + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != (fin.split ? 2u : 1u)) { rstamp(2); return; }
+  {
+    const int pidx[7] = {SPDK, SPK, SPA, AKA, ADKA, AAA, BA};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double v = __hip_atomic_load(fin.gacc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fin.split) v += __hip_atomic_load(fin.gacc + FIN_GACC_PR + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot[pidx[i]] = v;
+    }
+  }
   tot[TRKA] = __hip_atomic_load(fin.gacc + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   tot[DTRKA] = __hip_atomic_load(fin.gacc + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   tot[SKDK] = __hip_atomic_load(fin.gacc + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -658,6 +680,12 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   for (int i = 0; i < 12; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels add into these slots)
   __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fin.split) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) __hip_atomic_store(fin.gacc + FIN_GACC_PR + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fin.flag_rl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (both P workgroups have drawn their tickets: past their waits)
+    __hip_atomic_store(fin.flag_lr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   {
     const double v = fin.th.v, sn = fin.th.s, N = fin.th.N;
     const double yy = stats[(long)(K + 1) * M + M];
@@ -665,7 +693,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
     tot[AKA] *= asc * asc; tot[ADKA] *= asc * asc; tot[AAA] *= asc * asc; tot[BA] *= asc;
     // the log-determinants were written by the two chains' lane 0 before their atomics (same lanes: program order + the drain above)
     tot[LOGK] = __hip_atomic_load(logdets + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tot[LOGP] = __hip_atomic_load(logdets + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[LOGP] = __hip_atomic_load(logdets + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (two P workgroups: the left one has added the right one's part)
     tot[CC] = tot[BA] / sn;
     const double two_pi = 6.283185307179586476925286766559;
     double elbo = -0.5 * N * log(two_pi * sn);
@@ -803,6 +831,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     // chains' ~100 KB of LDS, i.e. a CU of its own; with 10 workgroups two of them shared an XCD, and the second ELBO launch of the
     // in-flight schedule found no free CU there for a helper - its P chain then waited for the whole previous launch to finish
     ff.n_helpers = (int)((M + 255) / 256 < 6 ? (M + 255) / 256 : 6);
+    ff.split = 0; ff.xchg = nullptr; ff.flag_rl = ff.flag_lr = nullptr;
     ff.assembled = reinterpret_cast<unsigned*>(w.fin + 20);
     ff.debug_no_assembly = debug_env().no_assembly;
     ff.debug_stamps = debug_env().chain_stamps;   // test hook: the helpers never report -> the P chain gives up waiting
@@ -821,6 +850,14 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
           granted = lb;
         }
         if (h->mirror_dev) { ff.mirror = h->mirror_dev; ff.mirror_seq = ++h->mirror_seq; h->mirror_pending = ff.mirror_seq; }
+        // the P chain on two workgroups where its wide levels are throughput-bound (bcr_mfma.hpp BmSplit); 8 workgroups in all, one per XCD
+        if (nb >= 128 && !debug_env().no_split) {
+          ff.split = 1;
+          ff.xchg = w.LP;                                      // (the sequential sweeps' factor band: unused by this launch)
+          ff.flag_rl = reinterpret_cast<unsigned*>(w.fin + 28);
+          ff.flag_lr = reinterpret_cast<unsigned*>(w.fin + 29);
+          if (ff.n_helpers > 5) ff.n_helpers = 5;
+        }
         // The launch goes out FIRST: its ~8 us of dispatch latency, the helpers' assembly and the P chain (which needs only Kuu, not its
         // factors) run while this thread does the forward pass below; the Kuu workgroup waits on ready[slot] (bcr_mfma_backward_pre).
         const bool plan_first = debug_env().plan_first != 0;   // (measurement aid: the round-2 order, forward pass then launch)
@@ -828,7 +865,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
         const double t0 = host_times ? now_us() : 0.0;
         if (plan_first && !gpu_fwd) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
-        hipLaunchKernelGGL(kern, dim3(2 + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
+        hipLaunchKernelGGL(kern, dim3(2 + ff.split + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                            tab_k, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
                            (plan_first || gpu_fwd) ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
         if (gpu_fwd) return check_launch("elbo chains (matrix cores, forward pass on the GPU)");

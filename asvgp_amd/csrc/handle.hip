@@ -20,6 +20,7 @@ static void debug_env_load() {
   g_dbg.host_times = getenv("ASVGP_HOST_TIMES") ? 1 : 0;
   g_dbg.plan_first = getenv("ASVGP_PLAN_FIRST") ? 1 : 0;
   g_dbg.bcr_stamps = getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0;
+  g_dbg.no_split = getenv("ASVGP_NO_SPLIT") ? atoi(getenv("ASVGP_NO_SPLIT")) : 0;   // the matrix-core P chain on ONE workgroup (measurement aid)
   g_dbg_loaded = true;
 }
 const DebugEnv& debug_env() {

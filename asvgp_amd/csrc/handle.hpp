@@ -63,7 +63,7 @@ struct Handle {
 
 // Debug / measurement switches from the environment, read ONCE (a getenv per launch costs microseconds where the environment is large)
 // and again on asvgp_debug_reload_env() - the tests that flip them call that.
-struct DebugEnv { int no_assembly; int chain_stamps; long spin_limit; int host_times; int plan_first; int bcr_stamps; };
+struct DebugEnv { int no_assembly; int chain_stamps; long spin_limit; int host_times; int plan_first; int bcr_stamps; int no_split; };
 const DebugEnv& debug_env();
 
 Handle* as_handle(asvgp_handle_t h);      // NULL -> the process-wide default handle (created on first use)

@@ -39,13 +39,19 @@ ws = model._elbo_ws.cpu().numpy()
 off = 9 * (k + 1) * M + 2 * M * D
 st = ws[off + 8: off + 8 + 12].reshape(3, 4)
 t0 = st[:, 0].min()
-for name, row in zip(("P chain (workgroup 0)", "Kuu backward (workgroup 1)", "helper 0 (assemble, wait, finalize)"), st):
+for name, row in zip(("P chain (workgroup 0: left half / whole)", "Kuu backward (workgroup 1)", "workgroup 2 (P chain, right half; or helper 0)"), st):
     print("%-38s start +%.2f us | phase mark +%.2f us | end +%.2f us (100 MHz wall clock, relative to the earliest start)%s" % (
         name, (row[0] - t0) / 100, (row[0] - t0 + row[1]) / 100, (row[0] - t0 + row[2]) / 100,
         (" | solve done +%.2f us" % ((row[0] - t0 + row[3]) / 100)) if row[3] > 0 else ""))
 ex = ws[off + 24 + 4: off + 24 + 7]
 print("P workgroup tail (relative to its start): helpers' bands acquired +%.2f us | trace / quadratic-form loop done +%.2f us | workgroup sums done +%.2f us" % tuple(
     (st[0][0] - t0 + v) / 100 for v in ex))
+lv = ws[off + 32: off + 64]
+print("P chain (left / whole) per-phase cycles (s_memtime deltas): " + " ".join("%.1fK" % (v / 1e3) for v in lv if v > 0))
+E = (k + 1) * M
+lp = ws[5 * E + 128: 5 * E + 160]
+print("P chain, right workgroup, per-phase cycles:                 " + " ".join("%.1fK" % (v / 1e3) for v in lp if v > 0))
+print("  [pre-pass | forward levels 0.. (the top level preceded by the right -> left hand-over) | root | backward levels top..0 (the top one includes the left -> right hand-over) | outputs]")
 feat = model.inducing_features
 us, enq = timed(lambda: feat.inverse_band(model.kernel))
 print("Kuu chain alone (asvgp_kuu_inverse_band_1d: assemble + planned backward pass): %.1f us per call (host enqueue %.1f us)" % (us, enq))
