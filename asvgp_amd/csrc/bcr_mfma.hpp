@@ -105,7 +105,8 @@ struct BmSplit {
   unsigned* flag_lr = nullptr;   // left -> right
   long spin_limit = 0;
   int* gave_up = nullptr;        // LDS word of the caller
-};
+  unsigned tag = 4;              // this launch's flag values are tag + 1 (published) and tag + 2 (right -> left: the log-det part too):
+};                               // a flag an aborted launch left behind never matches
 constexpr int BM_XCHG = 96;
 
 // The whole solve for one matrix, called by all BM_THREADS threads of one workgroup.
@@ -151,7 +152,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   auto wait_flag = [&](unsigned* flag) -> bool {                 // all threads; false: gave up
     if (tid == 0) {
       long spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (sp.tag + 1u) > 1u) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > sp.spin_limit) { *sp.gave_up = 1; break; }
       }
@@ -209,7 +210,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
         if (tid < 16) __hip_atomic_store(sp.xchg + tid, Dl[(size_t)(ht >> 1) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid >= 16 && tid < 20) __hip_atomic_store(sp.xchg + tid, xs[ht * B + tid - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                          // (drains the stores: hipcc waits on vmcnt before the barrier)
-        if (tid == 0) __hip_atomic_store(sp.flag_rl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(sp.flag_rl, sp.tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // behind the flag, off the left workgroup's critical path (it reads them at its very end, flag value 2): log-det part, bad column
         const double mine = (r == 0 && c == 0) ? (log(ld.m) + (double)ld.e * 0.6931471805599453094) : 0.0;
         const double tot = wave_sum_dpp(mine);
@@ -226,7 +227,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
           __hip_atomic_store(sp.xchg + 20, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(sp.xchg + 21, (double)bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(sp.flag_rl, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp.flag_rl, sp.tag + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       } else {
         if (!wait_flag(sp.flag_rl)) return;
@@ -462,7 +463,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
         if (tid < 48) __hip_atomic_store(sp.xchg + 32 + tid, Rs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid >= 48 && tid < 52) __hip_atomic_store(sp.xchg + 32 + tid, xs[ht * B + tid - 48], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(sp.flag_lr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(sp.flag_lr, sp.tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         if (!wait_flag(sp.flag_lr)) return;
         if (tid < 48) {
@@ -507,7 +508,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
       for (int w2 = 0; w2 < BM_THREADS / 64; ++w2) { s += red[w2]; bmin = sbad[w2] < bmin ? sbad[w2] : bmin; }
       if (split) {                                                // the right workgroup's part (published tens of microseconds ago: flag value 2)
         long spins = 0;
-        while (__hip_atomic_load(sp.flag_rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u && ++spins <= sp.spin_limit) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(sp.flag_rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sp.tag + 2u && ++spins <= sp.spin_limit) __builtin_amdgcn_s_sleep(1);
         if (spins > sp.spin_limit) *sp.gave_up = 1;
         s_other = __hip_atomic_load(sp.xchg + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bad_other = (int)__hip_atomic_load(sp.xchg + 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -460,13 +460,16 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
                         fin.th, fin.alpha_scale, fin.gacc, fin.ticket, fin.arrived, fin.out);
 }
 
-// The same fused launch with both chains on the matrix cores (bcr_mfma.hpp; k = 4, D = 1): 1024-thread workgroups, workgroup 0 the P chain,
-// workgroup 1 the planned Kuu backward pass, the helpers assemble Kuu / dKuu and leave.  The finalize is done by the chains themselves:
-// each sums the traces / quadratic forms that involve ITS bands (which its CU has just written: no write-back, no wait for six other
-// CUs to fetch 740 KB from memory - that tail cost 10-17 us), adds them to the shared slots with agent-scope atomics and draws a ticket;
-// whoever draws the last one (normally the P chain) evaluates the bound and re-arms the slots.
-// A wait that gives up (helpers that never became resident) is sticky: the waiting workgroup sets info[1] = -1 and does NOT go on to solve
-// or to draw a ticket - nothing later overwrites the flag - and the host re-arms the workspace and re-issues the step through the
+// The same fused launch with both chains on the matrix cores (bcr_mfma.hpp; k = 4, D = 1): 1024-thread workgroups, workgroup 0 the P chain
+// (with fin.split: its left half + separator + root, workgroup 2 its right half - bcr_mfma.hpp BmSplit), workgroup 1 the planned Kuu
+// backward pass.  NO helper workgroups: both chains form Kuu and dKuu / dl in closed form (Toeplitz interior values + boundary tables from
+// the kernel arguments, copied to the LDS once), for the P chain's level-0 loads and for the traces - nobody assembles or waits for a band.
+// The finalize is done by the chains themselves: each sums the traces / quadratic forms of ITS bands (the P workgroups: of their own
+// columns, x from the solve's LDS image), stores them in its own slots with agent-scope stores and draws a ticket; whoever draws the last
+// one (normally the left P workgroup) evaluates the bound and re-arms the slots.  The ticket word and the hand-over flags carry the
+// launch's sequence number, so what an aborted launch left behind is never mistaken for this launch's.
+// A wait that gives up (the other half never resident, the factor table never published) is sticky: the waiting workgroup sets
+// info[1] = -1 and does NOT draw a ticket - no bound is written - and the host re-arms the workspace and re-issues the step through the
 // multi-launch sweeps (gpr.py).
 template <int K>
 __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterior ki, const double* S_static, KuuCoefs2 cf, double* Kuu, double* dK, const double* A, const double* b, int M,
@@ -485,32 +488,9 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       logdets[(slot < 4 ? 8 + 4 * (int)blockIdx.x : 24) + slot] = (slot == 0) ? (double)(t_start & 0xffffffffull) : (double)((__builtin_amdgcn_s_memrealtime() - t_start) & 0xffffffffull);
   };
   rstamp(0);
-  const int nsplit = fin.split ? 1 : 0;
-  if ((int)blockIdx.x >= 2 + nsplit) {                         // helpers: Kuu, dKuu/dl (theta-only), then gone
-    for (long e = (long)((int)blockIdx.x - 2 - nsplit) * blockDim.x + threadIdx.x; e < E; e += (long)fin.n_helpers * blockDim.x)
-      assemble_band_slice(S_static, cf.c, cf.dc, cf.n, E, e, Kuu, dK);
-    __syncthreads();
-    if (threadIdx.x == 0 && fin.debug_no_assembly == 0) {
-      __threadfence();
-      __hip_atomic_fetch_add(fin.assembled, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    rstamp(2);
-    return;
-  }
   __shared__ int gave_up;
   if (threadIdx.x == 0) gave_up = 0;
   __syncthreads();
-  auto wait_assembled = [&]() {                                // (both chains read the helpers' bands; the counter is re-armed by the last ticket)
-    if (threadIdx.x == 0) {
-      long spins = 0;
-      while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > spin_limit) { gave_up = 1; break; }
-      }
-    }
-    __syncthreads();
-    if (!gave_up) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  };
   const double* stats = fin.stats;
   enum { LOGK, LOGP, TRKA, DTRKA, SKDK, SPDK, SKK, SPK, SPA, CC, AKA, ADKA, AAA, BA, NACC };
   double acc[NACC];
@@ -518,10 +498,11 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const bool isP = blockIdx.x == 0 || (fin.split && blockIdx.x == 2);
   const bool isPR = fin.split && blockIdx.x == 2;
-  if (isP) {
-    rstamp(1);
-    __shared__ double kdl[16];
-    __shared__ double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND], dkb[2 * 5 * KI_DKB];
+  // Kuu and dKuu / dl in closed form for BOTH chains' own traces (and the P chain's level-0 loads): interior values kdl, boundary tables
+  __shared__ double kdl[16];
+  __shared__ double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND], dkb[2 * 5 * KI_DKB];
+  {
+    if (isP) rstamp(1);
     if (threadIdx.x == 0) {
       kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4];
       kdl[8] = ki.dk[0]; kdl[9] = ki.dk[1]; kdl[10] = ki.dk[2]; kdl[11] = ki.dk[3]; kdl[12] = ki.dk[4];
@@ -533,8 +514,13 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       else if (threadIdx.x < 2 * PRIOR_BND_DIAGS * PRIOR_BND + 2 * 5 * KI_DKB) dkb[threadIdx.x - 2 * PRIOR_BND_DIAGS * PRIOR_BND] = dkb_g[threadIdx.x - 2 * PRIOR_BND_DIAGS * PRIOR_BND];
     }
     __syncthreads();
+  }
+  if (isP) {
     BmSplit bsp;
-    if (fin.split) { bsp.half = isPR ? 1 : 0; bsp.xchg = fin.xchg; bsp.flag_rl = fin.flag_rl; bsp.flag_lr = fin.flag_lr; bsp.spin_limit = spin_limit; bsp.gave_up = &gave_up; }
+    if (fin.split) {
+      bsp.half = isPR ? 1 : 0; bsp.xchg = fin.xchg; bsp.flag_rl = fin.flag_rl; bsp.flag_lr = fin.flag_lr; bsp.spin_limit = spin_limit; bsp.gave_up = &gave_up;
+      bsp.tag = (unsigned)(seq & 0x0fffffffull) << 2;
+    }
     bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, (lds_cdouble_ptr)bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1, 1,
                                 fin.debug_stamps ? (isPR ? fin.xchg + 128 : logdets + 32) : (double*)nullptr, bsp);   // (per-level cycle stamps: tools/mside_probe.py)
     rstamp(3);
@@ -594,23 +580,48 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       }
     }
   } else {
+    if (fin.debug_no_assembly) {   // test hook (ASVGP_DEBUG_NO_ASSEMBLY): this workgroup behaves as if its factor table never arrived
+      if (threadIdx.x == 0) { for (long sp_ = 0; sp_ < spin_limit; ++sp_) __builtin_amdgcn_s_sleep(8); atomicExch(info + 1, -1); }
+      return;
+    }
     bcr_mfma_backward_pre(tab, n_rec, node_rec, M, wsK, lds, SK, dSK, logdets, info, done_flag, seq, ready_flag,
                           spin_limit < (1L << 20) ? spin_limit : (1L << 20), &gave_up);
     if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }   // (the host never published the table: sticky, like the helpers' case)
     rstamp(1);
     if (fin.finalize) {
-      wait_assembled();
-      if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
-      for (long j = threadIdx.x; j < M; j += blockDim.x) {
+      // like the P chain's: no wait for the helpers' bands (the LAST ticket waits for them before it re-arms their counter), Kuu and
+      // dKuu / dl in closed form, both columns' loads in flight together
+      __syncthreads();                                         // (orders SK, dSK: this workgroup's own global stores)
+      double sk[2][K + 1], dsk[2][K + 1], av[2][K + 1];
+#pragma unroll
+      for (int cI = 0; cI < 2; ++cI) {
+        const long j = (long)threadIdx.x + cI * BM_THREADS, jc = j < M ? j : M - 1;
+#pragma unroll
+        for (int r = 0; r <= K; ++r) { sk[cI][r] = SK[(long)r * M + jc]; dsk[cI][r] = dSK[(long)r * M + jc]; av[cI][r] = stats[(long)r * M + jc]; }
+      }
+#pragma unroll
+      for (int cI = 0; cI < 2; ++cI) {
+        const long j = (long)threadIdx.x + cI * BM_THREADS;
+        if (j >= M) continue;
+        const bool left = j < ki.lo, right = j >= ki.hi;
 #pragma unroll
         for (int r = 0; r <= K; ++r) {
           const long o = (long)r * M + j;
           const double w2 = (r == 0) ? 1.0 : 2.0;
-          const double sk = SK[o], av = stats[o];
-          acc[TRKA] = fma(w2 * sk, av, acc[TRKA]);
-          acc[DTRKA] = fma(w2 * dSK[o], av, acc[DTRKA]);
-          acc[SKDK] = fma(w2 * sk, dK[o], acc[SKDK]);
-          acc[SKK] = fma(w2 * sk, Kuu[o], acc[SKK]);
+          double kv = kdl[r], dkv = kdl[8 + r];
+          if (left || right) {
+            kv = bnd[left ? (long)r * PRIOR_BND + j : (long)(PRIOR_BND_DIAGS + r) * PRIOR_BND + (j - ki.hi)];
+            if (ki.dk_tab) {
+              dkv = dkb[left ? (long)r * KI_DKB + j : (long)(5 + r) * KI_DKB + (j - ki.hi)];
+            } else {
+              dkv = 0.0;
+              for (int t = 0; t < cf.n; ++t) dkv = fma(cf.dc[t], S_static[(long)t * E + o], dkv);
+            }
+          }
+          acc[TRKA] = fma(w2 * sk[cI][r], av[cI][r], acc[TRKA]);
+          acc[DTRKA] = fma(w2 * dsk[cI][r], av[cI][r], acc[DTRKA]);
+          acc[SKDK] = fma(w2 * sk[cI][r], dkv, acc[SKDK]);
+          acc[SKK] = fma(w2 * sk[cI][r], kv, acc[SKK]);
         }
       }
     }
@@ -661,7 +672,17 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   for (int i = 0; i < 7; ++i)
     if (i < nmine) __hip_atomic_store(slot + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drained before the ticket; agent-scope accesses on both sides: no fences)
-  const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the ticket word carries this launch's sequence number: a count an aborted launch left behind (its workgroups that did finish) is not ours
+  unsigned t;
+  {
+    unsigned long long* T = reinterpret_cast<unsigned long long*>(fin.ticket);
+    const unsigned long long sq = seq & 0xffffffffull;
+    unsigned long long old = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      const unsigned long long cnt = ((old >> 32) == sq) ? (old & 0xffffffffull) : 0ull;
+      if (__hip_atomic_compare_exchange_strong(T, &old, (sq << 32) | (cnt + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { t = (unsigned)cnt; break; }
+    }
+  }
   if (t != (fin.split ? 2u : 1u)) { rstamp(2); return; }
   {
     const int pidx[7] = {SPDK, SPK, SPA, AKA, ADKA, AAA, BA};
@@ -678,8 +699,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   tot[SKK] = __hip_atomic_load(fin.gacc + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int i = 0; i < 12; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels add into these slots)
-  __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(fin.assembled, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.ticket), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the other kernels count from 0)
   if (fin.split) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) __hip_atomic_store(fin.gacc + FIN_GACC_PR + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -856,8 +876,8 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
           ff.xchg = w.LP;                                      // (the sequential sweeps' factor band: unused by this launch)
           ff.flag_rl = reinterpret_cast<unsigned*>(w.fin + 28);
           ff.flag_lr = reinterpret_cast<unsigned*>(w.fin + 29);
-          if (ff.n_helpers > 5) ff.n_helpers = 5;
         }
+        ff.n_helpers = 0;                                       // (both chains form Kuu / dKuu in closed form: nobody assembles the bands here)
         // The launch goes out FIRST: its ~8 us of dispatch latency, the helpers' assembly and the P chain (which needs only Kuu, not its
         // factors) run while this thread does the forward pass below; the Kuu workgroup waits on ready[slot] (bcr_mfma_backward_pre).
         const bool plan_first = debug_env().plan_first != 0;   // (measurement aid: the round-2 order, forward pass then launch)
