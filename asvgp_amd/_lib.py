@@ -173,7 +173,9 @@ class Handle:
         return self._mirror
 
     def set_deferred_forward_pass(self, on):
-        check(self._lib.asvgp_set_deferred_forward_pass(self.ptr, int(bool(on))), "set_deferred_forward_pass")
+        """0: the ELBO call runs the host forward pass itself; 1: the caller does (publish_forward()); 2: the handle's worker thread does,
+        started before the launch call (the pass overlaps the launch path; one spinning host thread per handle)."""
+        check(self._lib.asvgp_set_deferred_forward_pass(self.ptr, int(on)), "set_deferred_forward_pass")
 
     def publish_forward(self):
         """asvgp_prior_publish: run the host forward pass a deferred launch is waiting for (a no-op when none is pending)."""

@@ -885,10 +885,17 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
         const double t0 = host_times ? now_us() : 0.0;
         if (plan_first && !gpu_fwd) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
+        const bool to_worker = !plan_first && !gpu_fwd && h->fwd_worker;
+        if (to_worker) {                                       // the handle's worker thread starts on the table NOW, beside the launch call
+          for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) { h->fwd.coef[t] = cf.c[t]; h->fwd.dcoef[t] = cf.dc[t]; }
+          h->fwd.tab = tab; h->fwd.slot = slot; h->fwd.seq = seq;
+          handle_post_forward(h);
+        }
         hipLaunchKernelGGL(kern, dim3(2 + ff.split + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                            tab_k, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
                            (plan_first || gpu_fwd) ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
         if (gpu_fwd) return check_launch("elbo chains (matrix cores, forward pass on the GPU)");
+        if (to_worker) return check_launch("elbo chains (matrix cores, forward pass on the worker thread)");
         const double t1 = host_times ? now_us() : 0.0;
         if (!plan_first && h->defer_forward) {                  // the caller runs the forward pass later (asvgp_prior_publish): e.g. after
           h->fwd.valid = true;                                   // enqueueing other work that should not wait 19 us behind it

@@ -5,6 +5,7 @@
 #include <time.h>
 
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "handle.hpp"
@@ -73,7 +74,43 @@ static void plan_release(Handle* h) {
   h->slot_doubles = 0;
 }
 
+static void worker_wait_idle(Handle* h) {
+  while (__atomic_load_n(&h->wstate, __ATOMIC_ACQUIRE) == 1) sched_yield();
+}
+static void worker_main(Handle* h) {
+  long idle = 0;
+  for (;;) {
+    const int st = __atomic_load_n(&h->wstate, __ATOMIC_ACQUIRE);
+    if (st == 2) return;
+    if (st == 1) {
+      if (h->plan) (void)prior_plan_eval(h->plan, h->fwd.coef, h->fwd.dcoef, h->fwd.tab);   // a non-positive pivot is reported through `info` by the kernel
+      __atomic_store_n(h->ready_host + h->fwd.slot, h->fwd.seq, __ATOMIC_RELEASE);
+      __atomic_store_n(&h->wstate, 0, __ATOMIC_RELEASE);
+      idle = 0;
+    } else if (++idle > 200000) {
+      sched_yield();                         // (a model that has stopped stepping: give the core away between looks)
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+}
+void handle_post_forward(Handle* h) {
+  if (!h->worker) h->worker = new std::thread(worker_main, h);
+  __atomic_store_n(&h->wstate, 1, __ATOMIC_RELEASE);
+}
+static void worker_stop(Handle* h) {
+  if (!h->worker) return;
+  worker_wait_idle(h);
+  __atomic_store_n(&h->wstate, 2, __ATOMIC_RELEASE);
+  std::thread* t = static_cast<std::thread*>(h->worker);
+  t->join();
+  delete t;
+  h->worker = nullptr;
+  h->wstate = 0;
+}
+
 void handle_publish_forward(Handle* h) {
+  if (h->worker) worker_wait_idle(h);        // (worker mode: the pass is on its way; callers need it finished)
   if (!h->fwd.valid) return;
   h->fwd.valid = false;
   if (h->plan) (void)prior_plan_eval(h->plan, h->fwd.coef, h->fwd.dcoef, h->fwd.tab);   // a non-positive pivot is reported through `info` by the kernel
@@ -169,6 +206,7 @@ extern "C" int asvgp_destroy(asvgp_handle_t handle) {
   if (!handle) return ASVGP_OK;
   Handle* h = reinterpret_cast<Handle*>(handle);
   if (h->magic != 0x41535647u) { set_error("asvgp_destroy: not a handle"); return ASVGP_ERR_BAD_ARG; }
+  worker_stop(h);
   plan_release(h);
   if (h->mirror_host) (void)hipHostFree(h->mirror_host);
   if (h->evK) (void)hipEventDestroy(h->evK);
@@ -213,8 +251,11 @@ extern "C" int asvgp_set_band_algorithm(asvgp_handle_t handle, int algo) {
 
 extern "C" int asvgp_set_deferred_forward_pass(asvgp_handle_t handle, int on) {
   Handle* h = as_handle(handle);
-  if (!on) handle_publish_forward(h);
-  h->defer_forward = on != 0;
+  if (on < 0 || on > 2) { set_error("set_deferred_forward_pass: 0 inline, 1 the caller publishes (asvgp_prior_publish), 2 the handle's worker thread"); return ASVGP_ERR_BAD_ARG; }
+  handle_publish_forward(h);
+  if (on != 2) worker_stop(h);
+  h->defer_forward = on == 1;
+  h->fwd_worker = on == 2;
   return ASVGP_OK;
 }
 

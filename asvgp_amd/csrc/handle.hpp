@@ -43,6 +43,11 @@ struct Handle {
   // deferred forward pass (asvgp_set_deferred_forward_pass): the matrix-core launch returns at once; asvgp_prior_publish runs the host
   // forward pass for it and sets the slot's ready word (the next ELBO call or the handle's teardown does it if the caller did not)
   bool defer_forward = false;
+  // ... or runs on the handle's own worker thread (asvgp_set_deferred_forward_pass(h, 2)): posted BEFORE the launch call, so the ~19 us of
+  // long-double arithmetic overlap the launch path and the caller's next enqueues; the worker spins while idle (one host core)
+  bool fwd_worker = false;
+  void* worker = nullptr;                 // std::thread*
+  int wstate = 0;                         // 0 idle, 1 job posted, 2 exit  (accessed with __atomic builtins)
   struct PendingForward { bool valid; double coef[ASVGP_MAX_KUU_TERMS], dcoef[ASVGP_MAX_KUU_TERMS]; double* tab; int slot; unsigned long long seq; } fwd = {false, {0}, {0}, nullptr, 0, 0};
   // forward pass on the GPU in double-double (asvgp_set_prior_forward(h, 1); prior_dd.hip): device image of the plan, device table ring
   bool prior_forward_gpu = false;
@@ -78,8 +83,10 @@ bool handle_mesh_is_linspace(Handle* h, const double* mesh_dev, long n_mesh, hip
 // accumulate call on the handle (so the parked partials are never overwritten).  stats != NULL: only when the pending reduce targets it.
 int handle_flush_phi_reduce(Handle* h, const double* stats, hipStream_t st);
 
-// run a pending deferred forward pass (no-op when none): prior_plan_eval into the slot, then the ready word
+// run a pending deferred forward pass (no-op when none): prior_plan_eval into the slot, then the ready word; worker mode: wait for it
 void handle_publish_forward(Handle* h);
+// worker mode: hand the pass described by h->fwd to the worker thread (started on first use)
+void handle_post_forward(Handle* h);
 
 // all-GPU forward pass (prior_dd.hip): enqueue the double-double forward pass for one theta on `st` into slot `slot` of the handle's
 // device table ring (*tab_out); the consumer is launched behind it on the same stream and needs no ready word

@@ -94,7 +94,10 @@ int asvgp_debug_reload_env(void);
 /* Deferred forward pass.  With on = 1 the matrix-core launch of asvgp_elbo_grad_1d returns right after the kernel launch; the host's
  * forward pass of the prior chain for that launch (~19 us, long double) runs in asvgp_prior_publish - which the caller issues after
  * enqueueing whatever should not wait behind it (bench.py: the theta-free Phi pass of the next step).  The launch's Kuu workgroup waits
- * (bounded) for the table; the next ELBO call, asvgp_set_deferred_forward_pass(h, 0) and asvgp_destroy publish a forgotten one. */
+ * (bounded) for the table; the next ELBO call, asvgp_set_deferred_forward_pass(h, 0) and asvgp_destroy publish a forgotten one.
+ * on = 2: the pass runs on a worker thread the handle owns, posted BEFORE the launch call - it overlaps the launch path and whatever the
+ * caller enqueues next, and the table is published ~20 us after the call was entered (on = 1 in bench.py's order: ~38 us).  The worker
+ * spins while idle (one host core per handle, yielding after ~1 ms without work); asvgp_prior_publish then only waits for it. */
 int asvgp_set_deferred_forward_pass(asvgp_handle_t handle, int on);
 int asvgp_prior_publish(asvgp_handle_t handle);
 /* Result mirror: 16 pinned host doubles owned by the handle.  While enabled, the fused ELBO + gradient launch (band algorithm 0 / 4 where
