@@ -667,28 +667,35 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
   if (threadIdx.x != 0) return;
   if (isP) rstamp(6);
-  double* slot = fin.gacc + (isPR ? FIN_GACC_PR : (isP ? 0 : 8));   // P (left / whole): gacc[0..6], Kuu: gacc[8..11], P right: gacc[21..27]
+  // Who finishes is fixed: the left (or only) P workgroup.  The others store their sums in their own slots (agent-scope stores, drained)
+  // and then a done word that carries this launch's tag - nothing an aborted launch left behind matches it; the finisher uses its own sums
+  // from registers, polls the done words (bounded; set ~10 us ago in every schedule measured) and reads the others' slots.  No ticket.
+  const unsigned tag = ((unsigned)(seq & 0x0fffffffull) << 2) | 1u;
+  unsigned* done_kuu = fin.arrived;                            // (the older kernels' chain-arrival counter: unused by this launch)
+  unsigned* done_pr = fin.flag_lr + 1;
+  if (!isP || isPR) {
+    double* slot = fin.gacc + (isPR ? FIN_GACC_PR : 8);        // Kuu: gacc[8..11], P right: gacc[21..27]
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
-    if (i < nmine) __hip_atomic_store(slot + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drained before the ticket; agent-scope accesses on both sides: no fences)
-  // the ticket word carries this launch's sequence number: a count an aborted launch left behind (its workgroups that did finish) is not ours
-  unsigned t;
+    for (int i = 0; i < 7; ++i)
+      if (i < nmine) __hip_atomic_store(slot + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(isPR ? done_pr : done_kuu, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rstamp(2);
+    return;
+  }
   {
-    unsigned long long* T = reinterpret_cast<unsigned long long*>(fin.ticket);
-    const unsigned long long sq = seq & 0xffffffffull;
-    unsigned long long old = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-      const unsigned long long cnt = ((old >> 32) == sq) ? (old & 0xffffffffull) : 0ull;
-      if (__hip_atomic_compare_exchange_strong(T, &old, (sq << 32) | (cnt + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { t = (unsigned)cnt; break; }
+    long spins = 0;
+    while (__hip_atomic_load(done_kuu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag ||
+           (fin.split && __hip_atomic_load(done_pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag)) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > spin_limit) { atomicExch(info + 1, -1); return; }   // (a chain that gave up never reports: no bound is written)
     }
   }
-  if (t != (fin.split ? 2u : 1u)) { rstamp(2); return; }
   {
     const int pidx[7] = {SPDK, SPK, SPA, AKA, ADKA, AAA, BA};
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      double v = __hip_atomic_load(fin.gacc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double v = red[i];
       if (fin.split) v += __hip_atomic_load(fin.gacc + FIN_GACC_PR + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       tot[pidx[i]] = v;
     }
@@ -699,13 +706,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   tot[SKK] = __hip_atomic_load(fin.gacc + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int i = 0; i < 12; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels add into these slots)
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.ticket), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the other kernels count from 0)
-  if (fin.split) {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) __hip_atomic_store(fin.gacc + FIN_GACC_PR + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fin.flag_rl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (both P workgroups have drawn their tickets: past their waits)
-    __hip_atomic_store(fin.flag_lr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  __hip_atomic_store(done_kuu, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the older kernels count arrivals from 0 there)
   {
     const double v = fin.th.v, sn = fin.th.s, N = fin.th.N;
     const double yy = stats[(long)(K + 1) * M + M];
@@ -742,8 +743,8 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
 #pragma unroll
       for (int i = 0; i < 10; ++i) { __hip_atomic_store(m + i, mv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); sum += mv[i]; }
       __hip_atomic_store(m + 11, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(m + 10, (double)fin.mirror_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(m + 10, (double)fin.mirror_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (no wait for the stores above: the
+                                                               //  host accepts a sequence number only together with a matching sum, else polls on)
     }
   }
   rstamp(2);
