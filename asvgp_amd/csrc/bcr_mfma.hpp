@@ -90,6 +90,36 @@ struct BmLog {
   }
 };
 
+// One-trip messages between workgroups in different XCDs: n <= 62 payload words and ONE check word = tag ^ (xor of the payload bits), all
+// agent-scope atomic accesses, written in any order with no drain and no separate flag; the reader (one wavefront) polls the WHOLE message
+// and accepts it when the check word matches - a message an earlier launch left in the box carries another tag and never does.  (A flag
+// behind drained stores costs the writer a vmcnt drain and the reader a second round trip for the payload: ~1.4 us per hand-over.)
+__device__ __forceinline__ unsigned long long bm_wave_xor(unsigned long long x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x ^= (unsigned long long)__shfl_xor((long long)x, off, 64);
+  return x;
+}
+// called by all 64 lanes of ONE wave; lane < n carries payload word v
+__device__ __forceinline__ void bm_msg_send(double* box, int n, double v, unsigned long long tag, int lane) {
+  unsigned long long* b = reinterpret_cast<unsigned long long*>(box);
+  const unsigned long long w = lane < n ? (unsigned long long)__double_as_longlong(v) : 0ull;
+  const unsigned long long x = bm_wave_xor(w) ^ tag;
+  if (lane < n) __hip_atomic_store(b + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == n) __hip_atomic_store(b + n, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// called by all 64 lanes of ONE wave; returns false when nothing valid arrived within the spin limit; lane < n receives word `lane`
+__device__ __forceinline__ bool bm_msg_recv(const double* box, int n, double& v, unsigned long long tag, int lane, long spin_limit) {
+  const unsigned long long* b = reinterpret_cast<const unsigned long long*>(box);
+  for (long spins = 0; spins <= spin_limit; ++spins) {
+    const unsigned long long w = lane <= n ? __hip_atomic_load(b + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long x = bm_wave_xor(lane < n ? w : 0ull) ^ tag;
+    const unsigned long long chk = (unsigned long long)__shfl((long long)w, n, 64);
+    if (x == chk) { v = __longlong_as_double((long long)w); return true; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
 // TWO workgroups on one matrix (the fused ELBO launch at nb >= 128).  The last level's node ht = 2^(levels - 1) separates the elimination
 // tree into the nodes below it (left) and above it (right), which meet nowhere else: workgroup `half` = 0 eliminates the left nodes of
 // the levels below the top, workgroup 1 the right ones - half the rounds on the wide, throughput-bound levels 0..2 -, each keeping its
@@ -100,13 +130,11 @@ struct BmLog {
 // are agent-scope accesses (no fences: the two workgroups sit in different XCDs); the waits are bounded (*gave_up, then return).
 struct BmSplit {
   int half = -1;                 // -1: the whole matrix in this workgroup
-  double* xchg = nullptr;        // 96 doubles
-  unsigned* flag_rl = nullptr;   // right -> left   (re-armed by the caller after both workgroups are through)
-  unsigned* flag_lr = nullptr;   // left -> right
+  double* xchg = nullptr;        // BM_XCHG doubles: three message boxes (right -> left 21 words at 0, its log-det part 3 words at 24, left -> right 53 at 32)
   long spin_limit = 0;
   int* gave_up = nullptr;        // LDS word of the caller
-  unsigned tag = 4;              // this launch's flag values are tag + 1 (published) and tag + 2 (right -> left: the log-det part too):
-};                               // a flag an aborted launch left behind never matches
+  unsigned long long tag = 0;    // this launch's message tag (sequence number << 8; the boxes add their own low byte)
+};
 constexpr int BM_XCHG = 96;
 
 // The whole solve for one matrix, called by all BM_THREADS threads of one workgroup.
@@ -148,17 +176,6 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
     } else {
       ne_h = sp.half == 0 ? ne : 0;
     }
-  };
-  auto wait_flag = [&](unsigned* flag) -> bool {                 // all threads; false: gave up
-    if (tid == 0) {
-      long spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (sp.tag + 1u) > 1u) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > sp.spin_limit) { *sp.gave_up = 1; break; }
-      }
-    }
-    __syncthreads();
-    return *sp.gave_up == 0;
   };
   int bad = 0;
   BmLog ld{1.0, 0};
@@ -206,12 +223,11 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
     if (split && l == top) {
       // ---- right -> left: the separator's pivot block and right-hand side as the right half leaves them, its log-det part, its bad column
       if (sp.half == 1) {
-        // (the record stores of the levels 0..2 are long done: the barrier's vmcnt drain costs nothing here)
-        if (tid < 16) __hip_atomic_store(sp.xchg + tid, Dl[(size_t)(ht >> 1) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid >= 16 && tid < 20) __hip_atomic_store(sp.xchg + tid, xs[ht * B + tid - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();                                          // (drains the stores: hipcc waits on vmcnt before the barrier)
-        if (tid == 0) __hip_atomic_store(sp.flag_rl, sp.tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // behind the flag, off the left workgroup's critical path (it reads them at its very end, flag value 2): log-det part, bad column
+        if (wv == 0) {
+          const double v = lane < 16 ? Dl[(size_t)(ht >> 1) * 16 + lane] : (lane < 20 ? xs[ht * B + lane - 16] : 0.0);
+          bm_msg_send(sp.xchg, 20, v, sp.tag | 1ull, lane);
+        }
+        // behind the message, off the left workgroup's critical path (it reads them at its very end): log-det part, bad column
         const double mine = (r == 0 && c == 0) ? (log(ld.m) + (double)ld.e * 0.6931471805599453094) : 0.0;
         const double tot = wave_sum_dpp(mine);
         int bm = bad ? bad : 0x7fffffff;
@@ -220,20 +236,23 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
         int* sbad = reinterpret_cast<int*>(red + 32);
         if (lane == 0) { red[wv] = tot; sbad[wv] = bm; }
         __syncthreads();
-        if (tid == 0) {
-          double s = 0.0;
+        if (wv == 0) {
+          double sv = 0.0;
           int bmin = 0x7fffffff;
-          for (int w2 = 0; w2 < BM_THREADS / 64; ++w2) { s += red[w2]; bmin = sbad[w2] < bmin ? sbad[w2] : bmin; }
-          __hip_atomic_store(sp.xchg + 20, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(sp.xchg + 21, (double)bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(sp.flag_rl, sp.tag + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int w2 = 0; w2 < BM_THREADS / 64; ++w2) { sv += red[w2]; bmin = sbad[w2] < bmin ? sbad[w2] : bmin; }
+          bm_msg_send(sp.xchg + 24, 2, lane == 0 ? sv : (double)bmin, sp.tag | 2ull, lane);
         }
       } else {
-        if (!wait_flag(sp.flag_rl)) return;
-        if (tid < 16) Dl[(size_t)(ht >> 1) * 16 + tid] += __hip_atomic_load(sp.xchg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid >= 16 && tid < 20) xs[ht * B + tid - 16] += __hip_atomic_load(sp.xchg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wv == 0) {
+          double v = 0.0;
+          if (!bm_msg_recv(sp.xchg, 20, v, sp.tag | 1ull, lane, sp.spin_limit)) { if (lane == 0) *sp.gave_up = 1; }
+          else {
+            if (lane < 16) Dl[(size_t)(ht >> 1) * 16 + lane] += v;
+            else if (lane < 20) xs[ht * B + lane - 16] += v;
+          }
+        }
         __syncthreads();
+        if (*sp.gave_up) return;
       }
       stamp();
     }
@@ -460,23 +479,24 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
       // ---- left -> right: the separator's backward record (Sigma_ii, C_a^T, C_b^T) and solution
       double* Rs = Sl + (size_t)(ht >> 2) * 48;
       if (sp.half == 0) {
-        if (tid < 48) __hip_atomic_store(sp.xchg + 32 + tid, Rs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid >= 48 && tid < 52) __hip_atomic_store(sp.xchg + 32 + tid, xs[ht * B + tid - 48], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(sp.flag_lr, sp.tag + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wv == 0) bm_msg_send(sp.xchg + 32, 52, lane < 48 ? Rs[lane < 48 ? lane : 0] : (lane < 52 ? xs[ht * B + lane - 48] : 0.0), sp.tag | 3ull, lane);
       } else {
-        if (!wait_flag(sp.flag_lr)) return;
-        if (tid < 48) {
-          const double v = __hip_atomic_load(sp.xchg + 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          Rs[tid] = v;
-          rec(ht)[BM_SD + tid] = v;                               // (its level-0 neighbour reads the workspace record: this workgroup's own copy)
-          if (tid < 16) {                                         // ... and this workgroup's traces read the separator's diagonal block of the band
-            const int rr = tid >> 2, cc = tid & 3;
-            if (rr >= cc && ht * B + rr < M) Sband[(long)(rr - cc) * M + ht * B + cc] = v;
+        if (wv == 0) {
+          double v = 0.0;
+          if (!bm_msg_recv(sp.xchg + 32, 52, v, sp.tag | 3ull, lane, sp.spin_limit)) { if (lane == 0) *sp.gave_up = 1; }
+          else if (lane < 48) {
+            Rs[lane] = v;
+            rec(ht)[BM_SD + lane] = v;                            // (its level-0 neighbour reads the workspace record: this workgroup's own copy)
+            if (lane < 16) {                                      // ... and this workgroup's traces read the separator's diagonal block of the band
+              const int rr = lane >> 2, cc = lane & 3;
+              if (rr >= cc && ht * B + rr < M) Sband[(long)(rr - cc) * M + ht * B + cc] = v;
+            }
+          } else if (lane < 52) {
+            xs[ht * B + lane - 48] = v;
           }
         }
-        if (tid >= 48 && tid < 52) xs[ht * B + tid - 48] = __hip_atomic_load(sp.xchg + 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        if (*sp.gave_up) return;
       }
     }
     stamp();
@@ -502,17 +522,15 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
     int* sbad = reinterpret_cast<int*>(red + 32);
     if (lane == 0) { red[wv] = tot; sbad[wv] = bm; }
     __syncthreads();
+    if (split && wv == 0) {                                       // the right workgroup's part (sent tens of microseconds ago)
+      double v = 0.0;
+      if (!bm_msg_recv(sp.xchg + 24, 2, v, sp.tag | 2ull, lane, sp.spin_limit)) { if (lane == 0) *sp.gave_up = 1; }
+      else { s_other = __shfl(v, 0, 64); bad_other = (int)__shfl(v, 1, 64); }
+    }
     if (tid == 0) {
       double s = 0.0;
       int bmin = 0x7fffffff;
       for (int w2 = 0; w2 < BM_THREADS / 64; ++w2) { s += red[w2]; bmin = sbad[w2] < bmin ? sbad[w2] : bmin; }
-      if (split) {                                                // the right workgroup's part (published tens of microseconds ago: flag value 2)
-        long spins = 0;
-        while (__hip_atomic_load(sp.flag_rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sp.tag + 2u && ++spins <= sp.spin_limit) __builtin_amdgcn_s_sleep(1);
-        if (spins > sp.spin_limit) *sp.gave_up = 1;
-        s_other = __hip_atomic_load(sp.xchg + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad_other = (int)__hip_atomic_load(sp.xchg + 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
       s += s_other;                                               // (the right workgroup's nodes)
       bmin = bad_other < bmin ? bad_other : bmin;
       // (agent-scope stores: the fused launch's last ticket may read them from another XCD, where a plain store would still be a dirty L2 line)

@@ -517,10 +517,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   }
   if (isP) {
     BmSplit bsp;
-    if (fin.split) {
-      bsp.half = isPR ? 1 : 0; bsp.xchg = fin.xchg; bsp.flag_rl = fin.flag_rl; bsp.flag_lr = fin.flag_lr; bsp.spin_limit = spin_limit; bsp.gave_up = &gave_up;
-      bsp.tag = (unsigned)(seq & 0x0fffffffull) << 2;
-    }
+    if (fin.split) { bsp.half = isPR ? 1 : 0; bsp.xchg = fin.xchg; bsp.spin_limit = spin_limit; bsp.gave_up = &gave_up; bsp.tag = seq << 8; }
     bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, (lds_cdouble_ptr)bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1, 1,
                                 fin.debug_stamps ? (isPR ? fin.xchg + 128 : logdets + 32) : (double*)nullptr, bsp);   // (per-level cycle stamps: tools/mside_probe.py)
     rstamp(3);
@@ -665,48 +662,36 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   double tot[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
-  if (threadIdx.x != 0) return;
-  if (isP) rstamp(6);
-  // Who finishes is fixed: the left (or only) P workgroup.  The others store their sums in their own slots (agent-scope stores, drained)
-  // and then a done word that carries this launch's tag - nothing an aborted launch left behind matches it; the finisher uses its own sums
-  // from registers, polls the done words (bounded; set ~10 us ago in every schedule measured) and reads the others' slots.  No ticket.
-  const unsigned tag = ((unsigned)(seq & 0x0fffffffull) << 2) | 1u;
-  unsigned* done_kuu = fin.arrived;                            // (the older kernels' chain-arrival counter: unused by this launch)
-  unsigned* done_pr = fin.flag_lr + 1;
+  if (isP && threadIdx.x == 0) rstamp(6);
+  // Who finishes is fixed: the left (or only) P workgroup.  The Kuu workgroup and the right P workgroup send their sums as one-trip messages
+  // (bcr_mfma.hpp bm_msg_*: payload + a check word that carries this launch's sequence number - nothing an aborted launch left behind is
+  // accepted); the finisher adds its own sums from registers.  No ticket, no flag, no drain.
+  const unsigned long long mtag = seq << 8;
+  double* box_kuu = fin.gacc + 8;                              // 4 sums + check word: gacc[8..12]
+  double* box_pr = fin.gacc + FIN_GACC_PR;                     // 7 sums + check word: gacc[21..28]
   if (!isP || isPR) {
-    double* slot = fin.gacc + (isPR ? FIN_GACC_PR : 8);        // Kuu: gacc[8..11], P right: gacc[21..27]
+    double v = red[0];
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
-      if (i < nmine) __hip_atomic_store(slot + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(isPR ? done_pr : done_kuu, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    rstamp(2);
+    for (int i = 1; i < 7; ++i) v = (lane == i) ? red[i] : v;
+    bm_msg_send(isPR ? box_pr : box_kuu, nmine, v, mtag | (isPR ? 5ull : 4ull), lane);
+    if (threadIdx.x == 0) rstamp(2);
     return;
   }
+  double kuu_v = 0.0, pr_v = 0.0;
   {
-    long spins = 0;
-    while (__hip_atomic_load(done_kuu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag ||
-           (fin.split && __hip_atomic_load(done_pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag)) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > spin_limit) { atomicExch(info + 1, -1); return; }   // (a chain that gave up never reports: no bound is written)
-    }
+    bool ok = bm_msg_recv(box_kuu, 4, kuu_v, mtag | 4ull, lane, spin_limit);
+    if (ok && fin.split) ok = bm_msg_recv(box_pr, 7, pr_v, mtag | 5ull, lane, spin_limit);
+    if (!ok) { if (lane == 0) atomicExch(info + 1, -1); return; }   // (a chain that gave up never reports: no bound is written)
   }
   {
     const int pidx[7] = {SPDK, SPK, SPA, AKA, ADKA, AAA, BA};
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      double v = red[i];
-      if (fin.split) v += __hip_atomic_load(fin.gacc + FIN_GACC_PR + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tot[pidx[i]] = v;
-    }
+    for (int i = 0; i < 7; ++i) tot[pidx[i]] = red[i] + (fin.split ? __shfl(pr_v, i, 64) : 0.0);
   }
-  tot[TRKA] = __hip_atomic_load(fin.gacc + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[DTRKA] = __hip_atomic_load(fin.gacc + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[SKDK] = __hip_atomic_load(fin.gacc + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tot[SKK] = __hip_atomic_load(fin.gacc + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot[TRKA] = __shfl(kuu_v, 0, 64); tot[DTRKA] = __shfl(kuu_v, 1, 64); tot[SKDK] = __shfl(kuu_v, 2, 64); tot[SKK] = __shfl(kuu_v, 3, 64);
+  if (threadIdx.x != 0) return;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels add into these slots)
-  __hip_atomic_store(done_kuu, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the older kernels count arrivals from 0 there)
+  for (int i = 0; i < 14; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels ADD into these slots; the message has been read)
   {
     const double v = fin.th.v, sn = fin.th.s, N = fin.th.N;
     const double yy = stats[(long)(K + 1) * M + M];
@@ -875,8 +860,6 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         if (nb >= 128 && !debug_env().no_split) {
           ff.split = 1;
           ff.xchg = w.LP;                                      // (the sequential sweeps' factor band: unused by this launch)
-          ff.flag_rl = reinterpret_cast<unsigned*>(w.fin + 28);
-          ff.flag_lr = reinterpret_cast<unsigned*>(w.fin + 29);
         }
         ff.n_helpers = 0;                                       // (both chains form Kuu / dKuu in closed form: nobody assembles the bands here)
         // The launch goes out FIRST: its ~8 us of dispatch latency, the helpers' assembly and the P chain (which needs only Kuu, not its

@@ -24,6 +24,7 @@ timeout -k 10 100 tools/micro/bin/bcr_mfma_bench 2048 > $O/bcr_mfma_bench.txt 2>
 timeout -k 10 200 python3 tools/phi_probe.py 10000000 > $O/phi_probe_10m.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/phi_probe.py 1250000 > $O/phi_probe_1250k.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/vjp_probe.py > $O/vjp_probe.txt 2>&1 || exit 1
+timeout -k 10 200 python3 tools/prior_dd_probe.py > $O/prior_dd_probe.txt 2>&1 || exit 1
 timeout -k 10 400 python3 tools/dep_probe.py > $O/dep_probe.txt 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kron -- python3 tools/kron_probe.py > $O/kron.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/predict -- python3 tools/predict_probe.py > $O/predict.log 2>&1 || exit 1

@@ -45,6 +45,7 @@ copy("bcr_mfma_bench.txt", tag + "_bcr_mfma_levels.txt")
 copy("phi_probe_10m.txt", tag + "_phi_probe_n10m.txt")
 copy("phi_probe_1250k.txt", tag + "_phi_probe_n1250k.txt")
 copy("vjp_probe.txt", tag + "_vjp_probe.txt")
+copy("prior_dd_probe.txt", tag + "_prior_dd_probe.txt")
 copy("dep_probe.txt", tag + "_dependent_step_ablation.txt")
 for sub in ("kron", "predict"):          # kernel-trace stats of tools/kron_probe.py / tools/predict_probe.py + the probes' own output
     fs = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
