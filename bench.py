@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--chain-streams", type=int, default=2, help="M-side streams of the independent-evaluations extra")
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the overlapped schedules (the chain workgroups need free CUs)")
     ap.add_argument("--no-three-sets", action="store_true", help="skip the extra dependent schedule with three buffer sets")
+    ap.add_argument("--worker-forward", action="store_true", help="dependent schedules: the host forward pass of the Kuu chain on the handle's worker thread (asvgp_set_deferred_forward_pass(h, 2))")
     ap.add_argument("--no-mirror", action="store_true", help="dependent schedule: read results through the stream (D2H copy + sync) instead of the pinned mirror")
     ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
     ap.add_argument("--phase-events", type=int, default=25, help="one-at-a-time schedule: per-phase events on every n-th step (0 = never)")
@@ -294,17 +295,17 @@ def main():
     # ---- schedule C (`value`): dependent steps.  theta_{i+1} = theta_0 (1 + 1e-6 delta(result_i)) is computed on the host from the result of
     # step i that the host has read, so nothing of step i+1 that needs theta (ELBO launch, host forward pass) can start earlier.  The Phi
     # pass, its cross-workgroup reduce and the [all-reduce] need no theta and run on a second stream into another buffer set:
-    #   two buffer sets (`value`): per step, in host order - theta_i, ELBO + gradient launch of step i (M stream, behind the statistics
-    #     event of its set; the call returns right after the launch: asvgp_set_deferred_forward_pass) -> Phi KERNEL of step i+1 (N stream;
-    #     its buffer set was released by the result just read) -> the host's long-double forward pass for the launch (asvgp_prior_publish;
-    #     the Kuu workgroup waits for it, the P chain does not) -> reduce, [all-reduce], event of step i+1 (N stream) -> the host polls the
-    #     pinned result mirror of step i.
+    #   two buffer sets (`value`): per step, in host order - Phi KERNEL of step i+1 (N stream; its buffer set was released by the result
+    #     just read; no theta in it) -> theta_i -> ELBO + gradient launch of step i (M stream, behind the statistics event of its set; the
+    #     call launches first and then runs the host's long-double forward pass: the Kuu workgroup waits for the table, the P chain does
+    #     not; --worker-forward moves the pass to the handle's worker thread - measured: no gain in this order) -> reduce, [all-reduce],
+    #     event of step i+1 (N stream) -> the host polls the pinned result mirror of step i.
     #   three buffer sets (extra `dependent_steps_phi_two_ahead`): ELBO launch of step i first, then the whole N side of step i+2.
     def dependent_schedule(n_sets):
         lanes = [new_model(N, overlapped=True, defer=(n_sets == 2)) for _ in range(n_sets)]
-        if not args.no_mirror:
+        if args.worker_forward and not args.no_mirror:
             for ln in lanes:
-                ln._h.set_deferred_forward_pass(2)                 # the launch returns at once; the handle's worker thread runs the forward pass
+                ln._h.set_deferred_forward_pass(2)                 # the handle's worker thread runs the host forward pass (measured: no gain in this order)
         s_n = torch.cuda.Stream()
         s_m = torch.cuda.Stream(priority=-1)
         ev_stats = [torch.cuda.Event() for _ in range(n_sets)]
@@ -333,6 +334,8 @@ def main():
                 i = state["i"]
                 ln, nxt = lanes[i % n_sets], (i + ahead) % n_sets
                 t0 = time.perf_counter()
+                if n_sets == 2:
+                    n_side_kernel(nxt)                              # its buffer set was released by the result just read; needs no theta
                 set_theta(ln, state["theta"])
                 if not ev_stats[i % n_sets].query():                # (complete unless the N side is the slower one: then the launch waits in-stream)
                     s_m.wait_event(ev_stats[i % n_sets])
@@ -343,7 +346,8 @@ def main():
                 else:
                     tok = ln.launch_elbo_host()
                 t1 = time.perf_counter()
-                n_side_kernel(nxt)
+                if n_sets != 2:
+                    n_side_kernel(nxt)
                 n_side_rest(nxt)
                 t2 = time.perf_counter()
                 if tok is None:
@@ -365,8 +369,8 @@ def main():
         n_acc = max(state["n"], 1)
         out = {"ms": ms, "kern_us": kern_us, "launches": launches, "last": state["last"],
                "fallbacks": sum(getattr(ln, "fused_launch_fallbacks", 0) for ln in lanes),
-               "host_us": {("theta_and_elbo_launch"): state["t_a"] / n_acc * 1e6,
-                           ("phi_kernel_reduce_event" if n_sets == 2 else "n_side_enqueue"): state["t_b"] / n_acc * 1e6,
+               "host_us": {("phi_kernel_enqueue_theta_and_elbo_launch" if n_sets == 2 else "theta_and_elbo_launch"): state["t_a"] / n_acc * 1e6,
+                           ("reduce_and_event_enqueue" if n_sets == 2 else "n_side_enqueue"): state["t_b"] / n_acc * 1e6,
                            "wait_for_result": state["t_poll"] / n_acc * 1e6}}
         torch.cuda.synchronize()
         del lanes
@@ -465,7 +469,7 @@ def main():
             dsp = spread(dep["ms"])
             schedule = ("dependent steps: theta_{i+1} computed on the host from the host-read result of step i (pinned result mirror%s); "
                         "ELBO + gradient launch of step i on one stream, the theta-free part of step i+1 (Phi pass, reduce, [all-reduce]) on a "
-                        "second stream under it (host order: ELBO launch of i, Phi kernel of i+1, host forward pass of i, reduce of i+1); two buffer sets alternate; Phi grid %d workgroups"
+                        "second stream under it (host order: Phi kernel of i+1, ELBO launch of i followed by the host's long-double forward pass for it, reduce of i+1); two buffer sets alternate; Phi grid %d workgroups"
                         % (" off: D2H copy + synchronise" if args.no_mirror else "", args.phi_workgroups))
         else:
             dsp = ser

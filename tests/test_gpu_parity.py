@@ -1905,3 +1905,31 @@ def test_bound_with_gpu_forward_pass_equals_host_forward_pass_all_orders(A, orde
     assert abs(res[0][0] - res[1][0]) <= 1e-11 * abs(res[0][0]) + 1e-9, (res[0][0], res[1][0])
     # (M = 4096 / Matern-5/2: cond(Kuu) ~ 1e9 and the tangents are fp64 on both sides - 2.4e-8 measured, the stated gradient gate is 1e-6)
     np.testing.assert_allclose(res[1][1:4], res[0][1:4], rtol=1e-6 if M == 4096 else 1e-8, atol=1e-8)
+
+
+def test_forward_pass_on_the_handles_worker_thread_gives_the_inline_numbers(A):
+    """asvgp_set_deferred_forward_pass(h, 2): the host's long-double forward pass of the Kuu chain runs on a worker thread the handle owns,
+    posted before the launch call.  Same table, same kernel: the results are bit-identical to the inline pass over a run of dependent steps
+    (theta changes every step), switching modes back and forth on one handle works, and teardown joins the thread."""
+    rng = np.random.default_rng(21)
+    N, M = 50000, 2048
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    ls = [0.05 * (1.0 + 0.01 * i) for i in range(12)]
+    ref = []
+    for l in ls:
+        model.kernel.lengthscales.assign(l)
+        ref.append(model.elbo_and_grad_host())
+    for mode in (2, 1, 2, 0):
+        model._h.set_deferred_forward_pass(mode)
+        got = []
+        for l in ls:
+            model.kernel.lengthscales.assign(l)
+            got.append(model.elbo_and_grad_host())       # (mode 1: read_elbo_host publishes the pass itself)
+        assert got == ref, mode
+    model._h.set_deferred_forward_pass(2)
+    model.kernel.lengthscales.assign(0.05)
+    assert model.elbo_and_grad().tolist()[:4] == ref[0]       # the stream path waits for the same table
+    model.close()                                             # joins the worker
