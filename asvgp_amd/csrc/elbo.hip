@@ -823,9 +823,12 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     // chains' launch; the table then sits in the handle's device ring and no launch waits for the host
     const bool gpu_fwd = h->prior_forward_gpu;
     const double* tab_k = h->tab_dev + (size_t)slot * h->slot_doubles;
+    const unsigned long long* dd_ready = nullptr;
     if (gpu_fwd) {
+      // the matrix-core launch: the pass on the handle's own stream BESIDE the chains' launch (its Kuu workgroup waits for the ready word as
+      // it does for the host's - the P chain does not wait at all); the other launches: in front, on the same stream
       double* t = nullptr;
-      rc = handle_prior_dd_forward(h, cf.c, cf.dc, slot, st, &t);
+      rc = handle_prior_dd_forward(h, cf.c, cf.dc, slot, st, &t, nullptr, use_mfma ? seq : 0ull, use_mfma ? &dd_ready : nullptr);
       if (rc) return rc;
       tab_k = t;
     }
@@ -877,7 +880,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         }
         hipLaunchKernelGGL(kern, dim3(2 + ff.split + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                            tab_k, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
-                           (plan_first || gpu_fwd) ? (const unsigned long long*)nullptr : h->ready_dev + slot, spin_limit, ff);
+                           gpu_fwd ? dd_ready : (plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot), spin_limit, ff);
         if (gpu_fwd) return check_launch("elbo chains (matrix cores, forward pass on the GPU)");
         if (to_worker) return check_launch("elbo chains (matrix cores, forward pass on the worker thread)");
         const double t1 = host_times ? now_us() : 0.0;

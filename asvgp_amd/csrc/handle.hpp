@@ -55,6 +55,8 @@ struct Handle {
   int dd_n_img = 0;
   double* dd_img_d = nullptr;
   double* dd_tab = nullptr;               // TAB_SLOTS x slot_doubles, device memory (slot numbering shared with the pinned ring)
+  hipStream_t dd_stream = nullptr;        // the matrix-core launch runs the pass BESIDE the chains' launch (its Kuu workgroup waits on dd_ready)
+  unsigned long long* dd_ready = nullptr; // TAB_SLOTS device words: sequence number of the table the pass has finished writing
   // result mirror (asvgp_result_mirror): 16 pinned doubles the fused launch's last ticket writes [out[0..7], info[0], info[1], sequence]
   double* mirror_host = nullptr;
   double* mirror_dev = nullptr;
@@ -92,7 +94,9 @@ void handle_post_forward(Handle* h);
 // device table ring (*tab_out); the consumer is launched behind it on the same stream and needs no ready word
 int handle_prior_dd_prepare(Handle* h);
 void handle_prior_dd_release(Handle* h);
-int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out, unsigned long long* stamps = nullptr);
+// seq != 0: on the handle's own stream, concurrently with whatever `st` holds; the kernel then publishes seq in dd_ready[slot] (*ready_out)
+int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out, unsigned long long* stamps = nullptr,
+                            unsigned long long seq = 0, const unsigned long long** ready_out = nullptr);
 
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);

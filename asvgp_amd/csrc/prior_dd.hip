@@ -15,13 +15,17 @@ namespace {
 template <int B>
 __global__ __launch_bounds__(64 * pd_waves<B>()) void prior_forward_dd_kernel(const int* __restrict__ img, const double* __restrict__ stat,
                                                                               PdCoefs cf, double* __restrict__ tab, int n_img_lds,
-                                                                              unsigned long long* stamps) {
+                                                                              unsigned long long* stamps, unsigned long long* ready, unsigned long long seq) {
   extern __shared__ double lds[];
   prior_forward_dd<B>(img, n_img_lds, stat, cf, tab, lds, (int)threadIdx.x, 64 * pd_waves<B>(), stamps);
+  // a consumer on ANOTHER stream (the matrix-core launch's Kuu workgroup) waits for this word: every wave's stores are acknowledged (the
+  // barrier above), one release writes the L2 back for the other XCDs
+  if (ready && threadIdx.x == 0) __hip_atomic_store(ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int B>
-int pd_launch(const int* img_i, int n_img, int n_rec, const double* img_d, const PdCoefs& cf, double* tab, hipStream_t st, unsigned long long* stamps) {
+int pd_launch(const int* img_i, int n_img, int n_rec, const double* img_d, const PdCoefs& cf, double* tab, hipStream_t st, unsigned long long* stamps,
+              unsigned long long* ready, unsigned long long seq) {
   int n_img_lds = n_img;                                          // the class maps ride in the LDS when they fit beside the blocks
   if (sizeof(double) * pd_lds_doubles<B>(n_rec, n_img_lds) > 160 * 1024) n_img_lds = 0;
   const size_t lds_bytes = sizeof(double) * pd_lds_doubles<B>(n_rec, n_img_lds);
@@ -33,7 +37,7 @@ int pd_launch(const int* img_i, int n_img, int n_rec, const double* img_d, const
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
     granted = lds_bytes;
   }
-  hipLaunchKernelGGL(kern, dim3(1), dim3(64 * pd_waves<B>()), lds_bytes, st, img_i, img_d, cf, tab, n_img_lds, stamps);
+  hipLaunchKernelGGL(kern, dim3(1), dim3(64 * pd_waves<B>()), lds_bytes, st, img_i, img_d, cf, tab, n_img_lds, stamps, ready, seq);
   return ASVGP_OK;
 }
 
@@ -65,22 +69,40 @@ void handle_prior_dd_release(Handle* h) {
   if (h->dd_img_i) { (void)hipFree(h->dd_img_i); h->dd_img_i = nullptr; }
   if (h->dd_img_d) { (void)hipFree(h->dd_img_d); h->dd_img_d = nullptr; }
   if (h->dd_tab) { (void)hipFree(h->dd_tab); h->dd_tab = nullptr; }
+  if (h->dd_stream) { (void)hipStreamSynchronize(h->dd_stream); (void)hipStreamDestroy(h->dd_stream); h->dd_stream = nullptr; }
+  if (h->dd_ready) { (void)hipFree(h->dd_ready); h->dd_ready = nullptr; }
 }
 
 // enqueue the forward pass for one theta on `st`; the table lands in slot `slot` of the handle's DEVICE ring (returned)
-int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out, unsigned long long* stamps) {
+int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out, unsigned long long* stamps,
+                            unsigned long long seq, const unsigned long long** ready_out) {
   int rc = handle_prior_dd_prepare(h);
   if (rc) return rc;
+  hipStream_t lst = st;
+  unsigned long long* rdy = nullptr;
+  if (seq) {
+    if (!h->dd_stream) {
+      if (hipStreamCreateWithFlags(&h->dd_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&h->dd_ready), sizeof(unsigned long long) * TAB_SLOTS) != hipSuccess ||
+          hipMemset(h->dd_ready, 0, sizeof(unsigned long long) * TAB_SLOTS) != hipSuccess) {
+        set_error("prior forward pass on the GPU: stream / ready words: %s", hipGetErrorString(hipGetLastError()));
+        return ASVGP_ERR_HIP;
+      }
+    }
+    lst = h->dd_stream;
+    rdy = h->dd_ready + slot;
+    if (ready_out) *ready_out = rdy;
+  }
   PdCoefs cf;
   for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) { cf.c[t] = coef[t]; cf.dc[t] = dcoef[t]; }
   double* tab = h->dd_tab + (size_t)slot * h->slot_doubles;
   switch (prior_plan_k(h->plan)) {
-    case 1: rc = pd_launch<1>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, st, stamps); break;
-    case 2: rc = pd_launch<2>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, st, stamps); break;
-    case 3: rc = pd_launch<3>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, st, stamps); break;
-    case 4: rc = pd_launch<4>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, st, stamps); break;
-    case 5: rc = pd_launch<5>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, st, stamps); break;
-    case 6: rc = pd_launch<6>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, st, stamps); break;
+    case 1: rc = pd_launch<1>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, lst, stamps, rdy, seq); break;
+    case 2: rc = pd_launch<2>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, lst, stamps, rdy, seq); break;
+    case 3: rc = pd_launch<3>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, lst, stamps, rdy, seq); break;
+    case 4: rc = pd_launch<4>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, lst, stamps, rdy, seq); break;
+    case 5: rc = pd_launch<5>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, lst, stamps, rdy, seq); break;
+    case 6: rc = pd_launch<6>(h->dd_img_i, h->dd_n_img, prior_plan_nrec(h->plan), h->dd_img_d, cf, tab, lst, stamps, rdy, seq); break;
     default: set_error("prior forward pass on the GPU: bandwidth 1..6"); return ASVGP_ERR_BAD_ARG;
   }
   if (rc) return rc;

@@ -89,7 +89,7 @@ int asvgp_prior_interior_kuu_host(const double* static_bands_host, int n_terms, 
 /* Mantissa width of the arithmetic the host forward pass of the planned prior chain runs in: 64 (x87 extended; the build refuses any other). */
 int asvgp_host_mantissa_bits(void);
 /* The library reads its debug / measurement switches (ASVGP_SPIN_LIMIT, ASVGP_DEBUG_NO_ASSEMBLY, ASVGP_CHAIN_STAMPS, ASVGP_BCR_STAMPS,
- * ASVGP_HOST_TIMES, ASVGP_PLAN_FIRST) from the environment once; call this after changing them in a running process. */
+ * ASVGP_HOST_TIMES, ASVGP_PLAN_FIRST, ASVGP_NO_SPLIT) from the environment once; call this after changing them in a running process. */
 int asvgp_debug_reload_env(void);
 /* Deferred forward pass.  With on = 1 the matrix-core launch of asvgp_elbo_grad_1d returns right after the kernel launch; the host's
  * forward pass of the prior chain for that launch (~19 us, long double) runs in asvgp_prior_publish - which the caller issues after
@@ -224,8 +224,9 @@ size_t asvgp_prior_table_doubles(const double* static_bands_host, int n_terms, i
 int asvgp_prior_forward_host(const double* static_bands_host, int n_terms, int64_t M, int k, const double* coef_host,
                              const double* dcoef_dl_host, double* table_host, size_t table_doubles, int* node_rec_host);
 /* Where the forward (elimination) half of the planned Kuu chain runs.  mode 0 (default): on the host in x87 long double, handed over
- * through the pinned table ring.  mode 1: on the GPU in double-double arithmetic (two-fp64 error-free transforms, ~106 bits; one
- * small launch in front of the chains' launch on the same stream, table in device memory) - no host stage, no PCIe-mapped table, no
+ * through the pinned table ring.  mode 1: on the GPU in double-double arithmetic (two-fp64 error-free transforms, ~104 bits; one
+ * small launch - on the handle's own stream beside the matrix-core chains' launch, whose Kuu workgroup waits for it, else in front of
+ * the consumer on the same stream -, table in device memory) - no host stage, no PCIe-mapped table, no
  * dependence on the host's long double format.  Replaces the factorisation half of gpr.py:56-59 (banded.cholesky_band(Kuu)) either
  * way; same table (asvgp_prior_forward_host), same consumers.  Needs a plan (asvgp_prior_plan_1d) when an ELBO entry point runs. */
 int asvgp_set_prior_forward(asvgp_handle_t handle, int mode);

@@ -1933,3 +1933,38 @@ def test_forward_pass_on_the_handles_worker_thread_gives_the_inline_numbers(A):
     model.kernel.lengthscales.assign(0.05)
     assert model.elbo_and_grad().tolist()[:4] == ref[0]       # the stream path waits for the same table
     model.close()                                             # joins the worker
+
+
+@pytest.mark.parametrize("M", [512, 513, 516, 517, 1020, 1024, 1025, 1028, 1029, 1500, 2044, 2047, 2048])
+def test_p_chain_on_two_workgroups_at_awkward_sizes(A, M):
+    """The matrix-core P chain is split over two workgroups at the top of its elimination tree when nb = ceil(M / 4) >= 128 (bcr_mfma.hpp
+    BmSplit): sizes around the powers of two - a right half of one node, of none (nb = 2^j + 1: the separator is the last node), an odd
+    last block, a matrix that ends inside a block - against the oracle (statistics from the oracle, so only the chains differ), against the
+    single-workgroup chain (ASVGP_NO_SPLIT: equal to rounding) and through the host-read path."""
+    rng = np.random.default_rng(M)
+    N = 30000
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    v, l, s = 1.1, 6.0 / M, 0.02
+    ob = O.Basis(4, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
+    oe, og, _ = O.elbo_grad_1d(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(s)
+    r = model.elbo_and_grad().cpu().numpy()
+    assert abs(r[0] - oe) <= elbo_tol(oe, N, v, s, yy, bcr=True), (M, r[0], oe)
+    np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
+    rh = model.elbo_and_grad_host()
+    assert rh == r[:4].tolist()
+    os.environ["ASVGP_NO_SPLIT"] = "1"
+    _reload_env()
+    try:
+        r1 = model.elbo_and_grad().cpu().numpy()
+    finally:
+        del os.environ["ASVGP_NO_SPLIT"]
+        _reload_env()
+    np.testing.assert_allclose(r1[:4], r[:4], rtol=1e-11)
+    mean, var = model.predict_f(np.linspace(0.01, 0.99, 50).reshape(-1, 1))
+    om, ov = O.predict_f_1d_banded(ob, O.MATERN32, Ab, b, v, l, s, np.linspace(0.01, 0.99, 50).reshape(-1, 1))
+    np.testing.assert_allclose(np.asarray(mean), om, atol=1e-8)
+    np.testing.assert_allclose(np.asarray(var), ov, atol=1e-8)

@@ -44,7 +44,7 @@ for name, row in zip(("P chain (workgroup 0: left half / whole)", "Kuu backward 
         name, (row[0] - t0) / 100, (row[0] - t0 + row[1]) / 100, (row[0] - t0 + row[2]) / 100,
         (" | solve done +%.2f us" % ((row[0] - t0 + row[3]) / 100)) if row[3] > 0 else ""))
 ex = ws[off + 24 + 4: off + 24 + 7]
-print("P workgroup tail (relative to its start): helpers' bands acquired +%.2f us | trace / quadratic-form loop done +%.2f us | workgroup sums done +%.2f us" % tuple(
+print("P workgroup tail (relative to its start): barrier behind the solve +%.2f us | trace / quadratic-form loop done +%.2f us | workgroup sums done +%.2f us" % tuple(
     (st[0][0] - t0 + v) / 100 for v in ex))
 lv = ws[off + 32: off + 64]
 print("P chain (left / whole) per-phase cycles (s_memtime deltas): " + " ".join("%.1fK" % (v / 1e3) for v in lv if v > 0))
