@@ -381,7 +381,7 @@ struct FusedFin {
   long D; int n_helpers; int finalize; int debug_no_assembly; int debug_stamps;
   double* mirror; unsigned long long mirror_seq;   // asvgp_result_mirror (matrix-core launch only)
   // matrix-core launch, P chain on TWO workgroups (bcr_mfma.hpp BmSplit): workgroup 2 is the right half, the helpers start at 3
-  int split; double* xchg; unsigned* flag_rl; unsigned* flag_lr;
+  int split; double* xchg;                        // xchg: BM_XCHG doubles of message boxes
 };
 constexpr int FIN_GACC_PR = 21;                    // the right P workgroup's seven partial sums: gacc[21..27]
 __device__ __forceinline__ void assemble_band_slice(const double* __restrict__ S, const double* __restrict__ coef, const double* __restrict__ dcoef, int n_terms,
@@ -840,7 +840,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
     // chains' ~100 KB of LDS, i.e. a CU of its own; with 10 workgroups two of them shared an XCD, and the second ELBO launch of the
     // in-flight schedule found no free CU there for a helper - its P chain then waited for the whole previous launch to finish
     ff.n_helpers = (int)((M + 255) / 256 < 6 ? (M + 255) / 256 : 6);
-    ff.split = 0; ff.xchg = nullptr; ff.flag_rl = ff.flag_lr = nullptr;
+    ff.split = 0; ff.xchg = nullptr;
     ff.assembled = reinterpret_cast<unsigned*>(w.fin + 20);
     ff.debug_no_assembly = debug_env().no_assembly;
     ff.debug_stamps = debug_env().chain_stamps;   // test hook: the helpers never report -> the P chain gives up waiting
