@@ -403,11 +403,28 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
   __syncthreads();
   stamp();
   // ---------------- backward: solve + selected inverse ----------------
+  unsigned long long lw = 0ull;
   for (int l = levels - 1; l >= 0; --l) {
     const int h = 1 << l;
     const int ne = (nb > h) ? (nb - h + 2 * h - 1) / (2 * h) : 0;
     int m0, ne_h;
     level_share(l, ne, m0, ne_h);
+    if (split && sp.half == 0 && wv == BM_THREADS / 64 - 1) {
+      // the right workgroup's log-det part and bad column (sent ~10 us ago): a wave without nodes on the narrow levels requests the message
+      // at the top of the backward pass and validates it a few levels later - at the very end the round trip would sit on the finisher's
+      // critical path (not there yet / torn: a blocking receive, here, still off that path)
+      if (l == top - 1 && lane <= 2)
+        lw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(sp.xchg + 24) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (l == 2) {
+        const unsigned long long x = bm_wave_xor(lane < 2 ? lw : 0ull) ^ (sp.tag | 2ull);
+        const unsigned long long chk = (unsigned long long)__shfl((long long)lw, 2, 64);
+        double v = __longlong_as_double((long long)lw);
+        bool ok = x == chk;
+        if (!ok) ok = bm_msg_recv(sp.xchg + 24, 2, v, sp.tag | 2ull, lane, sp.spin_limit);
+        if (!ok) { if (lane == 0) *sp.gave_up = 1; }
+        else if (lane < 2) red[48 + lane] = v;
+      }
+    }
 #pragma unroll
     for (int rd = 0; rd < RMAXR; ++rd) {
       __builtin_amdgcn_sched_barrier(0);
@@ -522,11 +539,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_solve(Src A, const doubl
     int* sbad = reinterpret_cast<int*>(red + 32);
     if (lane == 0) { red[wv] = tot; sbad[wv] = bm; }
     __syncthreads();
-    if (split && wv == 0) {                                       // the right workgroup's part (sent tens of microseconds ago)
-      double v = 0.0;
-      if (!bm_msg_recv(sp.xchg + 24, 2, v, sp.tag | 2ull, lane, sp.spin_limit)) { if (lane == 0) *sp.gave_up = 1; }
-      else { s_other = __shfl(v, 0, 64); bad_other = (int)__shfl(v, 1, 64); }
-    }
+    if (split && tid == 0) { s_other = red[48]; bad_other = (int)red[49]; }   // (fetched during the backward pass)
     if (tid == 0) {
       double s = 0.0;
       int bmin = 0x7fffffff;

@@ -488,8 +488,9 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       logdets[(slot < 4 ? 8 + 4 * (int)blockIdx.x : 24) + slot] = (slot == 0) ? (double)(t_start & 0xffffffffull) : (double)((__builtin_amdgcn_s_memrealtime() - t_start) & 0xffffffffull);
   };
   rstamp(0);
-  __shared__ int gave_up;
-  if (threadIdx.x == 0) gave_up = 0;
+  __shared__ int gave_up, kuu_ok;
+  __shared__ double kuu_pref[4];
+  if (threadIdx.x == 0) { gave_up = 0; kuu_ok = 0; }
   __syncthreads();
   const double* stats = fin.stats;
   enum { LOGK, LOGP, TRKA, DTRKA, SKDK, SPDK, SKK, SPK, SPA, CC, AKA, ADKA, AAA, BA, NACC };
@@ -537,6 +538,12 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
       while ((1 << lv) < nbl) ++lv;
       const long jsep = (long)(1 << (lv > 0 ? lv - 1 : 0)) * K;
       const long j0 = isPR ? jsep : 0, j1 = (fin.split && !isPR) ? jsep : (long)M;
+      // the Kuu workgroup's sums (sent ~10 us ago): wave 1 of the finisher requests the message HERE and validates it behind the loop - at
+      // the very end the round trip would sit on the critical path (not there yet / torn: the finisher polls as before)
+      unsigned long long kw = 0ull;
+      const bool kuu_reader = !isPR && (threadIdx.x >> 6) == 1;
+      if (kuu_reader && (threadIdx.x & 63) <= 4)
+        kw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(fin.gacc + 8) + (threadIdx.x & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       double sp[2][K + 1], av[2][K + 1], bj[2];
 #pragma unroll
       for (int cI = 0; cI < 2; ++cI) {
@@ -574,6 +581,12 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
           acc[AAA] = fma(av[cI][r], xx, acc[AAA]);
         }
         acc[BA] = fma(bj[cI], xj, acc[BA]);
+      }
+      if (kuu_reader) {
+        const int ln = threadIdx.x & 63;
+        const unsigned long long x = bm_wave_xor(ln < 4 ? kw : 0ull) ^ ((seq << 8) | 4ull);
+        const unsigned long long chk = (unsigned long long)__shfl((long long)kw, 4, 64);
+        if (x == chk) { if (ln < 4) kuu_pref[ln] = __longlong_as_double((long long)kw); if (ln == 0) kuu_ok = 1; }
       }
     }
   } else {
@@ -679,7 +692,9 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   }
   double kuu_v = 0.0, pr_v = 0.0;
   {
-    bool ok = bm_msg_recv(box_kuu, 4, kuu_v, mtag | 4ull, lane, spin_limit);
+    bool ok = true;
+    if (kuu_ok) kuu_v = lane < 4 ? kuu_pref[lane] : 0.0;         // (validated behind the trace loop)
+    else ok = bm_msg_recv(box_kuu, 4, kuu_v, mtag | 4ull, lane, spin_limit);
     if (ok && fin.split) ok = bm_msg_recv(box_pr, 7, pr_v, mtag | 5ull, lane, spin_limit);
     if (!ok) { if (lane == 0) atomicExch(info + 1, -1); return; }   // (a chain that gave up never reports: no bound is written)
   }
