@@ -56,6 +56,7 @@ SIGNATURES = {
     "asvgp_set_prior_forward": (_I, [_P, _I]),
     "asvgp_prior_forward_device": (_I, [_P, _P, _P, _P, _Z, _P]),
     "asvgp_prior_forward_stamps": (_I, [_P, _P, _P, _P, _P]),
+    "asvgp_prior_plan_image_host": (_I, [_P, _I, _L, _I, _P, _P, _P, _P]),
     "asvgp_elbo_grad_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "asvgp_kuu_inverse_band_1d": (_I, [_P, _P, _I, _D, _D, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "asvgp_elbo_chain_sync": (_I, [_P, _I]),

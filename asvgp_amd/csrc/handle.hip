@@ -395,3 +395,22 @@ extern "C" int asvgp_prior_forward_host(const double* static_bands_host, int n_t
   prior_plan_destroy(p);
   return ASVGP_OK;
 }
+
+// Host-only: the device image of the plan (what the GPU forward pass of prior_dd.hpp walks): ints / doubles as laid out in prior_plan.cpp.
+// Call with NULL buffers to get the sizes.  For the CPU tests.
+extern "C" int asvgp_prior_plan_image_host(const double* static_bands_host, int n_terms, int64_t M, int k, int* ints, size_t* n_ints,
+                                           double* doubles, size_t* n_doubles) {
+  if (!n_ints || !n_doubles) { set_error("prior_plan_image_host: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  char err[256] = "";
+  PriorPlan* p = prior_plan_create(static_bands_host, n_terms, (long)M, k, err, sizeof(err));
+  if (!p) { set_error("%s", err); return strstr(err, "bad argument") ? ASVGP_ERR_BAD_ARG : ASVGP_ERR_UNSUPPORTED; }
+  const size_t ni = prior_plan_image_ints(p), nd = prior_plan_image_doubles(p);
+  int rc = ASVGP_OK;
+  if (ints && doubles) {
+    if (*n_ints < ni || *n_doubles < nd) { set_error("prior_plan_image_host: buffers too small"); rc = ASVGP_ERR_WORKSPACE; }
+    else prior_plan_image(p, ints, doubles);
+  }
+  *n_ints = ni; *n_doubles = nd;
+  prior_plan_destroy(p);
+  return rc;
+}

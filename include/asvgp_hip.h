@@ -234,6 +234,10 @@ int asvgp_set_prior_forward(asvgp_handle_t handle, int mode);
  * `stream` and copied to table_host (asvgp_prior_table_doubles entries); synchronises the stream. */
 int asvgp_prior_forward_device(asvgp_handle_t handle, const double* coef_host, const double* dcoef_dl_host, double* table_host,
                                size_t table_doubles, void* stream);
+/* Host-only: the plan's device image (class maps as ints, level-0 static-band entries as doubles: csrc/prior_plan.cpp) - what the GPU
+ * forward pass walks.  ints / doubles NULL: sizes only.  For the CPU tests. */
+int asvgp_prior_plan_image_host(const double* static_bands_host, int n_terms, int64_t M, int k, int* ints, size_t* n_ints,
+                                double* doubles, size_t* n_doubles);
 /* Diagnostics: s_memtime stamps of thread 0 along one GPU forward pass (out64: 64 values, [63] = how many; tools/prior_dd_probe.py). */
 int asvgp_prior_forward_stamps(asvgp_handle_t handle, const double* coef_host, const double* dcoef_dl_host, uint64_t* out64, void* stream);
 int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,

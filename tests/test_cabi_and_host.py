@@ -333,3 +333,52 @@ def test_prior_plan_host_forward_vs_long_double_bcr(lib, order, M, kind, l):
     Sr = np.ascontiguousarray(S + rng.uniform(0, 1e-3, S.shape) * (np.abs(S) > 0))
     if nb > 64:
         assert lib.asvgp_prior_table_doubles(Sr.ctypes.data, len(terms), M, order) == 0
+
+
+@pytest.mark.parametrize("order,M,kind", [(4, 2048, 1), (4, 2047, 1), (3, 333, 2), (6, 90, 1), (1, 37, 0), (4, 13, 0), (4, 4096, 2)])
+def test_prior_plan_device_image_is_consistent_with_the_host_plan(lib, order, M, kind):
+    """The GPU forward pass (csrc/prior_dd.hpp, asvgp_set_prior_forward(h, 1)) walks a flat image of the plan: class maps per level as ints,
+    the static-band entries of the level-0 representative blocks as doubles.  Host-only checks: header fields, level offsets inside the
+    image, class indices inside the previous level's class counts, node counts summing to the number of nodes a level eliminates, record
+    numbering equal to the host table's, and the level-0 entries reproducing Kuu's blocks exactly (same rounding sequence as make_Kuu)."""
+    bs = O.Basis(order, 0, 1, M)
+    terms = O.kuu_terms(kind, 0.9, 0.07)
+    S = np.ascontiguousarray(np.stack([getattr(bs, nm) for nm, _, _ in terms]))
+    ni, nd = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.asvgp_prior_plan_image_host(S.ctypes.data, len(terms), M, order, None, ctypes.byref(ni), None, ctypes.byref(nd)) == 0
+    ints = np.zeros(ni.value, dtype=np.int32)
+    dbl = np.zeros(max(nd.value, 1))
+    assert lib.asvgp_prior_plan_image_host(S.ctypes.data, len(terms), M, order, ints.ctypes.data, ctypes.byref(ni), dbl.ctypes.data, ctypes.byref(nd)) == 0
+    B, nt, levels, n_rec, nd0, ne0, off_lv, total, off_dc, off_ec = [int(v) for v in ints[:10]]
+    nb = (M + B - 1) // B
+    assert B == order and nt == len(terms) and total == ni.value and off_lv == 16 and (1 << levels) >= nb > (1 << levels) // 2
+    n = lib.asvgp_prior_table_doubles(S.ctypes.data, len(terms), M, order)
+    assert n == 8 + 2 * n_rec * (6 * B * B + B)
+    prev_d, prev_e, rec, left = nd0, ne0, 0, nb
+    for l in range(levels):
+        nq, ndn, o_node, o_rep, o_dn, rec0 = [int(v) for v in ints[off_lv + 8 * l: off_lv + 8 * l + 6]]
+        assert rec0 == rec and 0 < nq <= 24 and 0 < ndn <= 24 and 16 + 8 * levels <= o_node < o_rep <= o_dn < off_dc
+        node = ints[o_node:o_node + 4 * nq].reshape(nq, 4)
+        assert node[:, 0].min() >= 0 and node[:, 0].max() < prev_d and node[:, 1].min() >= 0 and node[:, 1].max() < prev_e
+        assert node[:, 2].min() >= -1 and node[:, 2].max() < prev_e
+        assert int(node[:, 3].sum()) == left // 2                    # every second node of the level is eliminated
+        reps = ints[o_rep:o_rep + nq]
+        assert reps.min() >= 0 and reps.max() < nb
+        dn = ints[o_dn:o_dn + 3 * ndn].reshape(ndn, 3)
+        assert dn[:, 0].min() >= 0 and dn[:, 0].max() < prev_d and dn[:, 1:].min() >= -1 and dn[:, 1:].max() < nq
+        rec += nq
+        left -= left // 2
+        prev_d, prev_e = ndn, nq                                     # next level: D classes; couplings = the fills of the eliminated nodes
+    assert rec == n_rec - 1 and left == 1
+    # level-0 entries: sum_t c_t * entry_t equals the Kuu block entries of a representative (class 0 = block 0: the top-left corner)
+    c = np.array([t[1] for t in terms])
+    K = O.make_Kuu(bs, kind, 0.9, 0.07)
+    codes = ints[off_dc:off_dc + B * B].reshape(B, B)
+    ent = dbl[:B * B * nt].reshape(B, B, nt)
+    for r in range(B):
+        for cc in range(r + 1):
+            if r < M:
+                acc = c[0] * ent[r, cc, 0]
+                for t in range(1, nt):
+                    acc = acc + c[t] * ent[r, cc, t]
+                assert codes[r, cc] == 0 and acc == K[r - cc, cc], (r, cc)
