@@ -71,11 +71,11 @@ def run(name, phi, defer, event, prio=-1, steps=200, wgs=240, phi_first=False, n
 run("M side only (theta, launch, poll)", False, False, False)
 run("M side only, forward pass on the worker thread", False, False, False, worker=True)
 run("bench.py round-3 first form: ELBO launch, Phi + reduce + event (two buffer sets)", True, False, True)
-run("Phi KERNEL first, ELBO launch, then reduce + event (two buffer sets)", True, False, True, phi_first=True, split=True)
-run("same, forward pass on the worker thread (= bench.py's `value` schedule)", True, False, True, phi_first=True, split=True, worker=True)
+run("Phi KERNEL first, ELBO launch, then reduce + event (two buffer sets) = bench.py's `value`", True, False, True, phi_first=True, split=True)
+run("same, forward pass on the worker thread (bench.py --worker-forward)", True, False, True, phi_first=True, split=True, worker=True)
 run("same, both streams at default priority", True, False, True, phi_first=True, split=True, prio=0)
 run("same, Phi grid 248 workgroups", True, False, True, phi_first=True, split=True, wgs=248)
 run("three buffer sets: ELBO launch first, Phi of step i+2 behind it", True, False, True, nl=3)
 run("same, both streams at default priority", True, False, True, nl=3, prio=0)
 run("three buffer sets, split Phi (kernel, ELBO launch, reduce + event)", True, False, True, nl=3, phi_first=True, split=True)
-run("three buffer sets, forward pass on the worker thread (= bench.py's three-set extra)", True, False, True, nl=3, worker=True)
+run("three buffer sets, forward pass on the worker thread (bench.py --worker-forward)", True, False, True, nl=3, worker=True)
