@@ -172,53 +172,33 @@ template <int K>
 __device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn, unsigned ho, int first, int stride, int lane, double* slot) {
   constexpr int NS = 2 * K;
   const unsigned nsl = (hn + 63u) >> 6;
-  {
-    double S2[NS];
+  // ONE pass: every point read once, powers shared by the S and the T sums (two passes - S then T - re-read the run and re-formed the
+  // powers: ~25 % more instructions in what is half of a sorted input's kernel time)
+  double S2[NS], T2[K + 1];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) S2[q] = 0.0;
-    for (unsigned sl = (unsigned)first; sl < nsl; sl += (unsigned)stride) {
-      const unsigned j = sl * 64 + lane;
-      if (j < hn) {
-        const double sv = buf[ho + j].x;
-        double pw[K + 1];
-        pw[0] = 1.0; pw[1] = sv;
+  for (int q = 0; q < NS; ++q) S2[q] = 0.0;
 #pragma unroll
-        for (int q = 2; q <= K; ++q) pw[q] = pw[q / 2] * pw[q - q / 2];
-#pragma unroll
-        for (int q = 1; q <= K; ++q) S2[q - 1] += pw[q];
-#pragma unroll
-        for (int q = K + 1; q <= NS; ++q) S2[q - 1] = fma(pw[K], pw[q - K], S2[q - 1]);
-      }
+  for (int q = 0; q <= K; ++q) T2[q] = 0.0;
+  for (unsigned sl = (unsigned)first; sl < nsl; sl += (unsigned)stride) {
+    const unsigned j = sl * 64 + lane;
+    if (j < hn) {
+      const double2 pt = buf[ho + j];
+      ps_acc<K>(pt.x, pt.y, S2, T2);
     }
-    if constexpr (NS <= 8) {
-      int idx;
-      const double t = ps_reduce_scatter8<NS>(S2, lane, idx);
-      if (lane < 8 && idx < NS) lds_add(slot + idx, t);
-    } else {
+  }
+  if constexpr (NS <= 8) {
+    int idx;
+    const double t = ps_reduce_scatter8<NS>(S2, lane, idx);
+    if (lane < 8 && idx < NS) lds_add(slot + idx, t);
+  } else {
 #pragma unroll
-      for (int q = 0; q < NS; ++q) { const double t = wave_sum_dpp(S2[q]); if (lane == 0) lds_add(slot + q, t); }
-    }
+    for (int q = 0; q < NS; ++q) { const double t = wave_sum_dpp(S2[q]); if (lane == 0) lds_add(slot + q, t); }
   }
   __builtin_amdgcn_sched_barrier(0);
   {
-    double T2[K + 1];
-#pragma unroll
-    for (int q = 0; q <= K; ++q) T2[q] = 0.0;
-    for (unsigned sl = (unsigned)first; sl < nsl; sl += (unsigned)stride) {
-      const unsigned j = sl * 64 + lane;
-      if (j < hn) {
-        const double2 pt = buf[ho + j];
-        double pw = 1.0;
-        T2[0] += pt.y;
-#pragma unroll
-        for (int q = 1; q <= K; ++q) { pw *= pt.x; T2[q] = fma(pt.y, pw, T2[q]); }
-      }
-    }
-    {
-      int idx;
-      const double t = ps_reduce_scatter8<K + 1>(T2, lane, idx);
-      if (lane < 8 && idx <= K) lds_add(slot + NS + idx, t);
-    }
+    int idx;
+    const double t = ps_reduce_scatter8<K + 1>(T2, lane, idx);
+    if (lane < 8 && idx <= K) lds_add(slot + NS + idx, t);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
