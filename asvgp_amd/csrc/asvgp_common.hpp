@@ -98,6 +98,20 @@ __device__ __forceinline__ double dpp_step_add(double v) {
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
   return v + __hiloint2double(hi, lo);
 }
+// One DPP move of a double (two 32-bit halves): lane exchanges on the VALU instead of the LDS crossbar (__shfl_xor = ds_bpermute: ~100
+// cycles of latency per step of a dependent chain).  quad_perm 0xB1 = lane ^ 1, 0x4E = lane ^ 2; row_ror:8 (0x128) = lane ^ 8; lane ^ 4 is
+// row_ror:12 (0x12C) for lanes with bit 2 clear and row_ror:4 (0x124) for the others.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_xor4_f64(double x, bool bit2) {
+  const double up = dpp_move_f64<0x12C>(x), dn = dpp_move_f64<0x124>(x);
+  return bit2 ? dn : up;
+}
+
 __device__ __forceinline__ double wave_sum_dpp(double v) {
   v = dpp_step_add<0x111, 0xf>(v);   // row_shr:1
   v = dpp_step_add<0x112, 0xf>(v);   // row_shr:2

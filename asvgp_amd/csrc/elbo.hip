@@ -656,11 +656,11 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
   double s4[4], s2[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const double keep = b0 ? mine[4 + i] : mine[i], send = b0 ? mine[i] : mine[4 + i]; s4[i] = keep + __shfl_xor(send, 1, 64); }
+  for (int i = 0; i < 4; ++i) { const double keep = b0 ? mine[4 + i] : mine[i], send = b0 ? mine[i] : mine[4 + i]; s4[i] = keep + dpp_move_f64<0xB1>(send); }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const double keep = b1 ? s4[2 + i] : s4[i], send = b1 ? s4[i] : s4[2 + i]; s2[i] = keep + __shfl_xor(send, 2, 64); }
-  double s1 = (b2 ? s2[1] : s2[0]) + __shfl_xor(b2 ? s2[0] : s2[1], 4, 64);
-  s1 += __shfl_xor(s1, 8, 64); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  for (int i = 0; i < 2; ++i) { const double keep = b1 ? s4[2 + i] : s4[i], send = b1 ? s4[i] : s4[2 + i]; s2[i] = keep + dpp_move_f64<0x4E>(send); }
+  double s1 = (b2 ? s2[1] : s2[0]) + dpp_xor4_f64(b2 ? s2[0] : s2[1], b2);      // (lanes ^ 1, ^ 2, ^ 4, ^ 8: DPP moves, no LDS crossbar)
+  s1 += dpp_move_f64<0x128>(s1); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
   // lane l < 8 now holds the wave total of accumulator idx(l) = 4 bit0 + 2 bit1 + bit2; it files it under its OWN lane number
   const int wv = threadIdx.x >> 6;
   if (lane < 8) part0[wv * 8 + lane] = s1;

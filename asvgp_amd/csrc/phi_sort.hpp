@@ -151,6 +151,8 @@ __device__ __forceinline__ void ps_own_cell(const double2* buf, unsigned l, unsi
 // Sum each of up to 8 per-lane values over the 64 lanes as a reduce-scatter butterfly: after the exchanges with lanes ^1, ^2, ^4 a lane
 // carries ONE of the values summed over its group of 8, three more exchanges finish it - 10 shuffles instead of 8 x 6 DPP steps (the
 // separate wave reductions were 83 K of the 164 K cycles a workgroup spends on sorted input).  Returns the total of value `idx`.
+// (the exchanges with lanes ^ 1, ^ 2, ^ 4, ^ 8 are DPP moves on the VALU - asvgp_common.hpp dpp_move_f64 -: as ds_bpermute-based __shfl_xor the
+// two butterflies of a slice group were ~5 us of a sorted input's pass)
 template <int NV>
 __device__ __forceinline__ double ps_reduce_scatter8(const double (&v)[NV], int lane, int& idx) {
   static_assert(NV <= 8, "at most eight values");
@@ -159,11 +161,13 @@ __device__ __forceinline__ double ps_reduce_scatter8(const double (&v)[NV], int 
 #pragma unroll
   for (int i = 0; i < 8; ++i) a8[i] = i < NV ? v[i] : 0.0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const double keep = b0 ? a8[4 + i] : a8[i], send = b0 ? a8[i] : a8[4 + i]; s4[i] = keep + __shfl_xor(send, 1, 64); }
+  for (int i = 0; i < 4; ++i) { const double keep = b0 ? a8[4 + i] : a8[i], send = b0 ? a8[i] : a8[4 + i]; s4[i] = keep + dpp_move_f64<0xB1>(send); }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const double keep = b1 ? s4[2 + i] : s4[i], send = b1 ? s4[i] : s4[2 + i]; s2[i] = keep + __shfl_xor(send, 2, 64); }
-  double s1 = (b2 ? s2[1] : s2[0]) + __shfl_xor(b2 ? s2[0] : s2[1], 4, 64);
-  s1 += __shfl_xor(s1, 8, 64); s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  for (int i = 0; i < 2; ++i) { const double keep = b1 ? s4[2 + i] : s4[i], send = b1 ? s4[i] : s4[2 + i]; s2[i] = keep + dpp_move_f64<0x4E>(send); }
+  // lane ^ 4 = 4 lanes up (bit 2 clear: row_ror:12) or down (set: row_ror:4) inside the row of 16; lane ^ 8 = row_ror:8
+  double s1 = (b2 ? s2[1] : s2[0]) + dpp_xor4_f64(b2 ? s2[0] : s2[1], b2);
+  s1 += dpp_move_f64<0x128>(s1);
+  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
   idx = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
   return s1;
 }
