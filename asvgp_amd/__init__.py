@@ -30,6 +30,17 @@ def set_phi_algorithm(algo):
     set_default_algorithms(phi=int(algo))
 
 
+def set_phi_input_order(order):
+    """Input order of the tile-sort Phi pass (asvgp_set_phi_input_order): 0 = probe once per data buffer (default), 1 = unsorted,
+    2 = time series (sorted / locally sorted x: the instantiation with the time-series front loop).  The statistics are the same
+    either way; applied to every live model handle and to models created later."""
+    from ._lib import AsvgpError, get_lib, set_default_algorithms
+    get_lib()
+    if int(order) not in (0, 1, 2):
+        raise AsvgpError("set_phi_input_order: 0 (probe), 1 (unsorted) or 2 (time series)")
+    set_default_algorithms(phi_order=int(order))
+
+
 def set_prior_forward(mode):
     """Where the forward (elimination) half of the Kuu chain runs: 0 = on the host in x87 long double (default; prior_plan.cpp), 1 = on the
     GPU in double-double arithmetic (prior_dd.hip: no host stage, no dependence on the host's long double) - asvgp_set_prior_forward,

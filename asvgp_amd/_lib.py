@@ -21,6 +21,8 @@ SIGNATURES = {
     "asvgp_phi_accumulate_1d": (_I, [_P, _P, _P, _L, _L, _P, _L, _D, _I, _L, _P, _P, _Z, _P]),
     "asvgp_set_phi_algorithm": (_I, [_P, _I]),
     "asvgp_phi_last_algorithm": (_I, [_P]),
+    "asvgp_set_phi_input_order": (_I, [_P, _I]),
+    "asvgp_phi_last_input_order": (_I, [_P]),
     "asvgp_stream_probe": (_I, [_P, _P, _L, _P, _P]),
     "asvgp_debug_reload_env": (_I, []),
     "asvgp_set_deferred_forward_pass": (_I, [_P, _I]),
@@ -28,6 +30,8 @@ SIGNATURES = {
     "asvgp_host_mantissa_bits": (_I, []),
     "asvgp_prior_interior_kuu_host": (_I, [_P, _I, _L, _I, _P, _P, _c.POINTER(_L), _c.POINTER(_L), _P]),
     "asvgp_result_mirror": (_I, [_P, _I, _c.POINTER(_P)]),
+    "asvgp_result_mirror_read": (_I, [_P, _c.c_uint64, _P, _D]),
+    "asvgp_elbo_grad_host_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P, _P, _D]),
     "asvgp_result_mirror_pending": (_c.c_uint64, [_P]),
     "asvgp_set_phi_workgroups": (_I, [_P, _I]),
     "asvgp_set_phi_deferred_reduce": (_I, [_P, _I]),
@@ -119,7 +123,7 @@ def check(status, what=""):
 class Handle:
     """asvgp_create / asvgp_destroy: the library state of ONE model (algorithm choices, Phi workgroup count, chain events,
     timing ring, prior-chain plan).  Models own one each, so two models may step on two streams / host threads."""
-    _defaults = {"band": 0, "phi": 0, "prior_forward": 0}
+    _defaults = {"band": 0, "phi": 0, "prior_forward": 0, "phi_order": 0}
     _live = None
 
     def __init__(self):
@@ -129,6 +133,7 @@ class Handle:
         check(lib.asvgp_create(ctypes.byref(h)), "asvgp_create")
         self.ptr = h
         self._lib = lib
+        self.band_algorithm = 0
         if Handle._live is None:
             Handle._live = weakref.WeakSet()
         Handle._live.add(self)
@@ -138,6 +143,8 @@ class Handle:
             self.set_phi_algorithm(Handle._defaults["phi"])
         if Handle._defaults["prior_forward"]:
             self.set_prior_forward(Handle._defaults["prior_forward"])
+        if Handle._defaults["phi_order"]:
+            self.set_phi_input_order(Handle._defaults["phi_order"])
 
     def set_prior_forward(self, mode):
         """asvgp_set_prior_forward: 0 = the Kuu chain's forward pass on the host (x87 long double), 1 = on the GPU (double-double)."""
@@ -155,12 +162,20 @@ class Handle:
 
     def set_band_algorithm(self, algo):
         check(self._lib.asvgp_set_band_algorithm(self.ptr, int(algo)), "set_band_algorithm")
+        self.band_algorithm = int(algo)        # (what THIS handle runs: restored after a fallback step)
 
     def set_phi_algorithm(self, algo):
         check(self._lib.asvgp_set_phi_algorithm(self.ptr, int(algo)), "set_phi_algorithm")
 
     def phi_last_algorithm(self):
         return int(self._lib.asvgp_phi_last_algorithm(self.ptr))
+
+    def set_phi_input_order(self, order):
+        """asvgp_set_phi_input_order: 0 probe once per (x, N), 1 unsorted, 2 time series (selects the tile-sort instantiation)."""
+        check(self._lib.asvgp_set_phi_input_order(self.ptr, int(order)), "set_phi_input_order")
+
+    def phi_last_input_order(self):
+        return int(self._lib.asvgp_phi_last_input_order(self.ptr))
 
     def result_mirror(self, enable=True):
         """asvgp_result_mirror: the handle's 16 pinned doubles [out[0..7], info[0], info[1], sequence] as a numpy view (None when off)."""
@@ -219,13 +234,17 @@ class Handle:
         self.close()
 
 
-def set_default_algorithms(band=None, phi=None, prior_forward=None):
+def set_default_algorithms(band=None, phi=None, prior_forward=None, phi_order=None):
     """Algorithm choice for every live handle and for handles created later (asvgp_amd.set_band_algorithm / set_phi_algorithm /
     set_prior_forward)."""
     if prior_forward is not None:
         Handle._defaults["prior_forward"] = int(prior_forward)
         for h in list(Handle._live or ()):
             h.set_prior_forward(prior_forward)
+    if phi_order is not None:
+        Handle._defaults["phi_order"] = int(phi_order)
+        for h in list(Handle._live or ()):
+            h.set_phi_input_order(phi_order)
     if band is not None:
         Handle._defaults["band"] = int(band)
     if phi is not None:

@@ -732,14 +732,15 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
     out[0] = elbo; out[1] = d_v; out[2] = d_l; out[3] = d_s;
     out[4] = tot[LOGK]; out[5] = tot[LOGP]; out[6] = tot[TRKA]; out[7] = tot[CC];
     if (fin.mirror) {
-      // Pinned host memory: ten values and their sum, then - once those stores have been acknowledged - the sequence number.  (No
-      // system-scope RELEASE here: that would write the whole L2 back first, ~10 us.  System-scope stores go straight through; the
-      // host re-checks the sum after it has seen the sequence number.)
+      // Pinned host memory: ten values, their checksum, the sequence number.  (No system-scope RELEASE here: that would write the
+      // whole L2 back first, ~10 us.  System-scope stores go straight through, in no guaranteed order - so the checksum is BOUND to
+      // the launch: sequence number + the ten values, added left to right.  A host that sees the new sequence number beside the
+      // previous launch's values and checksum - all of them stale, hence consistent with each other - rejects them.)
       double* m = fin.mirror;
       const double mv[10] = {elbo, d_v, d_l, d_s, tot[LOGK], tot[LOGP], tot[TRKA], tot[CC],
                              (double)__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                              (double)__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-      double sum = 0.0;
+      double sum = (double)fin.mirror_seq;
 #pragma unroll
       for (int i = 0; i < 10; ++i) { __hip_atomic_store(m + i, mv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); sum += mv[i]; }
       __hip_atomic_store(m + 11, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1137,6 +1138,51 @@ static int elbo_args_ok(const void* stats, const void* S, const void* out, int64
   if (M > 0x3fffffff) { set_error("%s: M too large", who); return ASVGP_ERR_UNSUPPORTED; }
   if (!ws || wsb < asvgp_elbo_workspace_bytes(M, k, D)) { set_error("%s: workspace too small", who); return ASVGP_ERR_WORKSPACE; }
   return ASVGP_OK;
+}
+
+// asvgp_elbo_grad_1d + the host's read of its result in ONE call (an optimiser's evaluation, example.py:31-32): launch with the result
+// mirror armed, then poll the mirror from C.  result[0..9] = [out[0..7], info[0], info[1]].
+extern "C" int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
+                                  double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                                  double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+extern "C" int asvgp_result_mirror_read(asvgp_handle_t handle, uint64_t token, double* result10, double timeout_seconds) {
+  Handle* h = as_handle(handle);
+  if (!result10) { set_error("result_mirror_read: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  handle_publish_forward(h);                 // (deferred-forward-pass mode: the launch must not be left waiting for its table)
+  if (token == 0 || !h->mirror_host) return 1;                    // this launch does not write the mirror: read through the stream
+  volatile const double* m = h->mirror_host;
+  const double want = (double)token;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned long spins = 0;; ++spins) {
+    if (m[10] == want) {
+      double r[12];
+      for (int i = 0; i < 12; ++i) r[i] = m[i];
+      double sum = want;
+      for (int i = 0; i < 10; ++i) sum += r[i];                   // (left to right, as the kernel adds)
+      if (r[10] == want && (sum == r[11] || r[11] != r[11])) {     // (NaN results pass through)
+        for (int i = 0; i < 10; ++i) result10[i] = r[i];
+        return ASVGP_OK;
+      }
+    }
+    __builtin_ia32_pause();
+    if ((spins & 1023) == 1023) {
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_seconds) return 1;   // (a launch that gave up never writes it)
+    }
+  }
+}
+extern "C" int asvgp_elbo_grad_host_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
+                                       double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                                       double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream,
+                                       double* result10, double timeout_seconds) {
+  Handle* h = as_handle(handle);
+  if (!h->mirror_host) { const double* p = nullptr; const int rcm = asvgp_result_mirror(handle, 1, &p); if (rcm) return rcm; }
+  const int rc = asvgp_elbo_grad_1d(handle, stats, static_bands, kind, variance, lengthscale, noise_variance, N, M, k, D, out, info, workspace,
+                                    workspace_bytes, stream);
+  if (rc) return rc;
+  return asvgp_result_mirror_read(handle, h->mirror_pending, result10, timeout_seconds);
 }
 
 extern "C" int asvgp_elbo_grad_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,

@@ -213,6 +213,7 @@ extern "C" int asvgp_destroy(asvgp_handle_t handle) {
   if (h->evP) (void)hipEventDestroy(h->evP);
   if (h->prof_made)
     for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(h->prof_ev[i][0]); (void)hipEventDestroy(h->prof_ev[i][1]); }
+  if (h->order_dev) { (void)hipFree(h->order_dev); h->order_dev = nullptr; }
   h->magic = 0;
   delete h;
   return ASVGP_OK;
@@ -226,6 +227,16 @@ extern "C" int asvgp_set_phi_algorithm(asvgp_handle_t handle, int algo) {
   as_handle(handle)->phi_algo = algo;
   return ASVGP_OK;
 }
+
+extern "C" int asvgp_set_phi_input_order(asvgp_handle_t handle, int order) {
+  if (order < 0 || order > 2) { set_error("set_phi_input_order: 0 probe once per (x, N), 1 unsorted, 2 time series"); return ASVGP_ERR_BAD_ARG; }
+  Handle* h = as_handle(handle);
+  h->phi_order = order;
+  h->n_order_seen = 0;
+  return ASVGP_OK;
+}
+
+extern "C" int asvgp_phi_last_input_order(asvgp_handle_t handle) { return as_handle(handle)->phi_last_series ? 2 : 1; }
 
 extern "C" int asvgp_set_phi_workgroups(asvgp_handle_t handle, int n) {
   if (n < 0 || n > 256) { set_error("set_phi_workgroups: 0 (default, one per CU) .. 256"); return ASVGP_ERR_BAD_ARG; }
@@ -362,11 +373,12 @@ extern "C" int asvgp_prior_plan_1d(asvgp_handle_t handle, const double* static_b
     set_error("prior_plan_1d: device / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
     return ASVGP_ERR_HIP;
   }
-  memset(h->done_host, 0, sizeof(unsigned long long) * TAB_SLOTS);
-  memset(h->ready_host, 0, sizeof(unsigned long long) * TAB_SLOTS);
+  // The handle's sequence number is MONOTONIC across re-plans: the message boxes of the split launch in the caller's
+  // workspace (separator share, partial sums, done words) are validated by tags derived from it and are never cleared, so a new plan
+  // that started again at 1 could accept what the old plan's launch number 1 left there.  The fresh ring counts as consumed up to it.
+  for (int i = 0; i < TAB_SLOTS; ++i) { h->done_host[i] = h->seq; h->ready_host[i] = h->seq; }
   h->plan = p;
   h->plan_terms = n_terms;
-  h->seq = 0;
   if (planned) *planned = 1;
   return ASVGP_OK;
 }

@@ -66,6 +66,15 @@ struct Handle {
   struct MeshSeen { const double* ptr; long n; int regular; double step, first, last; };
   MeshSeen mesh_seen[8];
   int n_mesh_seen = 0;
+  // input order of the Phi pass (asvgp_set_phi_input_order): 0 = probe once per (x pointer, N) - a sample of 128-point rows, one
+  // 4-byte device-to-host copy -, 1 = treat as unsorted, 2 = treat as a time series.  Both kernels are correct for ANY input: the
+  // verdict only chooses between the instantiation that is fastest on i.i.d. points and the one with the time-series front loop.
+  int phi_order = 0;
+  struct OrderSeen { const double* ptr; long n; int series; };
+  OrderSeen order_seen[8];
+  int n_order_seen = 0;
+  int* order_dev = nullptr;               // one device word for the probe's count
+  int phi_last_series = 0;                // 1: the last tile-sort launch was the time-series instantiation
 };
 
 // Debug / measurement switches from the environment, read ONCE (a getenv per launch costs microseconds where the environment is large)

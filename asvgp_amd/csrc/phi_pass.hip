@@ -599,9 +599,88 @@ static int launch_phi_moments(Handle* h, const double* x, const double* y, long 
   return rc;
 }
 
+// Input-order probe: rows of 128 consecutive points, one per lane pair as the kernels read them; a row conforms when its points lie in
+// at most two mesh cells (the arithmetic cell guess, spread <= 2 as in the kernel's own first vote).  count += conforming rows.
+__global__ __launch_bounds__(64) void phi_order_probe_kernel(const double* __restrict__ x, long N, long row_stride, int nrows_probe, double m0, double inv_delta,
+                                                             int n_mesh, int* __restrict__ count) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (r >= nrows_probe) return;
+  const long base = ((long)r * row_stride) & ~1L;
+  if (base + 128 > N) return;
+  const double xa = x[base + 2 * lane], xb = x[base + 2 * lane + 1];
+  const int ca = mq_guess(xa, m0, inv_delta, n_mesh), cb = mq_guess(xb, m0, inv_delta, n_mesh);
+  const int c0 = __builtin_amdgcn_readfirstlane(ca);
+  bool good = true;
+  if (!__all(ca == c0 && cb == c0)) {
+    const unsigned long long d0 = __ballot(ca != c0), d1 = __ballot(cb != c0);
+    const int c1 = d0 ? __builtin_amdgcn_readlane(ca, (int)__builtin_ctzll(d0)) : __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(d1 | (1ull << 63)));
+    good = __all((ca - c0 <= 2 && c0 - ca <= 2) || (ca - c1 <= 2 && c1 - ca <= 2)) && __all((cb - c0 <= 2 && c0 - cb <= 2) || (cb - c1 <= 2 && c1 - cb <= 2));
+  }
+  if (lane == 0 && good) atomicAdd(count, 1);
+}
+
+// Is x a time series (sorted / locally sorted)?  Decided once per (pointer, N) from 512 sampled rows; a stale verdict - the caller has
+// overwritten the buffer with data of another order - costs speed, never correctness.
+static bool handle_phi_is_series(Handle* h, const double* x, long N, double m0, double inv_delta, long n_mesh, hipStream_t st) {
+  if (h->phi_order == 1) return false;
+  if (h->phi_order == 2) return true;
+  for (int i = 0; i < h->n_order_seen; ++i)
+    if (h->order_seen[i].ptr == x && h->order_seen[i].n == N) return h->order_seen[i].series != 0;
+  int series = 0;
+  const int nprobe = 512;
+  if (N >= 128L * nprobe) {
+    if (!h->order_dev && hipMalloc(&h->order_dev, sizeof(int)) != hipSuccess) h->order_dev = nullptr;
+    int cnt = 0;
+    if (h->order_dev && hipMemsetAsync(h->order_dev, 0, sizeof(int), st) == hipSuccess) {
+      hipLaunchKernelGGL(phi_order_probe_kernel, dim3(nprobe), dim3(64), 0, st, x, N, N / nprobe, nprobe, m0, inv_delta, (int)n_mesh, h->order_dev);
+      if (hipMemcpyAsync(&cnt, h->order_dev, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+        series = cnt * 10 >= nprobe * 9 ? 1 : 0;                 // nine rows in ten: the front loop will carry the pass
+    }
+  }
+  if (h->n_order_seen < 8) h->order_seen[h->n_order_seen++] = Handle::OrderSeen{x, N, series};
+  return series != 0;
+}
+
 // Tile-sort Phi pass (algorithm 6, phi_sort.hpp).  Returns 1 when it does not apply - D != 1, unaligned inputs, fewer than two points,
 // more than 2048 columns, a mesh that is not an exact numpy.linspace, or knots so large against delta that the arithmetic cell guess
 // has no safe margin - and the caller falls back to the moment scatter (5), then the band scatter (3).
+// Two instantiations: TP points per thread and tile without the time-series front loop (fastest on i.i.d. points), and 4 points per
+// thread and tile with it (TS; the run sums and the second register set of its prefetch need the room) for inputs the order probe
+// - or the caller, asvgp_set_phi_input_order - calls a time series.
+template <int K, int TP, int TS>
+static int launch_phi_sort_as(Handle* h, const double* x, const double* y, long N, const double* mesh, long n_mesh, double delta,
+                              long M, double* stats, double* ws, hipStream_t st, double step, double m0, double m_last, double margin) {
+  size_t lds_bytes = ps_lds_bytes<K, TP, TS>();
+  if (ps_epilogue_bytes<K>() > lds_bytes) lds_bytes = ps_epilogue_bytes<K>();
+  if (lds_bytes > 160 * 1024) return 1;
+  long nblk = (N + TP * PS_THREADS - 1) / (TP * PS_THREADS);   // at least one tile per workgroup
+  const long gmax = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
+  const int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
+  long ppb = (N + G - 1) / G;
+  ppb = TS ? ((ppb + 127) & ~127L) : ((ppb + 1) & ~1L);       // (TS: whole rows of 64 pairs - only the grid's last workgroup has an incomplete one)
+  if (ppb > 0x3fffffffL) return 1;                              // (32-bit pair indices inside a workgroup)
+  PsArgs a;
+  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M;
+  a.m0 = m0; a.m_last = m_last; a.step = step; a.smax_fast = 0.5 - margin;
+  a.partials = ws; a.ppb = ppb; a.zero_ptr = stats; a.zero_n = (K + 2) * M + 1; a.stamps = nullptr; a.stamps_wave = 0;
+  auto kern = phi_sort_kernel<K, TP, 0, 1, TS>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
+  const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
+  if (prof) (void)hipEventRecord(h->prof_ev[h->prof_n][0], st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(PS_THREADS), lds_bytes, st, a);
+  if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
+  h->phi_last_series = TS;
+  const int E1 = (int)((K + 2) * M + 1);
+  const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
+  if (h->phi_defer) {   // the caller enqueues the reduce itself (asvgp_phi_reduce_1d), e.g. on the stream that consumes the statistics
+    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true};
+    return check_launch("phi_accumulate_1d (tile sort, reduce deferred)");
+  }
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
+  return check_launch("phi_accumulate_1d (tile sort)");
+}
+
 template <int K>
 static int launch_phi_sort(Handle* h, const double* x, const double* y, long N, long D, const double* mesh, long n_mesh, double delta,
                            long M, double* stats, double* ws, hipStream_t st) {
@@ -612,34 +691,12 @@ static int launch_phi_sort(Handle* h, const double* x, const double* y, long N, 
   const double margin = 16.0 * 2.220446049250313e-16 * amax / delta + 1e-12;   // knot rounding (two roundings <= ulp(|knot|)) over delta
   if (!(margin < 0.125)) return 1;
   constexpr int TP = ps_tile_points<K>();
-  size_t lds_bytes = ps_lds_bytes<K, TP>();
-  if (ps_epilogue_bytes<K>() > lds_bytes) lds_bytes = ps_epilogue_bytes<K>();
-  if (lds_bytes > 160 * 1024) return 1;
-  long nblk = (N + TP * PS_THREADS - 1) / (TP * PS_THREADS);   // at least one tile per workgroup
-  const long gmax = (h->phi_blocks > 0 && h->phi_blocks < PHI_MAX_BLOCKS) ? h->phi_blocks : PHI_MAX_BLOCKS;
-  const int G = (int)(nblk < 1 ? 1 : (nblk > gmax ? gmax : nblk));
-  long ppb = (N + G - 1) / G;
-  ppb = (ppb + 1) & ~1L;
-  if (ppb > 0x3fffffffL) return 1;                              // (32-bit pair indices inside a workgroup)
-  PsArgs a;
-  a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M;
-  a.m0 = m0; a.m_last = m_last; a.step = step; a.smax_fast = 0.5 - margin;
-  a.partials = ws; a.ppb = ppb; a.zero_ptr = stats; a.zero_n = (K + 2) * M + 1; a.stamps = nullptr; a.stamps_wave = 0;
-  auto kern = phi_sort_kernel<K, TP, 0, 1>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
-  const bool prof = h->prof_on && h->prof_n < PROF_RING && (h->prof_calls++ % h->prof_every == 0);
-  if (prof) (void)hipEventRecord(h->prof_ev[h->prof_n][0], st);
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(PS_THREADS), lds_bytes, st, a);
-  if (prof) { (void)hipEventRecord(h->prof_ev[h->prof_n][1], st); ++h->prof_n; }
-  const int E1 = (int)((K + 2) * M + 1);
-  const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
-  if (h->phi_defer) {   // the caller enqueues the reduce itself (asvgp_phi_reduce_1d), e.g. on the stream that consumes the statistics
-    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true};
-    return check_launch("phi_accumulate_1d (tile sort, reduce deferred)");
+  constexpr int TPS = TP < 4 ? TP : 4;
+  if (handle_phi_is_series(h, x, N, m0, 1.0 / delta, n_mesh, st)) {
+    const int rc = launch_phi_sort_as<K, TPS, 1>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, step, m0, m_last, margin);
+    if (rc != 1) return rc;
   }
-  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
-  return check_launch("phi_accumulate_1d (tile sort)");
+  return launch_phi_sort_as<K, TP, 0>(h, x, y, N, mesh, n_mesh, delta, M, stats, ws, st, step, m0, m_last, margin);
 }
 
 // Band-scatter Phi pass (algorithms 1 and 3): the (k+1)(k+2)/2 + (k+1) products of every point go straight into the

@@ -56,9 +56,14 @@ struct PsArgs {
 // points per thread and tile: as many as leave the 2 (3k+1) owner accumulators, the tile in flight and the current tile's (s, y, rank)
 // inside 128 VGPRs without a spill (a scratch reload counts in vmcnt and stalls on the prefetched tile)
 template <int K> constexpr int ps_tile_points() { return K <= 3 ? 8 : (K == 4 ? 6 : (K == 5 ? 4 : 2)); }
-template <int K, int TP> constexpr size_t ps_lds_bytes() {
+#ifndef PS_GW
+#define PS_GW 4
+#endif
+constexpr int PS_TS_SLOTS = 256;           // cells the time-series table of a workgroup holds (open addressing)
+template <int K> constexpr size_t ps_ts_bytes() { return (size_t)PS_TS_SLOTS * (3 * K + 2) * 8 + (size_t)2 * PS_TS_SLOTS * 4; }
+template <int K, int TP, int TS = 0> constexpr size_t ps_lds_bytes() {
   return (size_t)(TP * PS_THREADS + 1) * 16 + (size_t)3 * PS_NCELL * 4 + 64 * 4 + 64 * 8 +
-         (size_t)PS_HROUND * (3 * K + 1) * 8 + (size_t)PS_HLIST * 12;
+         (size_t)PS_HROUND * (3 * K + 1) * 8 + (size_t)PS_HLIST * 12 + (TS ? ps_ts_bytes<K>() : 0);
 }
 // LDS of the epilogue's largest round: the Q planes of one half (all (K+1)(K+2)/2 for K <= 4, else those of the sub-diagonals d >= 2 or
 // d < 2, whichever are more) or the 2 (K+1) rhs planes
@@ -103,6 +108,9 @@ __device__ __forceinline__ unsigned ps_wave_max_u32(unsigned v) {
   v = ps_dpp_max_u32<0x143, 0xc>(v);
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+
+// wave64 minimum of values < 2^31, wave-uniform
+__device__ __forceinline__ unsigned ps_wave_min_u32(unsigned v) { return 0x7fffffffu - ps_wave_max_u32(0x7fffffffu - v); }
 
 // one point into a cell's moments: powers s^1..s^K once (shortest chains), S_p = sum s^p (p = 1..2K), T_p = sum y s^p (p = 0..K)
 template <int K>
@@ -209,7 +217,8 @@ __device__ __forceinline__ void ps_heavy_slices(const double2* buf, unsigned hn,
 
 // ABL: 0 product; 1 loads + cell search only; 2 + rank atomics; 3 + scan; 4 + scatter; 5 + owners (no epilogue conversion);
 //      9 product + per-phase cycle stamps of thread 0
-template <int K, int TP, int ABL = 0, int PF = 0>
+//      TS: 1 = the time-series front loop is compiled in (see below)
+template <int K, int TP, int ABL = 0, int PF = 0, int TS = 0>
 __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   extern __shared__ double lds[];
   static_assert(TP % 2 == 0 && TP * PS_THREADS <= 8192, "tile: rank field is 13 bits");
@@ -224,6 +233,12 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   double* hacc = scratch + 64;                                    // [PS_HROUND][NSTAT] hand-over table of the heavy cells
   unsigned* hlist = reinterpret_cast<unsigned*>(hacc + PS_HROUND * NSTAT);   // [PS_HLIST] x (cell, count, offset)
   unsigned* nheavy_p = wtot + 32;                                 // heavy cells of the current tile
+  // time-series table: the runs the front loop hands over, keyed by cell (open addressing), read by the owners before the epilogue
+  constexpr int TSW = NSTAT + 1;                                  // 3k+1 sums + the count
+  double* tstab = reinterpret_cast<double*>(hlist + 3 * PS_HLIST);   // [PS_TS_SLOTS][TSW]
+  int* tskey = reinterpret_cast<int*>(tstab + PS_TS_SLOTS * TSW);    // [PS_TS_SLOTS] cell of each slot, -1 = free
+  int* tslist = tskey + PS_TS_SLOTS;                              // [PS_TS_SLOTS] occupied slots in order of allocation
+  unsigned* ts_ctl = wtot + 40;                                   // [0] slots in use, [1] "leave the front loop"
   if (a.zero_ptr) for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.zero_n; e += (long)gridDim.x * blockDim.x) a.zero_ptr[e] = 0.0;
   const int tid0 = threadIdx.x;
   int tid = tid0, lane = tid0 & 63, wv = tid0 >> 6;
@@ -234,7 +249,11 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   {
     uint4* z = reinterpret_cast<uint4*>(cnt);
     z[tid] = make_uint4(0u, 0u, 0u, 0u);                          // 2 x 2048 counters = 1024 x 16 B
-    if (tid == 0) buf[T] = make_double2(0.0, 0.0);
+    if (tid == 0) { buf[T] = make_double2(0.0, 0.0); ts_ctl[0] = 0; ts_ctl[1] = 0; }
+    if constexpr (TS == 1) {
+      if (tid < PS_TS_SLOTS) tskey[tid] = -1;
+      for (int e = tid; e < PS_TS_SLOTS * TSW; e += PS_THREADS) tstab[e] = 0.0;
+    }
   }
   unsigned nbad = 0;
   {   // the host chose this kernel from its copy of the mesh; a table that is NOT that linspace here is reported loudly
@@ -268,7 +287,29 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   const int npair = (int)((end >> 1) - ubeg);                     // full pairs of this workgroup (beg is even)
   const bool tail = (end & 1) != 0;                               // one odd last point (only the workgroup that reaches N)
   const int nunit = npair + (tail ? 1 : 0);
-  const int n_tiles = (nunit + T / 2 - 1) / (T / 2);
+  // Point -> thread mapping.  TS = 0: row q2 of tile t is the 1024 pairs t T/2 + q2 1024 + tid.  TS = 1: the workgroup's pairs form rows of
+  // 64; the 16 waves form 16 / PS_GW groups, every group streams its own CONTIGUOUS share of the rows, its PS_GW waves taking
+  // consecutive rows in turn (wave w' of the group: the group's rows w', w' + PS_GW, ...), TP / 2 rows per wave and tile.  PS_GW = 16 is
+  // the TS = 0 order up to a permutation inside the tile; the smaller PS_GW, the longer a sorted / time-series input keeps a wave
+  // inside one cell (a wave's consecutive rows are PS_GW rows apart) and the shorter the contiguous piece a load instruction of the
+  // workgroup reads (PS_GW KiB).
+  constexpr int GW = PS_GW, NG = (PS_THREADS / 64) / GW;
+  const int nrows = (nunit + 63) >> 6;
+  const int rpg = (nrows + NG - 1) / NG;                          // rows per group
+  const int rpw = (rpg + GW - 1) / GW;                            // rows per wave
+  const int n_tiles = TS == 1 ? (rpw + TP / 2 - 1) / (TP / 2) : (nunit + T / 2 - 1) / (T / 2);
+  auto unit_of = [&](int tile, int q2, bool& inside) __attribute__((always_inline)) -> int {
+    if constexpr (TS == 1) {
+      const int w = tid >> 6, g = w / GW, wi = w - g * GW;
+      const int gr = (tile * (TP / 2) + q2) * GW + wi;             // row inside the group
+      const int row = g * rpg + gr;
+      inside = gr < rpg && row < nrows;
+      return (row << 6) + (tid & 63);
+    } else {
+      inside = true;
+      return tile * (T / 2) + q2 * PS_THREADS + tid;
+    }
+  };
   typedef double ps_nt2 __attribute__((ext_vector_type(2)));
   // (a workgroup without a full pair - only possible at the very end of the data - aims its unconditional loads at pair 0 of the
   // arrays: the host sends N < 2 to another algorithm)
@@ -279,16 +320,18 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   double xs[TP], ys[TP];
   // unconditional, clamped loads and NO branch around them: a branch makes the loaded values phi nodes, which hipcc copies right
   // behind the loads (s_waitcnt vmcnt(1)) - the prefetch then overlaps nothing
-  auto load_tile = [&](int tile) __attribute__((always_inline)) {
+  auto load_into = [&](int tile, double (&X)[TP], double (&Y)[TP]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q2 = 0; q2 < TP / 2; ++q2) {
-      int u = tile * (T / 2) + q2 * PS_THREADS + tid;
+      bool inside;
+      int u = unit_of(tile, q2, inside);
       u = u < ulast ? u : ulast;
       const ps_nt2 xv = __builtin_nontemporal_load(x2 + u);     // read exactly once: keep the stream out of the L2's LRU order
       const ps_nt2 yv = __builtin_nontemporal_load(y2 + u);
-      xs[2 * q2] = xv.x; xs[2 * q2 + 1] = xv.y; ys[2 * q2] = yv.x; ys[2 * q2 + 1] = yv.y;
+      X[2 * q2] = xv.x; X[2 * q2 + 1] = xv.y; Y[2 * q2] = yv.x; Y[2 * q2 + 1] = yv.y;
     }
   };
+  auto load_tile = [&](int tile) __attribute__((always_inline)) { load_into(tile, xs, ys); };
 
   double SA[NS], TA[K + 1], SB[NS], TB[K + 1];
 #pragma unroll
@@ -307,9 +350,224 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
     }
   };
 
+  // ---- cell and centred coordinate of the tile held in (xs, ys): the first half of P1, shared by the front loop and the sort loop.
+  // One pair at a time (sched_barrier): the scheduler otherwise interleaves all TP points and needs ~120 registers for this block
+  // alone, next to the 2 (3k+1) owner accumulators.  cr = the cell; bit q of valm: point q exists and lies inside the mesh.
+  double sv[TP], yv[TP];
+  int cr[TP];
+  unsigned valm = 0;
+  int t_done = 0;                                                 // tiles whose rows THIS wave has summed in the front loop (the sort loop skips them)
+  // (tile_bad: where the tile's number of points outside the mesh is added)
+  auto search_from = [&](int tile, const double (&X)[TP], const double (&Y)[TP], unsigned& tile_bad) __attribute__((always_inline)) {
+    valm = 0;
+#pragma unroll
+    for (int q2 = 0; q2 < TP / 2; ++q2) {
+      bool inside;
+      const int u = unit_of(tile, q2, inside);
+      double xv[2] = {X[2 * q2], X[2 * q2 + 1]};
+      bool val[2] = {inside && u < npair, inside && u < npair};
+      yv[2 * q2] = Y[2 * q2]; yv[2 * q2 + 1] = Y[2 * q2 + 1];
+      if (tail && inside && u == npair) {                                   // the odd last point: a scalar reload by ONE lane of the kernel
+        xv[0] = a.x[end - 1]; yv[2 * q2] = a.y[end - 1]; val[0] = true;
+      }
+      bool slow = false;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double g = floor((xv[e] - m0) * inv_delta);
+        const int c = __double2int_rz(g);                         // (v_cvt_i32_f64: saturating; NaN -> 0)
+        double u0;
+        {
+#pragma clang fp contract(off)
+          const double t = g * step;                              // numpy.linspace's knot: i * step rounded, THEN + start rounded
+          u0 = t + m0;
+        }
+        const double s = (xv[e] - u0) * inv_delta - 0.5;
+        const bool fast = (unsigned)c < (unsigned)ncells && fabs(s) <= smax_fast;
+        slow = slow || (val[e] && !fast);
+        cr[2 * q2 + e] = c;
+        sv[2 * q2 + e] = s;
+      }
+      if (__any(slow)) {                                          // rare: the exact table rule, per lane
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          bool ok;
+          double sq;
+          const int c = cell_slow(xv[e], sq, ok);
+          cr[2 * q2 + e] = c;
+          sv[2 * q2 + e] = sq;
+          if (val[e] && !ok) { ++tile_bad; val[e] = false; }        // outside the mesh (or NaN): reported, never accumulated
+        }
+      }
+      valm |= (val[0] ? 1u : 0u) << (2 * q2) | (val[1] ? 2u : 0u) << (2 * q2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   load_tile(0);
   __syncthreads();
-  for (int tile = 0; tile < n_tiles; ++tile) {
+  int tile = 0;
+  // ---- TIME-SERIES FRONT LOOP (sorted / time-series input; SURVEY 8d's secondary case, the order of the reference's own large 1-D data,
+  // experiments/large_regression/electricity.py:31-32).  While every pair row of every wave of the tile lies in at most TWO cells, the
+  // tile needs no sort: the lanes add their points into a wave-private set of 3k+1 run sums (lane-parallel, every lane busy: 4k
+  // operations per point at full utilisation against one lane in ~3 in the owner loops), and when a wave's cell changes the run is
+  // summed over the wave and added to the cell's slot of a small LDS table (open addressing, PS_TS_SLOTS cells per workgroup) that
+  // the owners read once, before the epilogue.  The owner accumulators are not live in this loop - which is what makes room for the
+  // run sums: in ONE loop with the sort phases hipcc kept per-tile state in scratch - and the loop is left for good, at a tile
+  // boundary and by the whole workgroup, the first time a tile does not conform (unsorted input: at tile 0, for the price of the votes).
+  if constexpr (TS == 1 && (ABL == 0 || ABL == 9)) {
+    // does row 0 of every wave conform?  Asked as soon as the row's own loads have landed, before anything is prefetched: an unsorted
+    // input leaves here for the price of a few votes and one barrier, with nothing fetched twice.
+    {
+      bool inside;
+      const int u = unit_of(0, 0, inside);
+      const bool v = inside && u < npair;
+      const int ca = mq_guess(xs[0], m0, inv_delta, n_mesh), cb = mq_guess(xs[1], m0, inv_delta, n_mesh);   // (the guess: within a cell of the rule)
+      const int c0 = __builtin_amdgcn_readfirstlane(ca);
+      bool good = !__any(v) || __all(v);
+      if (good && __any(v) && !__all(ca == c0 && cb == c0)) {
+        const unsigned long long d0 = __ballot(ca != c0), d1 = __ballot(cb != c0);
+        const int c1 = d0 ? __builtin_amdgcn_readlane(ca, (int)__builtin_ctzll(d0)) : __builtin_amdgcn_readlane(cb, (int)__builtin_ctzll(d1 | (1ull << 63)));
+        // (a sorted row that crosses a knot may show a third, adjacent cell in the arithmetic guess: allow a spread of two)
+        good = __all((ca - c0 <= 2 && c0 - ca <= 2) || (ca - c1 <= 2 && c1 - ca <= 2)) && __all((cb - c0 <= 2 && c0 - cb <= 2) || (cb - c1 <= 2 && c1 - cb <= 2));
+      }
+      if (lane == 0 && !good) ts_ctl[1] = 1u;
+      ps_lds_barrier();
+    }
+    if (ts_ctl[1] == 0u) {
+      double RS[NS], RT[K + 1];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) RS[p] = 0.0;
+#pragma unroll
+      for (int p = 0; p <= K; ++p) RT[p] = 0.0;
+      int run_c = -1;
+      unsigned run_n = 0;
+      // hand the open run to its cell's slot (lane 0 finds or claims the slot; the sums are wave totals, reduce-scatter butterflies:
+      // with the chunked mapping a wave changes cell about once per tile).  A slot is always free: the verdict of every tile keeps
+      // 16 TP + 16 entries in reserve, the most one tile and the closing hand-overs can claim.
+      auto ts_flush = [&]() __attribute__((always_inline)) {
+        int h = 0;
+        if (lane == 0) {
+          h = (int)(((unsigned)run_c * 40503u) & (unsigned)(PS_TS_SLOTS - 1));
+          for (int probe = 0; probe < PS_TS_SLOTS; ++probe) {
+            int expect = -1;
+            const bool won = __hip_atomic_compare_exchange_strong(tskey + h, &expect, run_c, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (won) { const unsigned pos = __hip_atomic_fetch_add(ts_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tslist[pos] = h; }
+            if (won || expect == run_c) break;
+            h = (h + 1) & (PS_TS_SLOTS - 1);
+          }
+        }
+        h = __builtin_amdgcn_readfirstlane(h);
+        double* sl = tstab + (size_t)h * TSW;
+        if constexpr (NS <= 8 && TP <= 4) {                       // (the butterflies' 28 temporaries fit beside two tiles of 4 points)
+          int idx;
+          const double t = ps_reduce_scatter8<NS>(RS, lane, idx);
+          if (lane < 8 && idx < NS) lds_add(sl + idx, t);
+          __builtin_amdgcn_sched_barrier(0);
+          const double t2 = ps_reduce_scatter8<K + 1>(RT, lane, idx);
+          if (lane < 8 && idx <= K) lds_add(sl + NS + idx, t2);
+        } else {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) { const double t = wave_sum_dpp(RS[q]); if (lane == 0) lds_add(sl + q, t); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+          for (int q = 0; q <= K; ++q) { const double t = wave_sum_dpp(RT[q]); if (lane == 0) lds_add(sl + NS + q, t); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (lane == 0) lds_add(sl + NSTAT, (double)run_n);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) RS[p] = 0.0;
+#pragma unroll
+        for (int p = 0; p <= K; ++p) RT[p] = 0.0;
+        run_c = -1;
+        run_n = 0;
+      };
+      // one tile per iteration, its points in (xs, ys); the NEXT tile's loads go into a second register set (xb, yb) before anything
+      // else - a whole tile ahead of their use -, so (xs, ys) are intact should the wave have to stop at this tile.  No barrier: a wave
+      // that cannot take its rows (or finds the table short of its reserve) raises the flag and stops; the others see the flag at their
+      // next tile and stop where THEY are; the sort loop then starts at the earliest of those tiles and every wave skips the rows it
+      // has already summed.
+      double xb[TP], yb[TP];
+      while (t_done < n_tiles) {
+        stamp(-1);
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        load_into(t_done + 1, xb, yb);                            // (clamped: past the end it re-reads the last pair)
+        unsigned tile_bad = 0;
+        search_from(t_done, xs, ys, tile_bad);
+        stamp(0);                                                 // (front loop stamps: 0 loads landed + search, 1 votes, 5 sums)
+        // verdict of this wave: every row either empty (beyond the data) or complete and inside at most two cells
+        int clo[TP / 2], chi[TP / 2];
+        bool good = true;
+#pragma unroll
+        for (int q2 = 0; q2 < TP / 2; ++q2) {
+          const bool va = (valm >> (2 * q2)) & 1u, vb = (valm >> (2 * q2 + 1)) & 1u;
+          const int c0 = __builtin_amdgcn_readfirstlane(cr[2 * q2]);
+          clo[q2] = c0; chi[q2] = c0;
+          if (!__any(va || vb)) { clo[q2] = -1; chi[q2] = -1; continue; }
+          if (__all(va && vb && cr[2 * q2] == c0 && cr[2 * q2 + 1] == c0)) continue;
+          if (!good) continue;                                     // (wave-uniform) the verdict is in
+          // not one cell: the cell of lane 0 and the first cell that differs from it - are those all?
+          const unsigned long long d0 = __ballot(cr[2 * q2] != c0), d1 = __ballot(cr[2 * q2 + 1] != c0);
+          const int c1 = d0 ? __builtin_amdgcn_readlane(cr[2 * q2], (int)__builtin_ctzll(d0))
+                            : __builtin_amdgcn_readlane(cr[2 * q2 + 1], (int)__builtin_ctzll(d1 | (1ull << 63)));
+          clo[q2] = c0 < c1 ? c0 : c1; chi[q2] = c0 < c1 ? c1 : c0;
+          good = __all(va && vb && (cr[2 * q2] == c0 || cr[2 * q2] == c1) && (cr[2 * q2 + 1] == c0 || cr[2 * q2 + 1] == c1));
+        }
+        if (__any(tile_bad != 0u)) good = false;                  // (a point outside the mesh: the sort loop reports it)
+        const unsigned stop = __builtin_amdgcn_readfirstlane((int)(ts_ctl[1] | (ts_ctl[0] > (unsigned)(PS_TS_SLOTS - 16 * TP - 16) ? 1u : 0u)));
+        if (!good || stop != 0u) { if (lane == 0) ts_ctl[1] = 1u; break; }
+        stamp(1);
+        // the sums: one rolled loop over the rows (one copy of the code), a second segment only for a row that crosses a knot
+        for (int q2 = 0; q2 < TP / 2; ++q2) {
+          int lo = clo[0], hi = chi[0];
+          double s0 = sv[0], s1 = sv[1], y0 = ys[0], y1 = ys[1];
+          int c0r = cr[0], c1r = cr[1];
+#pragma unroll
+          for (int r = 1; r < TP / 2; ++r)
+            if (q2 == r) { lo = clo[r]; hi = chi[r]; s0 = sv[2 * r]; s1 = sv[2 * r + 1]; y0 = ys[2 * r]; y1 = ys[2 * r + 1]; c0r = cr[2 * r]; c1r = cr[2 * r + 1]; }
+          if (lo < 0) continue;                                    // an empty row
+          yy = fma(y0, y0, yy);                                   // (a row that is not empty is complete)
+          yy = fma(y1, y1, yy);
+          if (run_c != lo) { if (run_c >= 0) ts_flush(); run_c = lo; }
+          if (lo == hi) {
+            run_n += 128u;
+            ps_acc<K>(s0, y0, RS, RT);
+            __builtin_amdgcn_sched_barrier(0);
+            ps_acc<K>(s1, y1, RS, RT);
+          } else {   // the row crosses a knot: the other cell's points count as the point (0, 0), which adds nothing
+            const bool a0 = c0r == lo, a1 = c1r == lo;
+            run_n += (unsigned)__popcll(__ballot(a0)) + (unsigned)__popcll(__ballot(a1));
+            ps_acc<K>(a0 ? s0 : 0.0, a0 ? y0 : 0.0, RS, RT);
+            __builtin_amdgcn_sched_barrier(0);
+            ps_acc<K>(a1 ? s1 : 0.0, a1 ? y1 : 0.0, RS, RT);
+            __builtin_amdgcn_sched_barrier(0);
+            ts_flush();
+            run_c = hi;
+            run_n = (unsigned)__popcll(__ballot(!a0)) + (unsigned)__popcll(__ballot(!a1));
+            ps_acc<K>(a0 ? 0.0 : s0, a0 ? 0.0 : y0, RS, RT);
+            __builtin_amdgcn_sched_barrier(0);
+            ps_acc<K>(a1 ? 0.0 : s1, a1 ? 0.0 : y1, RS, RT);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(5);
+        ++t_done;
+#pragma unroll
+        for (int q = 0; q < TP; ++q) { xs[q] = xb[q]; ys[q] = yb[q]; }   // (waits for the prefetched tile: it had the whole iteration to land)
+      }
+      if (run_c >= 0) ts_flush();                                 // (the table is read behind the barriers that end the sort loop)
+      // where does the sort loop start?  At the earliest tile a wave stopped at.
+      if (lane == 0) wtot[48 + wv] = (unsigned)t_done;
+      __syncthreads();
+      {
+        unsigned m = wtot[48 + (lane & 15)];
+        m = 0x7fffffffu - ps_wave_max_u32(0x7fffffffu - m);
+        tile = (int)m;
+      }
+      if (tile < n_tiles) load_tile(tile);                        // (only an input that stops being a time series gets here: one exposed round trip)
+    }
+  }
+  for (; tile < n_tiles; ++tile) {
     unsigned* cntb = cnt + (tile & 1) * PS_NCELL;
     stamp(-1);
     // the thread index is re-read per tile behind an opaque barrier: LDS addresses derived from it are then recomputed where they are
@@ -319,52 +577,10 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
     asm volatile("" : "+v"(tid));
     lane = tid & 63;
     wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- P1: cell, centred coordinate, rank inside the cell.  One pair at a time (sched_barrier): the scheduler otherwise interleaves
-    // all TP points and needs ~120 registers for this block alone, next to the 2 (3k+1) owner accumulators.
-    double sv[TP], yv[TP];
-    int cr[TP];                                                   // cell << 13 | rank; -1 = no point
+    // ---- P1: cell, centred coordinate, rank inside the cell
+    search_from(tile, xs, ys, nbad);
+    if constexpr (TS == 1) { if (tile < t_done) valm = 0; }       // (wave-uniform) rows this wave has summed in the front loop
     {
-      unsigned valm = 0;                                          // bit q: point q exists and lies inside the mesh
-#pragma unroll
-      for (int q2 = 0; q2 < TP / 2; ++q2) {
-        const int u = tile * (T / 2) + q2 * PS_THREADS + tid;
-        double xv[2] = {xs[2 * q2], xs[2 * q2 + 1]};
-        bool val[2] = {u < npair, u < npair};
-        yv[2 * q2] = ys[2 * q2]; yv[2 * q2 + 1] = ys[2 * q2 + 1];
-        if (tail && u == npair) {                                 // the odd last point: a scalar reload by ONE lane of the kernel
-          xv[0] = a.x[end - 1]; yv[2 * q2] = a.y[end - 1]; val[0] = true;
-        }
-        bool slow = false;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const double g = floor((xv[e] - m0) * inv_delta);
-          const int c = __double2int_rz(g);                       // (v_cvt_i32_f64: saturating; NaN -> 0)
-          double u0;
-          {
-#pragma clang fp contract(off)
-            const double t = g * step;                            // numpy.linspace's knot: i * step rounded, THEN + start rounded
-            u0 = t + m0;
-          }
-          const double s = (xv[e] - u0) * inv_delta - 0.5;
-          const bool fast = (unsigned)c < (unsigned)ncells && fabs(s) <= smax_fast;
-          slow = slow || (val[e] && !fast);
-          cr[2 * q2 + e] = c;
-          sv[2 * q2 + e] = s;
-        }
-        if (__any(slow)) {                                        // rare: the exact table rule, per lane
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            bool ok;
-            double sq;
-            const int c = cell_slow(xv[e], sq, ok);
-            cr[2 * q2 + e] = c;
-            sv[2 * q2 + e] = sq;
-            if (val[e] && !ok) { ++nbad; val[e] = false; }          // outside the mesh (or NaN): reported, never accumulated
-          }
-        }
-        valm |= (val[0] ? 1u : 0u) << (2 * q2) | (val[1] ? 2u : 0u) << (2 * q2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       if constexpr (ABL == 9) { __builtin_amdgcn_sched_barrier(0); ph[5] += __builtin_amdgcn_s_memtime() - tprev; __builtin_amdgcn_sched_barrier(0); }   // loads landed, cells known
       if constexpr (ABL == 1) {
 #pragma unroll
@@ -376,7 +592,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
           const bool va = (valm >> (2 * q2)) & 1u, vb = (valm >> (2 * q2 + 1)) & 1u;
           const int c0 = __builtin_amdgcn_readfirstlane(cr[2 * q2]);
           if (__all(va && vb && cr[2 * q2] == c0 && cr[2 * q2 + 1] == c0)) {
-            // sorted / time-series input: all 128 points of the wave's pair row in ONE cell - one atomic instead of 128 same-address ones
+            // all 128 points of the wave's pair row in ONE cell - one atomic instead of 128 same-address ones
             unsigned base = 0;
             if (lane == 0) base = __hip_atomic_fetch_add(cntb + c0, 128u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
@@ -516,6 +732,29 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   }
   stamp(-1);
 
+  // ---- the runs of the front loop go to their cells' owners
+  if constexpr (TS == 1 && (ABL == 0 || ABL == 9)) {
+    __syncthreads();
+    const unsigned nts = ts_ctl[0];
+    for (unsigned e = 0; e < nts; ++e) {
+      const int h = tslist[e];
+      const int c = tskey[h];
+      const double* sl = tstab + (size_t)h * TSW;
+      if (c == tid) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p) SA[p] += sl[p];
+#pragma unroll
+        for (int p = 0; p <= K; ++p) TA[p] += sl[NS + p];
+        n0A += (unsigned)sl[NSTAT];
+      } else if (c == tid + PS_THREADS) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p) SB[p] += sl[p];
+#pragma unroll
+        for (int p = 0; p <= K; ++p) TB[p] += sl[NS + p];
+        n0B += (unsigned)sl[NSTAT];
+      }
+    }
+  }
   // ---- epilogue: moments -> band / rhs entries of this workgroup (the LDS image aliases the sort buffers)
   double tot = block_sum(yy, scratch);                            // (its barriers also end the last owner phase)
   const double badf = block_sum((double)nbad, scratch + 32);

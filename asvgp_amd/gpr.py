@@ -105,6 +105,8 @@ class _GPModelSurface:
         h = getattr(self, "_h", None)
         if h is not None:
             h.close()
+        self._mirror = None                    # (the pinned mirror is gone with the handle: nothing may read through a stale view)
+        self.__dict__.pop("_host_call", None)
 
     def __enter__(self):
         return self
@@ -153,6 +155,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         self._out = torch.zeros(8, dtype=torch.float64, device=dev)
         self._info = torch.zeros(2, dtype=torch.int32, device=dev)
         self._post = None
+        self._host_result = np.zeros(10)      # [out[0..7], info[0], info[1]] of the last host-read evaluation
+        self._mirror_read = lib.asvgp_result_mirror_read
 
     # ------------------------------------------------------------------------------------------------------
     def _phi_pass_local(self):
@@ -224,24 +228,31 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
                                                  self._elbo_ws.numel() * 8, stream_ptr()), "elbo_data_chain_1d")
         return self._out
 
-    def _check_pd(self, relaunch=None, _retry=True):
+    def _check_pd(self, relaunch=None, _retry=2):
         self._h.publish_forward()
         info = self._info.tolist()
         if info[0] < 0 or info[1] < 0:
-            # The fused launch gave up waiting for its helper workgroups (they never became resident next to other work on the device).
-            # Its results are discarded; the arrival slots of the workspace are half-armed, so the workspace is zero-filled again, and the
-            # SAME step is re-issued through the multi-launch sweeps (band algorithm 1: no cross-workgroup waits), once.
+            # The fused launch gave up waiting (a workgroup of it never became resident next to other work on the device, or its table
+            # never arrived).  Its results are discarded; the arrival slots of the workspace are half-armed, so the workspace is zero-filled
+            # again and the SAME step is re-issued: first as it was, once the device is idle (the cause is transient co-residency, and the
+            # fused launch is the accurate path - band algorithm 1 is 1e-8 of the bound away at the headline's conditioning); if that gives
+            # up as well, through the multi-launch sweeps (band algorithm 1: no cross-workgroup waits).
             self.fused_launch_fallbacks = getattr(self, "fused_launch_fallbacks", 0) + 1
+            torch.cuda.current_stream().synchronize()
             self._elbo_ws.zero_()
             self._info.zero_()
             if not _retry or relaunch is None:
                 raise AsvgpError("the fused launch gave up waiting for its helper workgroups (they never became resident): results discarded")
+            if _retry >= 2:
+                relaunch()
+                return self._check_pd(relaunch, _retry=1)
+            previous = self._h.band_algorithm
             self._h.set_band_algorithm(1)
             try:
                 relaunch()
             finally:
-                self._h.set_band_algorithm(Handle._defaults["band"])
-            return self._check_pd(_retry=False)
+                self._h.set_band_algorithm(previous)   # (the handle's own setting, not the process default: ADVICE r3)
+            return self._check_pd(_retry=0)
         if info[0]:
             raise NotPositiveDefiniteError("Kuu band not positive definite at column %d" % (info[0] - 1))
         if info[1]:
@@ -278,34 +289,42 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         return self._h.result_mirror_pending()
 
     def read_elbo_host(self, token, check_pd=True, poll_seconds=0.05):
-        """Second half: [e, dv, dl, ds] as Python floats.  token != 0: the launch writes the pinned mirror, sequence number last - poll that
-        word of host memory (no device-to-host copy, no stream synchronisation); otherwise, or when nothing arrives within poll_seconds
-        (a launch that gave up waiting never writes the mirror), read through the stream (and through _check_pd's re-issue)."""
-        m = self._mirror
-        self._h.publish_forward()              # (deferred-forward-pass mode: the launch must not be left waiting for its table; else a no-op)
-        if token:
-            want = float(token)
-            t_end = time.perf_counter() + poll_seconds
-            spins = 0
-            while m[10] != want:
-                spins += 1
-                if (spins & 255) == 0 and time.perf_counter() > t_end:
-                    break
-            while m[10] == want:
-                r = m[:12].tolist()
-                if sum(r[:10]) == r[11] or r[11] != r[11]:       # (the sum the kernel wrote with the values; NaN results pass through)
-                    if (r[8] == 0.0 and r[9] == 0.0) or not check_pd:
-                        return r[:4]
-                    break
-                if time.perf_counter() > t_end:
-                    break
+        """Second half: [e, dv, dl, ds] as Python floats.  token != 0: the launch writes the pinned mirror - asvgp_result_mirror_read polls
+        it from C (no device-to-host copy, no stream synchronisation) and accepts the values only with the launch-bound checksum;
+        otherwise, or when nothing arrives within poll_seconds (a launch that gave up waiting never writes the mirror), read through the
+        stream (and through _check_pd's re-issue)."""
+        r = self._host_result
+        if token and self._mirror_read(self._h.ptr, token, r.ctypes.data, poll_seconds) == 0:
+            if (r[8] == 0.0 and r[9] == 0.0) or not check_pd:
+                return r[:4].tolist()
+        else:
+            self._h.publish_forward()          # (deferred-forward-pass mode: the launch must not be left waiting for its table; else a no-op)
         if check_pd:
             self._check_pd(self._launch_elbo)
         return self._out[:4].tolist()
 
-    def elbo_and_grad_host(self, check_pd=True):
-        """elbo_and_grad() for a host that needs the four numbers NOW (an optimiser step: example.py:31-32); a list [e, dv, dl, ds]."""
-        return self.read_elbo_host(self.launch_elbo_host(), check_pd)
+    def elbo_and_grad_host(self, check_pd=True, poll_seconds=0.05):
+        """elbo_and_grad() for a host that needs the four numbers NOW (an optimiser step: example.py:31-32); a list [e, dv, dl, ds].
+        ONE library call: asvgp_elbo_grad_host_1d launches with the result mirror armed and polls it from C."""
+        v, l, s = self.theta()
+        S = self._statics()
+        c = self.__dict__.get("_host_call")
+        if c is None or c[0] is not S or c[1] is not self._stats:
+            if getattr(self, "_mirror", None) is None:
+                self._mirror = self._h.result_mirror(True)
+            c = self._host_call = (S, self._stats, get_lib().asvgp_elbo_grad_host_1d, self._h.ptr, self._stats.data_ptr(), S.data_ptr(),
+                                   self.basis.m, self.bandwidth, self.D, self._out.data_ptr(), self._info.data_ptr(),
+                                   self._elbo_ws.data_ptr(), self._elbo_ws.numel() * 8, self._host_result.ctypes.data)
+        rc = c[2](c[3], c[4], c[5], self.kernel.kind, v, l, s, self.num_data, c[6], c[7], c[8], c[9], c[10], c[11], c[12], stream_ptr(),
+                  c[13], poll_seconds)
+        r = self._host_result
+        if rc == 0 and ((r[8] == 0.0 and r[9] == 0.0) or not check_pd):
+            return r[:4].tolist()
+        if rc not in (0, 1):
+            check(rc, "elbo_grad_host_1d")
+        if check_pd:
+            self._check_pd(self._launch_elbo)
+        return self._out[:4].tolist()
 
     # -- optimiser (example.py:28-33: gpflow.optimizers.Scipy = scipy L-BFGS-B on unconstrained variables) ---
     @property

@@ -109,8 +109,27 @@ int asvgp_prior_publish(asvgp_handle_t handle);
  * waiting (info[1] < 0, see asvgp_set_band_algorithm) never writes it: bound the poll and fall back to the stream. */
 int asvgp_result_mirror(asvgp_handle_t handle, int enable, const double** host_ptr);
 uint64_t asvgp_result_mirror_pending(asvgp_handle_t handle);
+/* The checksum (double 11) is bound to the launch: sequence number + the ten values, added left to right in fp64.
+ * asvgp_result_mirror_read: poll the mirror for `token` (asvgp_result_mirror_pending) from C and copy the ten values out once sequence
+ * word and checksum agree; returns ASVGP_OK, or 1 when the token is 0 / nothing valid arrives within timeout_seconds (read through the
+ * stream then).  asvgp_elbo_grad_host_1d = asvgp_elbo_grad_1d with the mirror armed + that read: ONE call per optimiser evaluation
+ * (example.py:31-32: the next theta depends on this result). */
+int asvgp_result_mirror_read(asvgp_handle_t handle, uint64_t token, double* result10, double timeout_seconds);
+int asvgp_elbo_grad_host_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
+                            double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
+                            double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream,
+                            double* result10, double timeout_seconds);
 /* the algorithm the handle's last asvgp_phi_accumulate_1d call actually ran (1, 3, 5 or 6; 0 before the first call) */
 int asvgp_phi_last_algorithm(asvgp_handle_t handle);
+/* Input order of the tile-sort Phi pass.  A time series (sorted / locally sorted x - the order of the reference's own large 1-D data,
+ * experiments/large_regression/electricity.py:31-32) needs no sort: the instantiation with the time-series front loop sums such
+ * an input lane-parallel into per-wave run sums and leaves that loop, at a tile boundary, for the general sort loop the first time a
+ * 128-point row spans more than two cells.  Both instantiations return the same statistics for ANY input; the order only selects
+ * the faster one.  order: 0 = probe once per (x pointer, N): 512 sampled rows, one 4-byte device-to-host copy and ONE stream
+ * synchronisation at the first pass over that buffer (default); 1 = unsorted; 2 = time series.
+ * asvgp_phi_last_input_order: what the last tile-sort launch on the handle ran as (1 or 2). */
+int asvgp_set_phi_input_order(asvgp_handle_t handle, int order);
+int asvgp_phi_last_input_order(asvgp_handle_t handle);
 /* Measurement aid: a read-only pass over x and y (16 B/point) with the Phi pass's launch shape - the stream ceiling the
  * Phi kernel's achieved bandwidth is reported beside.  sink: device buffer of >= 8 bytes (never written for finite data). */
 int asvgp_stream_probe(const double* x, const double* y, int64_t N, double* sink, asvgp_stream_t stream);

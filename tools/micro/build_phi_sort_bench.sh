@@ -14,8 +14,8 @@ for line in open('/tmp/phi_sort_build.log'):
         m = re.search(r'remark:\s+' + key + r': (\d+)', line)
         if m and name: rows[name][key] = int(m.group(1))
 for n, r in rows.items():
-    if 'phi_sort' in n or 'stream' in n:
-        m = re.search(r'phi_sort_kernelILi(\d)ELi(\d)ELi(\d)', n)
-        tag = ('sort K=%s TP=%s ABL=%s' % m.groups()) if m else n[:40]
+    if "phi_sort" in n:
+        m = re.search(r"phi_sort_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)", n)
+        tag = ("sort K=%s TP=%s ABL=%s PF=%s TS=%s" % m.groups()) if m else n[:40]
         print('%-28s VGPR %3d  spillV %3d spillS %3d scratch %4d occ %d' % (tag, r.get('VGPRs', -1), r.get('VGPRs Spill', -1), r.get('SGPRs Spill', -1), r.get('ScratchSize \\[bytes/lane\\]', -1), r.get('Occupancy \\[waves/SIMD\\]', -1)))
 PY

@@ -75,6 +75,14 @@ template <int TP, int ABL, int PF = 0> static float run_abl(PsArgs a, int G) {
   return time_us([&] { hipLaunchKernelGGL(kern, dim3(G), dim3(PS_THREADS), lds, 0, a); }, 20);
 }
 
+template <int TP, int TS> static float run_ts(PsArgs a, int G) {
+  auto kern = phi_sort_kernel<K, TP, 0, 1, TS>;
+  size_t lds = ps_lds_bytes<K, TP, TS>();
+  if (ps_epilogue_bytes<K>() > lds) lds = ps_epilogue_bytes<K>();
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return time_us([&] { hipLaunchKernelGGL(kern, dim3(G), dim3(PS_THREADS), lds, 0, a); }, 20);
+}
+
 template <int TP> static void run_all(PsArgs a, int G, long N, const char* tag) {
   const float t1 = run_abl<TP, 1>(a, G), t2 = run_abl<TP, 2>(a, G), t3 = run_abl<TP, 3>(a, G), t4 = run_abl<TP, 4>(a, G),
               t5 = run_abl<TP, 5>(a, G), t0 = run_abl<TP, 0>(a, G);
@@ -102,10 +110,10 @@ int main(int argc, char** argv) {
     if (dist == 2) { v = 0.5 + 0.08 * G01(rng); v = std::min(std::max(v, 1e-9), 1.0 - 1e-9); }
     x[i] = v;
   }
+  // a few awkward points: on knots, at the ends (planted before the sort: a time series stays one)
+  if (N > 100) { x[5] = mesh[17]; x[6] = mesh[1000]; x[7] = a0; x[8] = b0; x[9] = mesh[n_mesh - 2]; }
   if (dist == 1) std::sort(x.begin(), x.end());
   for (long i = 0; i < N; ++i) y[i] = std::sin(20.0 * x[i]) + 0.1 * G01(rng);
-  // a few awkward points: on knots, at the ends
-  if (N > 100) { x[5] = mesh[17]; x[6] = mesh[1000]; x[7] = a0; x[8] = b0; x[9] = mesh[n_mesh - 2]; }
 
   double *dx, *dy, *dmesh, *dpart, *dsink;
   unsigned long long* dstamps;
@@ -119,7 +127,7 @@ int main(int argc, char** argv) {
   CK(hipMemset(dpart, 0, G * E1 * 8));
 
   long ppb = (N + G - 1) / G;
-  ppb = (ppb + 1) & ~1L;
+  ppb = (ppb + 127) & ~127L;   // whole rows of 64 pairs: only the last workgroup of the grid has an incomplete row
   PsArgs a;
   a.x = dx; a.y = dy; a.N = N; a.mesh_g = dmesh; a.n_mesh = n_mesh; a.inv_delta = 1.0 / delta; a.M = M; a.step = step; a.m0 = mesh[0]; a.m_last = mesh[n_mesh - 1];
   a.smax_fast = 0.5 - (16.0 * DBL_EPSILON * std::max(std::fabs(a0), std::fabs(b0)) / delta + 1e-12);
@@ -141,6 +149,8 @@ int main(int argc, char** argv) {
     printf("   best = %.2f TB/s\n", 16.0 * N / std::min({s1, s2, s4, s8, p4, p8, w4}) * 1e-6);
   }
 
+  printf("product (late prefetch): TP=6 without / with the time-series front loop: %.1f / %.1f us;  TP=4: %.1f / %.1f us\n",
+         run_ts<6, 0>(a, G), run_ts<6, 1>(a, G), run_ts<4, 0>(a, G), run_ts<4, 1>(a, G));
 #ifndef PS_QUICK
   run_all<8>(a, G, N, "sort");
   run_all<6>(a, G, N, "sort");
@@ -162,6 +172,7 @@ int main(int argc, char** argv) {
     printf("%s wave %2d cycles over all tiles: P1 %.0f (landed+search %.0f, ranks back %.0f, rest = barrier) | P2 scan %.0f | P3 scatter %.0f | P4 owners %.0f (of which heavy-cell pass %.0f) | epilogue %.0f | total %.0f\n",
            tag, wave, m[0], m[5], m[6], m[1], m[2], m[3], m[7], m[4], m[0] + m[1] + m[2] + m[3] + m[4]);
   };
+  for (int w : {0, 7, 15}) stamps(phi_sort_kernel<K, 4, 9, 1, 1>, std::max(ps_lds_bytes<K, 4, 1>(), ps_epilogue_bytes<K>()), "TP=4 late TS", w);
   for (int w : {0, 5, 15}) stamps(phi_sort_kernel<K, 4, 9, 0>, std::max(ps_lds_bytes<K, 4>(), ps_epilogue_bytes<K>()), "TP=4 early", w);
 #ifndef PS_QUICK
   stamps(phi_sort_kernel<K, 4, 9, 1>, std::max(ps_lds_bytes<K, 4>(), ps_epilogue_bytes<K>()), "TP=4 late ", 0);
@@ -173,8 +184,8 @@ int main(int argc, char** argv) {
 
   // ---- correctness of the product kernel against a CPU evaluation
   if (check) {
-    auto kern = phi_sort_kernel<K, 8, 0>;
-    size_t lds = ps_lds_bytes<K, 8>();
+    auto kern = phi_sort_kernel<K, 6, 0, 1, 1>;
+    size_t lds = std::max(ps_lds_bytes<K, 6, 1>(), ps_epilogue_bytes<K>());
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(dpart, 0, G * E1 * 8));
     hipLaunchKernelGGL(kern, dim3(G), dim3(PS_THREADS), lds, 0, a);
@@ -205,7 +216,7 @@ int main(int argc, char** argv) {
     for (size_t e = 0; e < (size_t)(K + 1) * M; ++e) { mxb = std::max(mxb, std::fabs((double)ref[e])); eb = std::max(eb, std::fabs(got[e] - (double)ref[e])); }
     for (size_t e = (size_t)(K + 1) * M; e < (size_t)(K + 2) * M; ++e) { mxr = std::max(mxr, std::fabs((double)ref[e])); er = std::max(er, std::fabs(got[e] - (double)ref[e])); }
     const double yy = got[(size_t)(K + 2) * M], yyr = (double)ref[(size_t)(K + 2) * M];
-    printf("check: band max err %.3e (rel to max entry %.3e), rhs %.3e (%.3e), yy rel %.3e  -> %s\n", eb, eb / mxb, er, er / mxr,
+    printf("check (TP=6, late prefetch, front loop): band max err %.3e (rel to max entry %.3e), rhs %.3e (%.3e), yy rel %.3e  -> %s\n", eb, eb / mxb, er, er / mxr,
            std::fabs(yy - yyr) / yyr, (eb / mxb < 1e-12 && er / mxr < 1e-12 && std::fabs(yy - yyr) / yyr < 1e-12) ? "OK" : "FAIL");
     (void)ncells;
   }
