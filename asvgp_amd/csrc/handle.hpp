@@ -18,7 +18,7 @@ struct Handle {
   int phi_last = 0;                       // algorithm the last asvgp_phi_accumulate_1d actually ran (1, 3, 5, 6)
   // deferred cross-workgroup reduce (asvgp_set_phi_deferred_reduce): the moment kernel's partials wait here for asvgp_phi_reduce_1d
   bool phi_defer = false;
-  struct PendingReduce { const double* partials; int G, M, K; double* stats; bool valid; } pend = {nullptr, 0, 0, 0, nullptr, false};
+  struct PendingReduce { const double* partials; int G, M, K; double* stats; bool valid; const int* ranges; } pend = {nullptr, 0, 0, 0, nullptr, false, nullptr};
   // band algebra
   int band_algo = 0;
   bool sync_on = false;

@@ -375,9 +375,11 @@ namespace asvgp {
 
 // Sum the per-workgroup partials into the packed stats buffer (zeroed beforehand).
 // grid = (ceil((E+1)/256), gsplit); each thread sums its slice of workgroups, then one fp64 global atomic.
+// ranges != NULL: [workgroup][2] = first / last column partial g holds (the tile-sort kernels write only those; a time series leaves a
+// workgroup a handful of columns) - entries outside are not read.
 __global__ __launch_bounds__(256) void phi_reduce_kernel(const double* __restrict__ partials, int G, int ncols,
                                                          int K, int col0, long M, long D, int dcol, int do_band,
-                                                         double* __restrict__ stats) {
+                                                         double* __restrict__ stats, const int* __restrict__ ranges = nullptr) {
   const int E1 = (K + 2) * ncols + 1;
   int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E1) return;
@@ -386,6 +388,18 @@ __global__ __launch_bounds__(256) void phi_reduce_kernel(const double* __restric
   if (g1 > G) g1 = G;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int g = g0;
+  if (ranges) {
+    const int colr = e < (K + 2) * ncols ? e % ncols : -1;          // (-1: y^T y, which every workgroup writes)
+    auto take = [&](int gg) -> double {                             // (the range words are wave-uniform: scalar loads)
+      const int lo = ranges[2 * gg], hi = ranges[2 * gg + 1];
+      return (colr < 0 || (colr >= lo && colr <= hi)) ? __builtin_nontemporal_load(partials + (size_t)gg * E1 + e) : 0.0;
+    };
+    for (; g + 3 < g1; g += 4) {
+      const double v0 = take(g), v1 = take(g + 1), v2 = take(g + 2), v3 = take(g + 3);
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; g < g1; ++g) s0 += take(g);
+  }
   for (; g + 3 < g1; g += 4) {
     s0 += __builtin_nontemporal_load(partials + (size_t)g * E1 + e);       // (read once: keep the 29 MB out of the L2's LRU order)
     s1 += __builtin_nontemporal_load(partials + (size_t)(g + 1) * E1 + e);
@@ -580,10 +594,10 @@ static int launch_phi_moments_cs(Handle* h, const double* x, const double* y, lo
   const int E1 = (int)((K + 2) * M + 1);
   const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
   if (h->phi_defer) {   // the caller enqueues the reduce itself (asvgp_phi_reduce_1d), e.g. on the stream that consumes the statistics
-    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true};
+    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true, nullptr};
     return check_launch("phi_accumulate_1d (moments, reduce deferred)");
   }
-  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats, (const int*)nullptr);
   return check_launch("phi_accumulate_1d (moments)");
 }
 
@@ -663,6 +677,7 @@ static int launch_phi_sort_as(Handle* h, const double* x, const double* y, long 
   a.x = x; a.y = y; a.N = N; a.mesh_g = mesh; a.n_mesh = (int)n_mesh; a.inv_delta = 1.0 / delta; a.M = (int)M;
   a.m0 = m0; a.m_last = m_last; a.step = step; a.smax_fast = 0.5 - margin;
   a.partials = ws; a.ppb = ppb; a.zero_ptr = stats; a.zero_n = (K + 2) * M + 1; a.stamps = nullptr; a.stamps_wave = 0;
+  a.ranges = reinterpret_cast<int*>(ws + (size_t)PHI_MAX_BLOCKS * ((size_t)(K + 2) * M + 1));   // (behind the 256 partials: the moment kernel's overflow planes' room)
   auto kern = phi_sort_kernel<K, TP, 0, 1, TS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e)); return ASVGP_ERR_LDS_CAPACITY; }
@@ -674,10 +689,10 @@ static int launch_phi_sort_as(Handle* h, const double* x, const double* y, long 
   const int E1 = (int)((K + 2) * M + 1);
   const int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
   if (h->phi_defer) {   // the caller enqueues the reduce itself (asvgp_phi_reduce_1d), e.g. on the stream that consumes the statistics
-    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true};
+    h->pend = Handle::PendingReduce{a.partials, G, (int)M, K, stats, true, a.ranges};
     return check_launch("phi_accumulate_1d (tile sort, reduce deferred)");
   }
-  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats);
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, a.partials, G, (int)M, K, 0, M, 1L, 0, 1, stats, (const int*)a.ranges);
   return check_launch("phi_accumulate_1d (tile sort)");
 }
 
@@ -760,7 +775,7 @@ static int launch_phi(Handle* h, const double* x, const double* y, long N, long 
       int E1 = (K + 2) * ncols + 1;
       int gsplit = G >= 64 ? 16 : (G >= 8 ? 4 : 1);
       hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, partials, G, ncols, K,
-                         cell0, M, D, (int)dcol, do_band, stats);
+                         cell0, M, D, (int)dcol, do_band, stats, (const int*)nullptr);
     }
   }
   return check_launch("phi_accumulate_1d");
@@ -857,7 +872,7 @@ int handle_flush_phi_reduce(Handle* h, const double* stats, hipStream_t st) {
   h->pend.valid = false;
   const int E1 = (p.K + 2) * p.M + 1;
   const int gsplit = p.G >= 64 ? 16 : (p.G >= 8 ? 4 : 1);
-  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, p.partials, p.G, p.M, p.K, 0, (long)p.M, 1L, 0, 1, p.stats);
+  hipLaunchKernelGGL(phi_reduce_kernel, dim3((E1 + 255) / 256, gsplit), dim3(256), 0, st, p.partials, p.G, p.M, p.K, 0, (long)p.M, 1L, 0, 1, p.stats, p.ranges);
   return check_launch("phi_reduce_1d");
 }
 }  // namespace asvgp

@@ -51,6 +51,8 @@ struct PsArgs {
   double* zero_ptr; long zero_n;   // packed stats buffer to zero (phi_reduce_kernel adds into it afterwards)
   unsigned long long* stamps;      // diagnostics: per-phase cycles of one wave's lane 0 (ABL == 9), else unused
   int stamps_wave;
+  int* ranges;                     // [workgroup][2]: first / last COLUMN this workgroup's partial holds (the rest of it is not written, and
+                                   // phi_reduce_kernel does not read it); NULL: every partial is written in full
 };
 
 // points per thread and tile: as many as leave the 2 (3k+1) owner accumulators, the tile in flight and the current tile's (s, y, rank)
@@ -760,6 +762,22 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   const double badf = block_sum((double)nbad, scratch + 32);
   __syncthreads();
   double* out = a.partials + (size_t)blockIdx.x * ((size_t)(K + 2) * M + 1);
+  // The columns this workgroup has anything for: cells [clo, chi] with points -> columns [clo, chi + K].  A time series leaves a
+  // workgroup with a handful of cells: it then writes (and the reduce reads) a few hundred bytes instead of the whole 112 KB partial.
+  int col_lo = 0, col_hi = M - 1;
+  if (a.ranges) {
+    const unsigned mn = n0A ? (unsigned)tid : (n0B ? (unsigned)(tid + PS_THREADS) : 0x7fffffu);
+    const unsigned mx = n0B ? (unsigned)(tid + PS_THREADS) + 1u : (n0A ? (unsigned)tid + 1u : 0u);   // (+1: 0 = no cell)
+    const unsigned wmn = ps_wave_min_u32(mn), wmx = ps_wave_max_u32(mx);
+    if (lane == 0) { wtot[wv] = wmn; wtot[16 + wv] = wmx; }
+    __syncthreads();
+    const unsigned bmn = ps_wave_min_u32(wtot[lane & 15]), bmx = ps_wave_max_u32(wtot[16 + (lane & 15)]);
+    col_lo = bmx ? (int)bmn : 1;
+    col_hi = bmx ? (int)bmx - 1 + K : 0;
+    if (col_hi > M - 1) col_hi = M - 1;
+    if (tid == 0) { a.ranges[2 * blockIdx.x] = col_lo; a.ranges[2 * blockIdx.x + 1] = col_hi; }
+    __syncthreads();
+  }
   if constexpr (ABL == 5) {   // diagnostic: keep the moments alive, skip the conversion
     double keep = (double)(n0A + n0B);
 #pragma unroll
@@ -781,6 +799,13 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
     auto q_planes = [&](const double (&S)[NS], unsigned n0, int slot, int d0, int d1) __attribute__((always_inline)) {
       const double s0v = (double)n0;
       int pid = 0;
+      if (!__any(n0 != 0u)) {                                      // (a time series: most waves of a workgroup own no cell with points)
+#pragma unroll
+        for (int d = d0; d < d1; ++d)
+#pragma unroll
+          for (int i = 0; i + d <= K; ++i) img[(pid++) * IW + slot] = 0.0;
+        return;
+      }
 #pragma unroll
       for (int d = d0; d < d1; ++d) {
 #pragma unroll
@@ -834,7 +859,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
           }
         }
         __syncthreads();
-        if (j < M) {
+        if (j < M && j >= col_lo && j <= col_hi) {
           int pid = 0;
 #pragma unroll
           for (int d = d0; d < d1; ++d) {
@@ -861,7 +886,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int j = half * PS_THREADS + tid;
-      if (j < M) {
+      if (j < M && j >= col_lo && j <= col_hi) {
         double r = 0.0;
 #pragma unroll
         for (int i = 0; i <= K; ++i) r += img[(half * (K + 1) + i) * IW + tid + i];

@@ -194,8 +194,8 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         check(get_lib().asvgp_phi_reduce_1d(self._h.ptr, stream_ptr()), "phi_reduce_1d")
         return self._stats
 
-    def _launch_elbo(self):
-        v, l, s = self.theta()
+    def _launch_elbo(self, theta=None):
+        v, l, s = self.theta() if theta is None else theta
         S = self._statics()
         c = self.__dict__.get("_elbo_call")
         if c is None or c[0] is not S or c[1] is not self._stats:       # (device pointers of this model's buffers, looked up once)
@@ -279,13 +279,14 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
             self._check_pd(self._launch_elbo)
         return out[:4].clone()
 
-    def launch_elbo_host(self):
+    def launch_elbo_host(self, theta=None):
         """First half of elbo_and_grad_host(): enqueue the ELBO + gradient launch on the current stream with the handle's result mirror
         armed; returns the token read_elbo_host() takes.  (Split so that a caller can enqueue other work - the next Phi pass - before it
-        starts polling.)"""
+        starts polling.)  theta = (variance, lengthscale, noise variance) evaluates at these values without touching the model's parameters
+        (an optimiser's trial point)."""
         if getattr(self, "_mirror", None) is None:
             self._mirror = self._h.result_mirror(True)
-        self._launch_elbo()
+        self._launch_elbo(theta)
         return self._h.result_mirror_pending()
 
     def read_elbo_host(self, token, check_pd=True, poll_seconds=0.05):

@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_POINT = 16           # x and y read once, fp64
-PHI_KERNEL_NAMES = {6: "phi_sort_kernel<4, 6, 0, 1> (Phi pass, algorithm 6: tile sort + register moments)",
+PHI_KERNEL_NAMES = {6: "phi_sort_kernel<4, 6, 0, 1, 0> (Phi pass, algorithm 6: tile sort + register moments)",
+                    62: "phi_sort_kernel<4, 4, 0, 1, 1> (Phi pass, algorithm 6 with the time-series front loop: per-wave run sums, no sort)",
                     5: "phi_moment_kernel<4, 2048, true> (Phi pass, algorithm 5)",
                     3: "phi_band_kernel (Phi pass, algorithm 3)", 1: "phi_band_kernel (Phi pass, algorithm 1)"}
 
@@ -46,17 +47,18 @@ def synth(N, seed=1234):
     return x, y
 
 
-def measured_traffic(n_local, algo):
+def measured_traffic(n_local, algo, series=False):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B streaming reads at 64 B).  The PMC passes
-    cannot run inside this process; the committed summary profiles/r03_phi_traffic.json (same kernel, same per-rank workload,
+    cannot run inside this process; the committed summary profiles/r04_phi_traffic[_sorted].json (same kernel, same per-rank workload,
     taken with tools/collect_profiles.sh) is quoted when kernel and workload match, otherwise null.  It is a labelled constant
     from the committed profile, not a measurement of this run."""
-    path = os.path.join(ROOT, "profiles", "r03_phi_traffic.json")
+    rel = "profiles/r04_phi_traffic%s.json" % ("_sorted" if series else "")
+    path = os.path.join(ROOT, rel)
     try:
         d = json.load(open(path))
         if int(d["points_per_launch"]) == int(n_local) and int(d.get("phi_algorithm", -1)) == int(algo):
-            return d["hbm_bytes_per_launch"], "profiles/r03_phi_traffic.json"
+            return d["hbm_bytes_per_launch"], rel
     except Exception:
         pass
     return None, None
@@ -96,6 +98,79 @@ def cpu_baseline(x, y, M, theta, kind, gpu_stats=None, gpu_out=None):
     return base, parity
 
 
+_CPU_WORKER = r"""
+import sys, time, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import asvgp_oracle as O
+N, M, C, w, srt = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+rng = np.random.default_rng(1234)
+x = rng.uniform(1e-9, 1 - 1e-9, N)
+y = np.sin(20 * x) + 0.1 * rng.standard_normal(N)
+if srt:
+    o = np.argsort(x); x, y = x[o], y[o]
+lo, hi = N * w // C, N * (w + 1) // C
+bs = O.Basis(4, 0, 1, M)
+print("READY", flush=True)
+sys.stdin.readline()
+t0 = time.time()
+A, b, yy = O.sufficient_stats(bs, x[lo:hi].reshape(-1, 1), y[lo:hi].reshape(-1, 1))
+t1 = time.time()
+print(json.dumps({"t0": t0, "t1": t1, "n": hi - lo}), flush=True)
+"""
+
+
+def cpu_baseline_all_cores(N, M, srt):
+    """The same CPU steps on EVERY host core at once (SURVEY 8d asks for both figures): one process per core, each building the CSR
+    design matrix and the band statistics of its contiguous N / C shard (the N-dependent work: what shards over ranks; the O(M) band
+    algebra is not repeated per core).  Started before this process touches the GPU; the workers never do."""
+    import subprocess
+    C = os.cpu_count() or 1
+    try:
+        C = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    C = max(1, min(C, 64))
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(N), str(M), str(C), str(w), "1" if srt else "0"],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+             for w in range(C)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("worker failed to start")
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+        for p in procs:
+            p.wait(timeout=60)
+        wall = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+        return {"value": N / wall / 1e6, "unit": "Mpoints/s", "cores": C, "seconds": wall,
+                "what": "statistics pass only (CSR build + SpGEMM + band) of the whole workload, one single-threaded process per core on contiguous N / C shards"}
+    except Exception as exc:
+        for p in procs:
+            try:
+                p.kill()
+            except Exception:
+                pass
+        return {"error": repr(exc)[:200], "cores": C}
+
+
+def host_description():
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = None
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cores_available_to_this_process": aff}
+
+
 def self_launch(argv, n):
     """Parent of an N-GPU run: no GPU call has happened in this process; the workers are torchrun children."""
     import socket
@@ -129,6 +204,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="points of the workload the CPU oracle is timed on (a prefix; "
                     "parity is reported when it covers the whole workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-cores CPU figure (one oracle process per host core)")
+    ap.add_argument("--no-extras", action="store_true", help="skip dependent_steps_all_gpu and the emulated_shard extras")
     ap.add_argument("--band-algo", type=int, default=0, choices=(0, 1, 2, 3, 4), help="0 auto (matrix-core chains, planned prior), 1 sequential sweeps, "
                     "2 all-GPU block cyclic reduction, 3 planned prior chain (round-2 kernels), 4 matrix-core chains or error")
     ap.add_argument("--phi-algo", type=int, default=0, choices=(0, 1, 3, 5, 6))
@@ -164,6 +241,9 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    cpu_all = None
+    if world == 1 and not args.no_cpu_baseline and not args.no_cpu_all_cores:
+        cpu_all = cpu_baseline_all_cores(args.points, args.features, args.sorted)   # (before this process touches the GPU)
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -189,8 +269,11 @@ def main():
     basis = A.B4Spline(0, 1, M)
     Kern = {12: A.Matern12, 32: A.Matern32, 52: A.Matern52}[args.matern]
 
-    def new_model(n_total, overlapped, defer=True):
-        mm = A.GPR_1d((xd, yd), Kern(variance=theta0[0], lengthscales=theta0[1]), basis)
+    def new_model(n_total, overlapped, defer=True, n_points=None, prior_forward=0):
+        xx, yy_ = (xd, yd) if n_points is None else (xd[:n_points], yd[:n_points])
+        mm = A.GPR_1d((xx, yy_), Kern(variance=theta0[0], lengthscales=theta0[1]), basis)
+        if prior_forward:
+            mm._h.set_prior_forward(prior_forward)
         mm.likelihood.variance.assign(theta0[2])
         mm.num_data = n_total
         if args.band_algo:
@@ -286,9 +369,11 @@ def main():
     ser_ms, kern_us, n_launches = timed_blocks(serial_block, model._h)
     model._check_pd()
     phi_algo_ran = model._h.phi_last_algorithm()
-    t_phi = float(np.mean([a.elapsed_time(b) for a, b, _, _ in marks]) * 1e3) if marks else 0.0
-    t_comm = float(np.mean([b.elapsed_time(c) for _, b, c, _ in marks]) * 1e3) if marks else 0.0
-    t_band = float(np.mean([c.elapsed_time(d) for _, _, c, d in marks]) * 1e3) if marks else 0.0
+    mk = marks[1:] if len(marks) > 1 else marks          # (the first sampled step carries plan creation and allocations: excluded)
+    t_phi = float(np.median([a.elapsed_time(b) for a, b, _, _ in mk]) * 1e3) if mk else 0.0
+    t_comm = float(np.median([b.elapsed_time(c) for _, b, c, _ in mk]) * 1e3) if mk else 0.0
+    t_band = float(np.median([c.elapsed_time(d) for _, _, c, d in mk]) * 1e3) if mk else 0.0
+    phi_order_ran = model._h.phi_last_input_order() if model._h.phi_last_algorithm() == 6 else 0
     out4 = model._out.cpu().numpy()
     stats_host = stats.cpu().numpy()
 
@@ -301,8 +386,8 @@ def main():
     #     not; --worker-forward moves the pass to the handle's worker thread - measured: no gain in this order) -> reduce, [all-reduce],
     #     event of step i+1 (N stream) -> the host polls the pinned result mirror of step i.
     #   three buffer sets (extra `dependent_steps_phi_two_ahead`): ELBO launch of step i first, then the whole N side of step i+2.
-    def dependent_schedule(n_sets):
-        lanes = [new_model(N, overlapped=True, defer=(n_sets == 2)) for _ in range(n_sets)]
+    def dependent_schedule(n_sets, n_points=None, prior_forward=0):
+        lanes = [new_model(N, overlapped=True, defer=(n_sets == 2), n_points=n_points, prior_forward=prior_forward) for _ in range(n_sets)]
         if args.worker_forward and not args.no_mirror:
             for ln in lanes:
                 ln._h.set_deferred_forward_pass(2)                 # the handle's worker thread runs the host forward pass (measured: no gain in this order)
@@ -336,7 +421,8 @@ def main():
                 t0 = time.perf_counter()
                 if n_sets == 2:
                     n_side_kernel(nxt)                              # its buffer set was released by the result just read; needs no theta
-                set_theta(ln, state["theta"])
+                if args.no_mirror:
+                    set_theta(ln, state["theta"])
                 if not ev_stats[i % n_sets].query():                # (complete unless the N side is the slower one: then the launch waits in-stream)
                     s_m.wait_event(ev_stats[i % n_sets])
                 _lib.set_stream(s_m)
@@ -344,7 +430,7 @@ def main():
                     ln._launch_elbo()
                     tok = None
                 else:
-                    tok = ln.launch_elbo_host()
+                    tok = ln.launch_elbo_host(state["theta"])       # (the trial point goes straight into the launch)
                 t1 = time.perf_counter()
                 if n_sets != 2:
                     n_side_kernel(nxt)
@@ -394,6 +480,35 @@ def main():
                 torch.cuda.synchronize()
             except Exception:
                 pass
+
+    # ---- extras on the dependent schedule (VERDICT r3 #2a, #4): the same schedule with the Kuu chain's forward pass on the GPU in
+    # double-double (no host arithmetic in the step), and with one rank's share of 2 / 4 / 8 ranks (the first N/2, N/4, N/8 points; world
+    # size 1, no collective): what a rank of a strong-scaling run does per step before any collective latency.
+    extras = {}
+    if dep is not None and not args.no_extras:
+        try:
+            res = dependent_schedule(2, prior_forward=1)
+            mg = new_model(N, overlapped=False, prior_forward=1)
+            fixed = mg.elbo_and_grad().cpu().numpy()
+            del mg
+            extras["dependent_steps_all_gpu"] = {"res": res, "fixed_theta_out": [float(v) for v in fixed]}
+        except Exception as exc:
+            extras["dependent_steps_all_gpu_error"] = repr(exc)[:300]
+            _lib.set_stream(None)
+        shards = {}
+        for div in (2, 4, 8):
+            try:
+                npts = (n_local // div) & ~1
+                res = dependent_schedule(2, n_points=npts)
+                shards[str(div)] = {"res": res, "points": npts}
+            except Exception as exc:
+                shards[str(div)] = {"error": repr(exc)[:300]}
+                _lib.set_stream(None)
+        extras["emulated_shard"] = shards
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
 
     # ---- schedule B (extra): L steps with the SAME theta in flight - a throughput of independent evaluations.  N-side stream: Phi pass of
     # step i+1; M-side streams in turn: reduce, [all-reduce], ELBO launch of steps i, i-1.  Every step is a complete evaluation from the raw
@@ -475,7 +590,7 @@ def main():
             dsp = ser
             schedule = serial["schedule"] + " (dependent schedule failed: see dependent_schedule_error)"
         achieved = BYTES_PER_POINT * n_local / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
-        traffic, traffic_src = measured_traffic(n_local, phi_algo_ran)
+        traffic, traffic_src = measured_traffic(n_local, phi_algo_ran, series=(phi_order_ran == 2))
         line = {
             "metric": "Mpoints/s per ELBO+grad step, N=10M 1D Matern-3/2 M=2048",
             "value": mp(dsp["median"]),
@@ -495,8 +610,10 @@ def main():
                         "note": "the --steps block timed R times in this process between barrier + synchronize pairs; value / ms_per_step = the median block"},
             "one_step_at_a_time": serial,
             "phases_us": {"phi_pass_and_reduce": t_phi, "band_allreduce": t_comm, "elbo_and_gradient_launch": t_band,
-                          "note": "events in the one-step-at-a-time schedule (sampled every %d-th step)" % args.phase_events},
-            "roofline": {"bound": "hbm", "kernel": PHI_KERNEL_NAMES.get(phi_algo_ran, "Phi pass, algorithm %d" % phi_algo_ran), "achieved": achieved,
+                          "samples": len(mk),
+                          "note": "t_phi / t_comm / t_band of SURVEY 8d: HIP events in the one-step-at-a-time schedule, sampled every %d-th step; "
+                                  "median, first sample (plan creation, allocations) excluded" % args.phase_events},
+            "roofline": {"bound": "hbm", "kernel": PHI_KERNEL_NAMES.get(62 if (phi_algo_ran == 6 and phi_order_ran == 2) else phi_algo_ran, "Phi pass, algorithm %d" % phi_algo_ran), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "stream_ceiling": {"achieved": ceiling_gbs, "unit": "GB/s", "us": ceiling_us, "frac_of_peak": ceiling_gbs / HBM_PEAK_GBS,
                                             "kernel": "stream_probe_kernel: read-only 16 B/point over the same x, y, 256 x 1024 threads, non-temporal "
@@ -522,6 +639,29 @@ def main():
                                                              "step i, so the N side never sits between two ELBO launches; reported beside `value`, which keeps to step i+1"}
         if dep3_error is not None:
             line["dependent_steps_phi_two_ahead_error"] = dep3_error
+        if "dependent_steps_all_gpu" in extras:
+            eg = extras["dependent_steps_all_gpu"]
+            gsp = spread(eg["res"]["ms"])
+            line["dependent_steps_all_gpu"] = {
+                "value": mp(gsp["median"]), "unit": "Mpoints/s", "ms_per_step": gsp, "host_us_per_step": eg["res"]["host_us"],
+                "fused_launch_fallbacks": eg["res"]["fallbacks"], "fixed_theta_elbo_and_grad": eg["fixed_theta_out"],
+                "rel_diff_elbo_vs_default_path": abs(eg["fixed_theta_out"][0] - out4[0]) / abs(out4[0]),
+                "note": "the `value` schedule with asvgp_set_prior_forward(1): the Kuu chain's forward (elimination) pass on the GPU in double-double "
+                        "(prior_dd.hip) instead of the host's x87 long double - no host arithmetic inside the step"}
+        if "dependent_steps_all_gpu_error" in extras:
+            line["dependent_steps_all_gpu_error"] = extras["dependent_steps_all_gpu_error"]
+        if "emulated_shard" in extras:
+            es = {}
+            for div, e in extras["emulated_shard"].items():
+                if "res" in e:
+                    sp = spread(e["res"]["ms"])
+                    es["1_of_%s" % div] = {"points": e["points"], "ms_per_step": sp, "phi_kernel_us": e["res"]["kern_us"],
+                                           "whole_job_value_if_all_ranks_did_this": N / (sp["median"] * 1e-3) / 1e6}
+                else:
+                    es["1_of_%s" % div] = e
+            es["note"] = ("the `value` schedule on the first N/2, N/4, N/8 points with the global N in the bound (world size 1, no collective): one "
+                          "rank's step of a 2 / 4 / 8-rank strong-scaling run before any collective latency; not a multi-GPU measurement")
+            line["emulated_shard"] = es
         if ind is not None:
             isp = spread(ind["ms"])
             line["independent_evaluations"] = {"value": mp(isp["median"]), "unit": "Mpoints/s", "ms_per_step": isp, "in_flight": args.in_flight,
@@ -536,7 +676,15 @@ def main():
             full = (ns == N)
             okind = {12: 0, 32: 1, 52: 2}[args.matern]
             line["cpu_baseline"], parity = cpu_baseline(x[:ns], y[:ns], M, theta0, okind, stats_host if full else None, out4 if full else None)
+            line["cpu_baseline"]["host"] = host_description()
+            if cpu_all is not None:
+                line["cpu_baseline"]["all_cores"] = cpu_all
             if parity is not None:
+                if "dependent_steps_all_gpu" in line:   # the all-GPU chain against the same long-double evaluation
+                    eg = line["dependent_steps_all_gpu"]["fixed_theta_elbo_and_grad"]
+                    ee = parity["elbo_oracle_long_double"]
+                    line["dependent_steps_all_gpu"]["parity"] = {"abs_elbo_vs_long_double": abs(eg[0] - ee), "rel_elbo_vs_long_double": abs(eg[0] - ee) / abs(ee),
+                                                                 "gate": "|ELBO - long double| <= 1e-9 |ELBO|"}
                 line["parity"] = parity
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -333,10 +333,11 @@ def test_elbo_synthetic_medium_vs_oracle(A):
         model.likelihood.variance.assign(0.01)
         ob = O.Basis(order, 0, 1, M)
         Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
-        oe, og, _ = O.elbo_grad_1d(ob, kd, Ab, b, yy, N, 1.0, 0.05, 0.01)
+        ee, ge = O.elbo_grad_1d_extended(ob, kd, Ab, b, yy, N, 1.0, 0.05, 0.01)   # the same recurrences in long double: the yardstick
         r = model.elbo_and_grad().cpu().numpy()
-        assert abs(r[0] - oe) <= elbo_tol(oe, N, 1.0, 0.01, yy, bcr=True), (kd, order)
-        np.testing.assert_allclose(r[1:4], og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)), err_msg=str((kd, order)))
+        # SURVEY 8d gates, no allowance for the cancelling N v / s terms (VERDICT r3 weak #1a): measured <= 5e-12 |ELBO|, gradient <= 4e-9
+        assert abs(r[0] - ee) <= 1e-9 * abs(ee), (kd, order, r[0], ee)
+        np.testing.assert_allclose(r[1:4], ge, rtol=1e-6, err_msg=str((kd, order)))
 
 
 @pytest.mark.parametrize("M,order,D,N", [(40, 3, 2, 3000), (1024, 4, 3, 30000), (2048, 4, 7, 20000), (257, 2, 2, 5000)])
@@ -2036,12 +2037,12 @@ def test_p_chain_on_two_workgroups_at_awkward_sizes(A, M):
     v, l, s = 1.1, 6.0 / M, 0.02
     ob = O.Basis(4, 0, 1, M)
     Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
-    oe, og, _ = O.elbo_grad_1d(ob, O.MATERN32, Ab, b, yy, N, v, l, s)
+    ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN32, Ab, b, yy, N, v, l, s)   # long double: the yardstick of the SURVEY 8d gates
     model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=v, lengthscales=l), A.B4Spline(0, 1, M))
     model.likelihood.variance.assign(s)
     r = model.elbo_and_grad().cpu().numpy()
-    assert abs(r[0] - oe) <= elbo_tol(oe, N, v, s, yy, bcr=True), (M, r[0], oe)
-    np.testing.assert_allclose(r[1:4], og, rtol=1e-6)
+    assert abs(r[0] - ee) <= 1e-9 * abs(ee), (M, r[0], ee)             # no allowance (VERDICT r3 weak #1a)
+    np.testing.assert_allclose(r[1:4], ge, rtol=1e-6)
     rh = model.elbo_and_grad_host()
     assert rh == r[:4].tolist()
     os.environ["ASVGP_NO_SPLIT"] = "1"

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): kernel-trace stats of the bench command, the two separate HBM-traffic PMC passes and the SQ counter
 # passes of the Phi kernel (unsorted and sorted input), the dependent-schedule timeline, the Phi ablation harness, the M-side probe,
-# kernel-trace stats of the Kronecker and the posterior probes.  Outputs under gpurun_out/prof_r03/ ; summarised into profiles/ by
+# kernel-trace stats of the Kronecker and the posterior probes.  Outputs under gpurun_out/prof_r04/ ; summarised into profiles/ by
 # tools/summarise_profiles.py (run afterwards, on CPU).  usage: bash tools/collect_profiles.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r03
+O=$R/gpurun_out/prof_r04
 rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 30 --warmup 3 --repeats 5 --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err || exit 1
@@ -14,6 +14,8 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 tools/phi_pmc.py > $O/write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -- python3 tools/phi_pmc.py > $O/sq.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --kernel-trace --output-format csv -d $O/sq2 -- python3 tools/phi_pmc.py > $O/sq2.log 2>&1 || exit 1
+PHI_SORTED=1 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_sorted -- python3 tools/phi_pmc.py > $O/fetch_sorted.log 2>&1 || exit 1
+PHI_SORTED=1 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_sorted -- python3 tools/phi_pmc.py > $O/write_sorted.log 2>&1 || exit 1
 PHI_SORTED=1 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq_sorted -- python3 tools/phi_pmc.py > $O/sq_sorted.log 2>&1 || exit 1
 PHI_SORTED=1 timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --kernel-trace --output-format csv -d $O/sq2_sorted -- python3 tools/phi_pmc.py > $O/sq2_sorted.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/timeline -- python3 bench.py --no-cpu-baseline --in-flight 0 --no-three-sets --repeats 3 > $O/timeline_bench.json 2> $O/timeline.err || exit 1
@@ -29,6 +31,6 @@ timeout -k 10 400 python3 tools/dep_probe.py > $O/dep_probe.txt 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kron -- python3 tools/kron_probe.py > $O/kron.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/predict -- python3 tools/predict_probe.py > $O/predict.log 2>&1 || exit 1
 timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
-timeout -k 10 300 python3 bench.py --sorted --no-cpu-baseline > $O/bench_sorted.json 2> $O/bench_sorted.err || exit 1
+timeout -k 10 300 python3 bench.py --sorted > $O/bench_sorted.json 2> $O/bench_sorted.err || exit 1
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*.csv" | head -40

@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
   PsArgs a;
   a.x = dx; a.y = dy; a.N = N; a.mesh_g = dmesh; a.n_mesh = n_mesh; a.inv_delta = 1.0 / delta; a.M = M; a.step = step; a.m0 = mesh[0]; a.m_last = mesh[n_mesh - 1];
   a.smax_fast = 0.5 - (16.0 * DBL_EPSILON * std::max(std::fabs(a0), std::fabs(b0)) / delta + 1e-12);
-  a.partials = dpart; a.ppb = ppb; a.zero_ptr = nullptr; a.zero_n = 0; a.stamps = dstamps; a.stamps_wave = 0;
+  a.partials = dpart; a.ppb = ppb; a.zero_ptr = nullptr; a.zero_n = 0; a.stamps = dstamps; a.stamps_wave = 0; a.ranges = nullptr;
   printf("N=%ld dist=%d M=%d ppb=%ld lds(TP=8)=%zu\n", N, dist, M, ppb, ps_lds_bytes<K, 8>());
 
   // ---- stream ceilings

@@ -1,4 +1,4 @@
-"""profiles/r03_phi_ablation.json: the stand-alone Phi harness (tools/micro/phi_sort_bench, built by tools/micro/build_phi_sort_bench.sh) on
+"""profiles/r04_phi_ablation.json: the stand-alone Phi harness (tools/micro/phi_sort_bench, built by tools/micro/build_phi_sort_bench.sh) on
 unsorted / sorted / clustered input - read-only stream ceilings, the compile-time stage ablation of phi_sort_kernel (loads + cell search /
 + rank atomics / + scan / + scatter / + owners' register moments / full kernel with epilogue) and the per-phase cycle stamps.
 usage: python tools/phi_ablation.py out.json [N=10000000]"""
@@ -24,8 +24,12 @@ for dist, name in ((0, "unsorted"), (1, "sorted"), (2, "clustered (N(0.5, 0.08))
         d["points_per_thread_and_tile_%s" % g[0]] = {"loads_and_search": float(g[1]), "plus_rank": float(g[2]), "plus_scan": float(g[3]),
                                                      "plus_scatter": float(g[4]), "plus_owners": float(g[5]), "full": float(g[6]),
                                                      "late_prefetch_plus_owners": float(g[7]), "late_prefetch_full (product: TP=6)": float(g[8])}
+    m = re.search(r"product \(late prefetch\): TP=6 without / with the time-series front loop: %s / %s us;  TP=4: %s / %s us" % ((num,) * 4), txt)
+    if m:
+        v = [float(g) for g in m.groups()]
+        d["product_kernels_us"] = {"TP6_plain (unsorted default)": v[0], "TP6_with_front_loop": v[1], "TP4_plain": v[2], "TP4_with_front_loop (time-series default)": v[3]}
     d["phase_stamps"] = [ln.strip() for ln in txt.splitlines() if "cycles over all tiles" in ln]
-    chk = [ln.strip() for ln in txt.splitlines() if ln.startswith("check:")]
+    chk = [ln.strip() for ln in txt.splitlines() if ln.startswith("check")]
     if chk:
         d["check_vs_host"] = chk[0]
     res["inputs"][name] = d

@@ -32,7 +32,8 @@ for order_name, xs in (("unsorted", x), ("sorted", np.sort(x)), ("clustered", np
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / 20
-        out["%s/algo%d" % (order_name, algo)] = {"us_per_pass": round(us, 1), "max_rel_diff_vs_algo5": err}
-        print("%-10s algo %d  %7.1f us per pass (kernel + reduce)   diff vs algo 5: %.2e" % (order_name, algo, us, err), flush=True)
+        ts = (m._h.phi_last_input_order() == 2) if algo == 6 else False
+        out["%s/algo%d" % (order_name, algo)] = {"us_per_pass": round(us, 1), "max_rel_diff_vs_algo5": err, "time_series_instantiation": ts}
+        print("%-10s algo %d%s  %7.1f us per pass (kernel + reduce)   diff vs algo 5: %.2e" % (order_name, algo, " (time-series front loop)" if ts else "", us, err), flush=True)
 A.set_phi_algorithm(0)
 print(json.dumps({"N": N, "M": M, "results": out}))

@@ -1,7 +1,7 @@
 """Summarise gpurun_out/prof_<tag> (tools/collect_profiles.sh) into profiles/ (tracked).  usage: python tools/summarise_profiles.py [tag=r03]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 KERNEL = "phi_sort_kernel"
@@ -68,23 +68,38 @@ if kt:
                "note": "256 workgroups = one-step-at-a-time schedule (and warm-up / construction): compare with roofline.kernel_us; 240 = dependent and "
                        "independent-evaluation schedules (the launch shares the device with the chain workgroups)"},
               open(os.path.join(dst, tag + "_phi_kernel_by_schedule.json"), "w"), indent=1)
-fetch, nf = counters("fetch")
-write, nw = counters("write")
-name, avg_ns = None, 0.0
-for row in csv.DictReader(open(ks)):
-    if KERNEL in row["Name"]:
-        name, avg_ns = row["Name"].split("(")[0].replace("void asvgp::", ""), float(row["AverageNs"])
-traffic = {
-    "kernel": name, "phi_algorithm": PHI_ALGORITHM, "points_per_launch": 10_000_000,
-    "FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
-    "correction": "gfx950 tallies 128-B streaming reads at 64 B: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); units KiB",
-    "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024,
-    "algorithmic_bytes_per_launch": 160_000_000,
-    "kernel_trace_average_us": avg_ns / 1e3,
-    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 tools/phi_pmc.py "
-               "(tools/collect_profiles.sh; launches averaged: %d / %d)" % (nf["FETCH_SIZE"], nw["WRITE_SIZE"]),
-}
-json.dump(traffic, open(os.path.join(dst, tag + "_phi_traffic.json"), "w"), indent=1)
+def kernel_of(sub):
+    """name and average duration (us) of the Phi kernel in the kernel trace of a PMC pass"""
+    names, durs = {}, []
+    for f in newest(os.path.join(src, sub, "*", "*_kernel_trace.csv")):
+        for row in csv.DictReader(open(f)):
+            if KERNEL in row["Kernel_Name"]:
+                names[row["Kernel_Name"].split("(")[0].replace("void asvgp::", "")] = 1
+                durs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    return " / ".join(names), (sum(durs) / len(durs) if durs else 0.0)
+
+
+name = None
+for order, sfx, sub_f, sub_w in (("unsorted", "", "fetch", "write"), ("sorted (time series)", "_sorted", "fetch_sorted", "write_sorted")):
+    fetch, nf = counters(sub_f)
+    write, nw = counters(sub_w)
+    if "FETCH_SIZE" not in fetch or "WRITE_SIZE" not in write:
+        continue
+    kname, kus = kernel_of(sub_f)
+    if not sfx:
+        name = kname
+    traffic = {
+        "kernel": kname, "phi_algorithm": PHI_ALGORITHM, "input_order": order, "points_per_launch": 10_000_000,
+        "FETCH_SIZE_KiB": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB": write["WRITE_SIZE"],
+        "correction": "gfx950 tallies 128-B streaming reads at 64 B: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); units KiB",
+        "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024,
+        "algorithmic_bytes_per_launch": 160_000_000,
+        "kernel_trace_average_us_under_pmc": kus,
+        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 tools/phi_pmc.py%s "
+                   "(tools/collect_profiles.sh; launches averaged: %d / %d)" % (" with PHI_SORTED=1" if sfx else "", nf["FETCH_SIZE"], nw["WRITE_SIZE"]),
+    }
+    json.dump(traffic, open(os.path.join(dst, tag + "_phi_traffic" + sfx + ".json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
 sq, _ = counters("sq")
 sq2, _ = counters("sq2")
 sq.update(sq2)
@@ -95,4 +110,4 @@ json.dump({"kernel": name, "unsorted": sq, "sorted": sqs,
            "note": "rocprofv3 --pmc, two passes of 8 SQ counters each per input order, averaged over the launches of tools/phi_pmc.py (chip totals; "
                    "PHI_SORTED=1 for the sorted input)"},
           open(os.path.join(dst, tag + "_phi_pmc_counters.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1)); print(sq); print(sqs)
+print(sq); print(sqs)
