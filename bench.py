@@ -386,13 +386,17 @@ def main():
     #     not; --worker-forward moves the pass to the handle's worker thread - measured: no gain in this order) -> reduce, [all-reduce],
     #     event of step i+1 (N stream) -> the host polls the pinned result mirror of step i.
     #   three buffer sets (extra `dependent_steps_phi_two_ahead`): ELBO launch of step i first, then the whole N side of step i+2.
+    # Streams are made once and shared by every schedule of this process: HIP maps streams onto a handful of hardware queues round robin,
+    # and a schedule whose N-side and M-side streams land on the SAME queue runs them in series (measured: the third or fourth schedule
+    # of a process took 100-130 us per step instead of 72, its Phi kernel "70 us" - waiting behind the ELBO launch).
+    stream_pool = {"n": torch.cuda.Stream(), "m": torch.cuda.Stream(priority=-1), "m2": torch.cuda.Stream(priority=-1)}
+
     def dependent_schedule(n_sets, n_points=None, prior_forward=0):
         lanes = [new_model(N, overlapped=True, defer=(n_sets == 2), n_points=n_points, prior_forward=prior_forward) for _ in range(n_sets)]
         if args.worker_forward and not args.no_mirror:
             for ln in lanes:
                 ln._h.set_deferred_forward_pass(2)                 # the handle's worker thread runs the host forward pass (measured: no gain in this order)
-        s_n = torch.cuda.Stream()
-        s_m = torch.cuda.Stream(priority=-1)
+        s_n, s_m = stream_pool["n"], stream_pool["m"]              # (made ONCE: see stream_pool)
         ev_stats = [torch.cuda.Event() for _ in range(n_sets)]
         ahead = n_sets - 1
         state = {"i": 0, "theta": theta0, "primed": False, "last": None, "t_a": 0.0, "t_b": 0.0, "t_poll": 0.0, "n": 0}
@@ -459,7 +463,12 @@ def main():
                            ("reduce_and_event_enqueue" if n_sets == 2 else "n_side_enqueue"): state["t_b"] / n_acc * 1e6,
                            "wait_for_result": state["t_poll"] / n_acc * 1e6}}
         torch.cuda.synchronize()
+        for ln in lanes:
+            ln.close()                                             # (handles with their pinned rings and worker threads go now, not at garbage collection)
         del lanes
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         return out
 
     dep, dep_error, dep3, dep3_error = None, None, None, None
@@ -481,35 +490,6 @@ def main():
             except Exception:
                 pass
 
-    # ---- extras on the dependent schedule (VERDICT r3 #2a, #4): the same schedule with the Kuu chain's forward pass on the GPU in
-    # double-double (no host arithmetic in the step), and with one rank's share of 2 / 4 / 8 ranks (the first N/2, N/4, N/8 points; world
-    # size 1, no collective): what a rank of a strong-scaling run does per step before any collective latency.
-    extras = {}
-    if dep is not None and not args.no_extras:
-        try:
-            res = dependent_schedule(2, prior_forward=1)
-            mg = new_model(N, overlapped=False, prior_forward=1)
-            fixed = mg.elbo_and_grad().cpu().numpy()
-            del mg
-            extras["dependent_steps_all_gpu"] = {"res": res, "fixed_theta_out": [float(v) for v in fixed]}
-        except Exception as exc:
-            extras["dependent_steps_all_gpu_error"] = repr(exc)[:300]
-            _lib.set_stream(None)
-        shards = {}
-        for div in (2, 4, 8):
-            try:
-                npts = (n_local // div) & ~1
-                res = dependent_schedule(2, n_points=npts)
-                shards[str(div)] = {"res": res, "points": npts}
-            except Exception as exc:
-                shards[str(div)] = {"error": repr(exc)[:300]}
-                _lib.set_stream(None)
-        extras["emulated_shard"] = shards
-        try:
-            torch.cuda.synchronize()
-        except Exception:
-            pass
-
     # ---- schedule B (extra): L steps with the SAME theta in flight - a throughput of independent evaluations.  N-side stream: Phi pass of
     # step i+1; M-side streams in turn: reduce, [all-reduce], ELBO launch of steps i, i-1.  Every step is a complete evaluation from the raw
     # points into its own buffers; a lane is reused once the host has seen its previous step finish.
@@ -517,8 +497,8 @@ def main():
     if args.in_flight >= 2:
         try:
             lanes = [[new_model(N, overlapped=True), torch.cuda.Event(), torch.cuda.Event(), False] for _ in range(args.in_flight)]
-            s_phi = torch.cuda.Stream()
-            s_chains = [torch.cuda.Stream(priority=-1) for _ in range(max(1, args.chain_streams))]
+            s_phi = stream_pool["n"]
+            s_chains = [stream_pool["m"], stream_pool["m2"]][:max(1, min(2, args.chain_streams))]
             turn = [0]
 
             def independent_block(k):
@@ -553,6 +533,35 @@ def main():
                 torch.cuda.synchronize()
             except Exception:
                 pass
+
+    # ---- extras on the dependent schedule (VERDICT r3 #2a, #4): the same schedule with the Kuu chain's forward pass on the GPU in
+    # double-double (no host arithmetic in the step), and with one rank's share of 2 / 4 / 8 ranks (the first N/2, N/4, N/8 points; world
+    # size 1, no collective): what a rank of a strong-scaling run does per step before any collective latency.
+    extras = {}
+    if dep is not None and not args.no_extras:
+        try:
+            res = dependent_schedule(2, prior_forward=1)
+            mg = new_model(N, overlapped=False, prior_forward=1)
+            fixed = mg.elbo_and_grad().cpu().numpy()
+            del mg
+            extras["dependent_steps_all_gpu"] = {"res": res, "fixed_theta_out": [float(v) for v in fixed]}
+        except Exception as exc:
+            extras["dependent_steps_all_gpu_error"] = repr(exc)[:300]
+            _lib.set_stream(None)
+        shards = {}
+        for div in tuple(int(v) for v in os.environ.get("ASVGP_BENCH_SHARDS", "2,4,8").split(",")):
+            try:
+                npts = (n_local // div) & ~1
+                res = dependent_schedule(2, n_points=npts)
+                shards[str(div)] = {"res": res, "points": npts}
+            except Exception as exc:
+                shards[str(div)] = {"error": repr(exc)[:300]}
+                _lib.set_stream(None)
+        extras["emulated_shard"] = shards
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
 
     # Extra, N > 1 only: the one-at-a-time step with the BASELINE N on EVERY rank (weak scaling).  `value` stays the strong-scaling figure
     # the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
