@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r04
 rm -rf $O; mkdir -p $O
 cd $R
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 30 --warmup 3 --repeats 5 --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 30 --warmup 3 --repeats 5 --no-cpu-baseline --no-extras > $O/trace_bench.json 2> $O/trace.err || exit 1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 tools/phi_pmc.py > $O/fetch.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 tools/phi_pmc.py > $O/write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -- python3 tools/phi_pmc.py > $O/sq.log 2>&1 || exit 1

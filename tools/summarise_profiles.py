@@ -27,7 +27,7 @@ def copy(name_in, name_out):
     p = os.path.join(src, name_in)
     if os.path.exists(p):
         if name_in.endswith(".txt") or name_in.endswith(".log"):
-            lines = [ln for ln in open(p).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2")]
+            lines = [ln for ln in open(p).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2") and not ln.startswith("E20")]
             open(os.path.join(dst, name_out), "w").write("\n".join(lines) + "\n")
         else:
             shutil.copy(p, os.path.join(dst, name_out))
@@ -51,7 +51,7 @@ for sub in ("kron", "predict"):          # kernel-trace stats of tools/kron_prob
     fs = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if fs:
         shutil.copy(fs[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, sub)))
-        log = [ln for ln in open(os.path.join(src, sub + ".log")).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2")]
+        log = [ln for ln in open(os.path.join(src, sub + ".log")).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2") and not ln.startswith("E20")]
         open(os.path.join(dst, "%s_%s_probe.txt" % (tag, sub)), "w").write("\n".join(log[-12:]) + "\n")
 # the bench runs its schedules in one process: split the Phi kernel's launches by grid size (256 workgroups = one step at a time and
 # construction, fewer = the overlapped schedules) so that each average can be held against the matching figure of the bench line
@@ -62,7 +62,7 @@ if kt:
         if KERNEL in row["Kernel_Name"]:
             wgs = int(row["Grid_Size_X"]) // max(int(row["Workgroup_Size_X"]), 1)
             by_grid.setdefault(wgs, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-    json.dump({"kernel": KERNEL, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 3 --repeats 5 --no-cpu-baseline",
+    json.dump({"kernel": KERNEL, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 3 --repeats 5 --no-cpu-baseline --no-extras",
                "launches_by_workgroups": {str(k): {"launches": len(v), "average_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
                                           for k, v in sorted(by_grid.items())},
                "note": "256 workgroups = one-step-at-a-time schedule (and warm-up / construction): compare with roofline.kernel_us; 240 = dependent and "
