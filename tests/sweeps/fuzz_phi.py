@@ -33,6 +33,11 @@ for case in range(n_cases + n_big):
     if rng.random() < 0.3 and N > 10: y[rng.integers(0, N, 3)] *= 1e6
     algo = int(rng.choice([0, 0, 1, 3, 5, 6]))      # auto | fp64 scatter | fixed-point band scatter | fixed-point moments | tile sort
     A.set_phi_algorithm(algo)
+    order_mode = int(rng.choice([0, 0, 1, 2, 2]))   # input order of the tile sort: probe | plain instantiation | time-series front loop (round 4)
+    A.set_phi_input_order(order_mode)
+    if dist == "sorted" and rng.random() < 0.5:     # time-series shapes the front loop has to leave part of the way / re-enter never
+        if rng.random() < 0.5: x = x[::-1].copy()
+        else: x[N // 2:] = rng.uniform(lo, hi, N - N // 2)
     try:
         bs = getattr(A, "B%dSpline" % order)(a, b, M)
         xs = torch.from_numpy(np.concatenate([[0.0], x]))[1:].cuda() if rng.random() < 0.3 else torch.from_numpy(x).cuda()   # sometimes unaligned
@@ -53,6 +58,7 @@ for case in range(n_cases + n_big):
         print("EXC", repr(e)[:200])
     if not ok:
         fails += 1
-        print("FAIL case %d: order %d M %d N %d [%s,%s] %s yscale %g algo %d  band %.2e rhs %.2e yy %.2e" % (case, order, M, N, a, b, dist, yscale, algo, eb, er, ey), flush=True)
+        print("FAIL case %d: order %d M %d N %d [%s,%s] %s yscale %g algo %d input-order %d  band %.2e rhs %.2e yy %.2e" % (case, order, M, N, a, b, dist, yscale, algo, order_mode, eb, er, ey), flush=True)
 A.set_phi_algorithm(0)
+A.set_phi_input_order(0)
 print("cases %d, failures %d" % (n_cases, fails))
