@@ -31,6 +31,8 @@ SIGNATURES = {
     "asvgp_prior_interior_kuu_host": (_I, [_P, _I, _L, _I, _P, _P, _c.POINTER(_L), _c.POINTER(_L), _P]),
     "asvgp_result_mirror": (_I, [_P, _I, _c.POINTER(_P)]),
     "asvgp_result_mirror_read": (_I, [_P, _c.c_uint64, _P, _D]),
+    "asvgp_elbo_grad_ahead_1d": (_I, [_P, _P, _P, _I, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
+    "asvgp_elbo_publish_theta": (_I, [_P, _D, _D, _D]),
     "asvgp_elbo_grad_host_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P, _P, _D]),
     "asvgp_result_mirror_pending": (_c.c_uint64, [_P]),
     "asvgp_set_phi_workgroups": (_I, [_P, _I]),

@@ -11,6 +11,7 @@
 //   phase 3  finalize : log-dets (gpr.py:57,74), band traces (gpr.py:60-70), 7-term bound (gpr.py:78-87), gradient
 #include <stdlib.h>
 #include <time.h>
+#include <string.h>
 
 #include "bcr_pre.hpp"
 #include "bcr_mfma.hpp"
@@ -88,6 +89,17 @@ struct KuuCoefs2 { double c[ASVGP_MAX_KUU_TERMS]; double dc[ASVGP_MAX_KUU_TERMS]
 // (dk_tab = 1; wider boundaries: dk_tab = 0 and the kernel sums the static bands for those columns) - kernel arguments end at 4 KB
 constexpr int KI_DKB = 8;
 struct KuuInterior { double k[8]; long lo, hi; double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND]; double dk[8]; double dkb[2 * 5 * KI_DKB]; int dk_tab; };
+// Launch-ahead (asvgp_elbo_grad_ahead_1d / asvgp_elbo_publish_theta): everything of the matrix-core launch that depends on theta, handed
+// over through pinned host memory AFTER the launch - the kernel is resident (its ~8 us of launch path and dispatch latency already spent)
+// when the optimiser has its next theta.  seq is stored last (release); ~0: the host has withdrawn the launch.
+struct ThetaBox {
+  unsigned long long seq;
+  double s, alpha_scale, v, l, N;
+  double k[8], dk[8];
+  double bnd[2 * PRIOR_BND_DIAGS * PRIOR_BND];
+  double dkb[2 * 5 * KI_DKB];
+  double dc[ASVGP_MAX_KUU_TERMS];
+};
 typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;
 struct BandSumToep {
   const double* A; double inv_s;
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
                                                                       double s, const double* tab, int n_rec, const int* node_rec,
                                                                       double* wsK, double* SK, double* dSK,
                                                                       unsigned long long* done_flag, unsigned long long seq,
-                                                                      const unsigned long long* ready_flag, long spin_limit, FusedFin fin) {
+                                                                      const unsigned long long* ready_flag, long spin_limit, FusedFin fin, const ThetaBox* box) {
   extern __shared__ double lds[];
   static_assert(K == BM_B, "matrix-core chains: bandwidth 4");
   const long E = (long)(K + 1) * M;
@@ -492,6 +504,24 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   __shared__ double kuu_pref[4];
   if (threadIdx.x == 0) { gave_up = 0; kuu_ok = 0; }
   __syncthreads();
+  // theta and what the host derives from it: kernel arguments, or - launch-ahead - the handle's pinned box once the host has filled it
+  double s_v = s, asc_v = fin.alpha_scale;
+  ElboScalars th_v = fin.th;
+  if (box) {
+    if (threadIdx.x == 0) {
+      long spins = 0;
+      for (;;) {
+        const unsigned long long got = __hip_atomic_load(&box->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (got == seq) break;
+        if (got == ~0ull || ++spins > spin_limit) { gave_up = 1; break; }   // (withdrawn, or the host never came: bounded like every wait here)
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (gave_up) { if (threadIdx.x == 0) atomicExch(info + 1, -1); return; }
+    s_v = box->s; asc_v = box->alpha_scale;
+    th_v.v = box->v; th_v.l = box->l; th_v.s = box->s; th_v.N = box->N;
+  }
   const double* stats = fin.stats;
   enum { LOGK, LOGP, TRKA, DTRKA, SKDK, SPDK, SKK, SPK, SPA, CC, AKA, ADKA, AAA, BA, NACC };
   double acc[NACC];
@@ -505,12 +535,17 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   {
     if (isP) rstamp(1);
     if (threadIdx.x == 0) {
-      kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4];
-      kdl[8] = ki.dk[0]; kdl[9] = ki.dk[1]; kdl[10] = ki.dk[2]; kdl[11] = ki.dk[3]; kdl[12] = ki.dk[4];
+      if (box) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { kdl[i] = box->k[i]; kdl[8 + i] = box->dk[i]; }
+      } else {
+        kdl[0] = ki.k[0]; kdl[1] = ki.k[1]; kdl[2] = ki.k[2]; kdl[3] = ki.k[3]; kdl[4] = ki.k[4];
+        kdl[8] = ki.dk[0]; kdl[9] = ki.dk[1]; kdl[10] = ki.dk[2]; kdl[11] = ki.dk[3]; kdl[12] = ki.dk[4];
+      }
     }
-    {   // (ki is kernel argument 0: its tables are read in place, from the kernel-argument segment, ONCE)
-      const double* bnd_g = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
-      const double* dkb_g = reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, dkb));
+    {   // (ki is kernel argument 0: its tables are read in place, from the kernel-argument segment, ONCE - or from the box)
+      const double* bnd_g = box ? box->bnd : reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, bnd));
+      const double* dkb_g = box ? box->dkb : reinterpret_cast<const double*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KuuInterior, dkb));
       if (threadIdx.x < 2 * PRIOR_BND_DIAGS * PRIOR_BND) bnd[threadIdx.x] = bnd_g[threadIdx.x];
       else if (threadIdx.x < 2 * PRIOR_BND_DIAGS * PRIOR_BND + 2 * 5 * KI_DKB) dkb[threadIdx.x - 2 * PRIOR_BND_DIAGS * PRIOR_BND] = dkb_g[threadIdx.x - 2 * PRIOR_BND_DIAGS * PRIOR_BND];
     }
@@ -519,7 +554,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
   if (isP) {
     BmSplit bsp;
     if (fin.split) { bsp.half = isPR ? 1 : 0; bsp.xchg = fin.xchg; bsp.spin_limit = spin_limit; bsp.gave_up = &gave_up; bsp.tag = seq << 8; }
-    bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s, (lds_cdouble_ptr)kdl, (lds_cdouble_ptr)bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1, 1,
+    bcr_mfma_solve<BandSumToep>(BandSumToep{A, 1.0 / s_v, (lds_cdouble_ptr)kdl, (lds_cdouble_ptr)bnd, ki.lo, ki.hi}, b, M, wsP, lds, SP, x, logdets + 2, info + 1, 1,
                                 fin.debug_stamps ? (isPR ? fin.xchg + 128 : logdets + 32) : (double*)nullptr, bsp);   // (per-level cycle stamps: tools/mside_probe.py)
     rstamp(3);
     __syncthreads();                                           // (orders SP, the solve's last global stores, for the loop below)
@@ -569,7 +604,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
               dkv = dkb[left ? (long)r * KI_DKB + j : (long)(5 + r) * KI_DKB + (j - ki.hi)];
             } else {                                           // (five dependent trips to the static bands: ~5 us on the launch's tail)
               dkv = 0.0;
-              for (int t = 0; t < cf.n; ++t) dkv = fma(cf.dc[t], S_static[(long)t * E + o], dkv);
+              for (int t = 0; t < cf.n; ++t) dkv = fma(box ? box->dc[t] : cf.dc[t], S_static[(long)t * E + o], dkv);
             }
           }
           const double xx = (j + r < M) ? w2 * xj * xs_l[j + r] : 0.0;   // (below the matrix: the band entries there are 0 as well)
@@ -625,7 +660,7 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
               dkv = dkb[left ? (long)r * KI_DKB + j : (long)(5 + r) * KI_DKB + (j - ki.hi)];
             } else {
               dkv = 0.0;
-              for (int t = 0; t < cf.n; ++t) dkv = fma(cf.dc[t], S_static[(long)t * E + o], dkv);
+              for (int t = 0; t < cf.n; ++t) dkv = fma(box ? box->dc[t] : cf.dc[t], S_static[(long)t * E + o], dkv);
             }
           }
           acc[TRKA] = fma(w2 * sk[cI][r], av[cI][r], acc[TRKA]);
@@ -708,9 +743,9 @@ __global__ __launch_bounds__(BM_THREADS) void elbo_chains_mfma_kernel(KuuInterio
 #pragma unroll
   for (int i = 0; i < 14; ++i) __hip_atomic_store(fin.gacc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm (the older kernels ADD into these slots; the message has been read)
   {
-    const double v = fin.th.v, sn = fin.th.s, N = fin.th.N;
+    const double v = th_v.v, sn = th_v.s, N = th_v.N;
     const double yy = stats[(long)(K + 1) * M + M];
-    const double asc = fin.alpha_scale;                        // x = P^-1 b unscaled: alpha = x / s
+    const double asc = asc_v;                                  // x = P^-1 b unscaled: alpha = x / s
     tot[AKA] *= asc * asc; tot[ADKA] *= asc * asc; tot[AAA] *= asc * asc; tot[BA] *= asc;
     // the log-determinants were written by the two chains' lane 0 before their atomics (same lanes: program order + the drain above)
     tot[LOGK] = __hip_atomic_load(logdets + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -828,6 +863,7 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
       set_error("band algorithm 4 (matrix-core chains) needs k = 4, D = 1, M <= 2048, Toeplitz static bands and the ELBO + gradient entry point");
       return ASVGP_ERR_UNSUPPORTED;
     }
+    if (h->ahead_req && !use_mfma) { set_error("launch-ahead exists for the matrix-core launch only (k = 4, D = 1, M <= 2048, planned prior chain)"); return ASVGP_ERR_UNSUPPORTED; }
     if (!use_mfma && !fits) { set_error("BCR needs %zu B of LDS", lds_bytes); return ASVGP_ERR_LDS_CAPACITY; }
     unsigned long long seq = 0;
     int slot = 0;
@@ -888,7 +924,25 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
         const double t0 = host_times ? now_us() : 0.0;
         if (plan_first && !gpu_fwd) (void)prior_plan_eval(h->plan, cf.c, cf.dc, tab);
-        const bool to_worker = !plan_first && !gpu_fwd && h->fwd_worker;
+        // launch-ahead: theta comes later, through the handle's pinned box ring (asvgp_elbo_publish_theta); nothing below runs the forward pass
+        const ThetaBox* box_k = nullptr;
+        if (h->ahead_req) {
+          if (gpu_fwd || plan_first) { set_error("launch-ahead needs the host forward pass (asvgp_set_prior_forward(h, 0))"); return ASVGP_ERR_UNSUPPORTED; }
+          static_assert(sizeof(ThetaBox) <= BOX_BYTES, "theta box");
+          if (!h->box_host) {
+            if (hipHostMalloc(&h->box_host, BOX_BYTES * TAB_SLOTS, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer(&h->box_dev, h->box_host, 0) != hipSuccess) {
+              if (h->box_host) { (void)hipHostFree(h->box_host); h->box_host = nullptr; }
+              set_error("launch-ahead: pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
+              return ASVGP_ERR_HIP;
+            }
+            memset(h->box_host, 0, BOX_BYTES * TAB_SLOTS);
+          }
+          ThetaBox* bh = reinterpret_cast<ThetaBox*>(static_cast<char*>(h->box_host) + (size_t)slot * BOX_BYTES);
+          __atomic_store_n(&bh->seq, 0ull, __ATOMIC_RELEASE);     // (not this launch's theta yet)
+          box_k = reinterpret_cast<const ThetaBox*>(static_cast<const char*>(h->box_dev) + (size_t)slot * BOX_BYTES);
+        }
+        const bool to_worker = !plan_first && !gpu_fwd && h->fwd_worker && !h->ahead_req;
         if (to_worker) {                                       // the handle's worker thread starts on the table NOW, beside the launch call
           for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) { h->fwd.coef[t] = cf.c[t]; h->fwd.dcoef[t] = cf.dc[t]; }
           h->fwd.tab = tab; h->fwd.slot = slot; h->fwd.seq = seq;
@@ -896,7 +950,11 @@ static int run_chains(Handle* h, const double* stats, const double* S, int kind,
         }
         hipLaunchKernelGGL(kern, dim3(2 + ff.split + ff.n_helpers), dim3(BM_THREADS), lb, st, ki, S, cf, w.Kuu, w.dK, A, b, (int)M, w.bcrP, w.SP, w.alpha, w.logdets, info, s,
                            tab_k, n_rec, h->node_rec_dev, w.bcrK, w.SK, w.dSK, h->done_dev + slot, seq,
-                           gpu_fwd ? dd_ready : (plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot), spin_limit, ff);
+                           gpu_fwd ? dd_ready : (plan_first ? (const unsigned long long*)nullptr : h->ready_dev + slot), spin_limit, ff, box_k);
+        if (h->ahead_req) {
+          h->ahead = Handle::PendingAhead{true, slot, seq, tab, kind, (long)ff.th.N};
+          return check_launch("elbo chains (matrix cores, launched ahead of theta)");
+        }
         if (gpu_fwd) return check_launch("elbo chains (matrix cores, forward pass on the GPU)");
         if (to_worker) return check_launch("elbo chains (matrix cores, forward pass on the worker thread)");
         const double t1 = host_times ? now_us() : 0.0;
@@ -1108,6 +1166,49 @@ int KuuInvLauncher<K>::run(Handle* h, const double* S, int kind, double v, doubl
   return check_launch("kuu_inverse_band_1d (sweeps)");
 }
 
+#if ASVGP_ELBO_ONLY_K == 4 && (!defined(ASVGP_ELBO_PART) || ASVGP_ELBO_PART == 1)
+// Launch-ahead, second half: the theta of the launch that is out.  Coefficients, Kuu / dKuu in closed form (the reference's rounding
+// sequence, as in run_chains), the scalars of the bound -> the slot's box, sequence number LAST; then the host forward pass of the Kuu
+// chain and its ready word, exactly as the ordinary launch does behind its kernel launch.
+int elbo_publish_theta(Handle* h, double v, double l, double s, bool withdraw) {
+  if (!h->ahead.valid) { set_error("publish_theta: no launch is waiting for its theta"); return ASVGP_ERR_BAD_ARG; }
+  const Handle::PendingAhead a = h->ahead;
+  h->ahead.valid = false;
+  ThetaBox* bh = reinterpret_cast<ThetaBox*>(static_cast<char*>(h->box_host) + (size_t)a.slot * BOX_BYTES);
+  if (withdraw || !h->plan) {
+    __atomic_store_n(&bh->seq, ~0ull, __ATOMIC_RELEASE);
+    __atomic_store_n(h->ready_host + a.slot, a.seq, __ATOMIC_RELEASE);   // (nobody reads the table: the launch gives up at its first wait)
+    return ASVGP_OK;
+  }
+  KuuCoefs2 cf;
+  for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) cf.c[t] = cf.dc[t] = 0.0;
+  const int rc = asvgp_matern_coeffs(a.kind, v, l, cf.c, cf.dc, &cf.n);
+  if (rc) { __atomic_store_n(&bh->seq, ~0ull, __ATOMIC_RELEASE); return rc; }
+  constexpr int K = 4;
+  long lo = 0, hi = 0, lo2 = 0, hi2 = 0;
+  double bnd2[2 * PRIOR_BND_DIAGS * PRIOR_BND];
+  for (int i = 0; i < 8; ++i) { bh->k[i] = 0.0; bh->dk[i] = 0.0; }
+  prior_plan_interior_kuu(h->plan, cf.c, bh->k, &lo, &hi, bh->bnd);
+  prior_plan_interior_kuu(h->plan, cf.dc, bh->dk, &lo2, &hi2, bnd2);
+  for (int sd = 0; sd < 2; ++sd)
+    for (int d = 0; d <= K; ++d)
+      for (int cI = 0; cI < KI_DKB; ++cI)
+        bh->dkb[(sd * 5 + d) * KI_DKB + cI] = bnd2[(size_t)(sd * PRIOR_BND_DIAGS + d) * PRIOR_BND + cI];
+  for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) bh->dc[t] = cf.dc[t];
+  bh->s = s; bh->alpha_scale = 1.0 / s; bh->v = v; bh->l = l; bh->N = (double)a.N;
+  __atomic_store_n(&bh->seq, a.seq, __ATOMIC_RELEASE);          // the kernel proceeds: P chain at once, the Kuu workgroup waits for the table
+  if (h->defer_forward) {                                       // (asvgp_set_deferred_forward_pass(h, 1): the caller enqueues other work first, then asvgp_prior_publish)
+    h->fwd.valid = true;
+    for (int t = 0; t < ASVGP_MAX_KUU_TERMS; ++t) { h->fwd.coef[t] = cf.c[t]; h->fwd.dcoef[t] = cf.dc[t]; }
+    h->fwd.tab = a.tab; h->fwd.slot = a.slot; h->fwd.seq = a.seq;
+    return ASVGP_OK;
+  }
+  (void)prior_plan_eval(h->plan, cf.c, cf.dc, a.tab);           // a non-positive pivot is reported through `info` by the kernel
+  __atomic_store_n(h->ready_host + a.slot, a.seq, __ATOMIC_RELEASE);
+  return ASVGP_OK;
+}
+#endif
+
 // ASVGP_ELBO_PART: 1 = ELBO + gradient launcher (tangent chains), 2 = posterior launcher, unset = both
 #if !defined(ASVGP_ELBO_PART) || ASVGP_ELBO_PART == 1
 template struct ElboLauncher<ASVGP_ELBO_ONLY_K>;
@@ -1172,6 +1273,20 @@ extern "C" int asvgp_result_mirror_read(asvgp_handle_t handle, uint64_t token, d
       if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_seconds) return 1;   // (a launch that gave up never writes it)
     }
   }
+}
+extern "C" int asvgp_elbo_grad_ahead_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, int64_t N, int64_t M,
+                                        int k, int64_t D, double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream) {
+  Handle* h = as_handle(handle);
+  if (h->ahead.valid) { set_error("elbo_grad_ahead_1d: the previous launch still waits for its theta (asvgp_elbo_publish_theta)"); return ASVGP_ERR_BAD_ARG; }
+  if (!h->mirror_host) { const double* p = nullptr; const int rcm = asvgp_result_mirror(handle, 1, &p); if (rcm) return rcm; }
+  h->ahead_req = true;
+  const int rc = asvgp_elbo_grad_1d(handle, stats, static_bands, kind, 1.0, 1.0, 1.0, N, M, k, D, out, info, workspace, workspace_bytes, stream);
+  h->ahead_req = false;
+  return rc;
+}
+extern "C" int asvgp_elbo_publish_theta(asvgp_handle_t handle, double variance, double lengthscale, double noise_variance) {
+  if (!(variance > 0.0) || !(lengthscale > 0.0) || !(noise_variance > 0.0)) { set_error("elbo_publish_theta: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  return elbo_publish_theta(as_handle(handle), variance, lengthscale, noise_variance, false);
 }
 extern "C" int asvgp_elbo_grad_host_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                                        double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,

@@ -47,6 +47,7 @@ Handle* as_handle(asvgp_handle_t h) {
 // flight reads the pinned ring or writes the mirror.  Bounded; a launch that gave up waiting never reports, so the fallback is a
 // device synchronisation.  This replaces a device-wide synchronisation on every model teardown.
 static void handle_quiesce(Handle* h) {
+  if (h->ahead.valid) (void)elbo_publish_theta(h, 1.0, 1.0, 1.0, true);   // (a launch still waiting for its theta is told to give up)
   handle_publish_forward(h);
   bool need_sync = false;
   struct timespec t0;
@@ -214,6 +215,7 @@ extern "C" int asvgp_destroy(asvgp_handle_t handle) {
   if (h->prof_made)
     for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(h->prof_ev[i][0]); (void)hipEventDestroy(h->prof_ev[i][1]); }
   if (h->order_dev) { (void)hipFree(h->order_dev); h->order_dev = nullptr; }
+  if (h->box_host) { (void)hipHostFree(h->box_host); h->box_host = nullptr; h->box_dev = nullptr; }
   h->magic = 0;
   delete h;
   return ASVGP_OK;

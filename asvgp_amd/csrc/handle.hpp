@@ -75,7 +75,14 @@ struct Handle {
   int n_order_seen = 0;
   int* order_dev = nullptr;               // one device word for the probe's count
   int phi_last_series = 0;                // 1: the last tile-sort launch was the time-series instantiation
+  // launch-ahead of the matrix-core ELBO launch (asvgp_elbo_grad_ahead_1d / asvgp_elbo_publish_theta): a pinned ring of theta boxes (one per
+  // table slot) the kernel reads once the host has filled it; `ahead`: the launch that is out and still waits for its theta
+  bool ahead_req = false;                 // set by the entry point around its call into the launcher
+  void* box_host = nullptr;               // TAB_SLOTS x BOX_BYTES, pinned + mapped
+  void* box_dev = nullptr;
+  struct PendingAhead { bool valid; int slot; unsigned long long seq; double* tab; int kind; long N; } ahead = {false, 0, 0, nullptr, 0, 0};
 };
+constexpr size_t BOX_BYTES = 4096;
 
 // Debug / measurement switches from the environment, read ONCE (a getenv per launch costs microseconds where the environment is large)
 // and again on asvgp_debug_reload_env() - the tests that flip them call that.
@@ -106,6 +113,10 @@ void handle_prior_dd_release(Handle* h);
 // seq != 0: on the handle's own stream, concurrently with whatever `st` holds; the kernel then publishes seq in dd_ready[slot] (*ready_out)
 int handle_prior_dd_forward(Handle* h, const double* coef, const double* dcoef, int slot, hipStream_t st, double** tab_out, unsigned long long* stamps = nullptr,
                             unsigned long long seq = 0, const unsigned long long** ready_out = nullptr);
+
+// launch-ahead: fill the pending launch's theta box and publish it, then run the host forward pass for it (elbo.hip, k = 4 unit);
+// withdraw = true: tell the waiting kernel to give up instead (teardown)
+int elbo_publish_theta(Handle* h, double v, double l, double s, bool withdraw);
 
 // next table slot for writing: waits (bounded) until the GPU has consumed the slot's previous table
 double* handle_table_acquire(Handle* h, unsigned long long* seq_out, int* slot_out);

@@ -157,6 +157,7 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         self._post = None
         self._host_result = np.zeros(10)      # [out[0..7], info[0], info[1]] of the last host-read evaluation
         self._mirror_read = lib.asvgp_result_mirror_read
+        self._publish = lib.asvgp_elbo_publish_theta
 
     # ------------------------------------------------------------------------------------------------------
     def _phi_pass_local(self):
@@ -288,6 +289,27 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
             self._mirror = self._h.result_mirror(True)
         self._launch_elbo(theta)
         return self._h.result_mirror_pending()
+
+    def launch_elbo_ahead(self):
+        """Launch-ahead (asvgp_elbo_grad_ahead_1d): enqueue the NEXT evaluation's ELBO + gradient launch on the current stream BEFORE its
+        theta exists; the kernel becomes resident and waits for publish_theta().  Returns the token read_elbo_host() takes, or None when
+        the matrix-core launch does not apply to this model (nothing is launched then: use launch_elbo_host)."""
+        S = self._statics()
+        if getattr(self, "_mirror", None) is None:
+            self._mirror = self._h.result_mirror(True)
+        rc = get_lib().asvgp_elbo_grad_ahead_1d(self._h.ptr, self._stats.data_ptr(), S.data_ptr(), self.kernel.kind, self.num_data, self.basis.m,
+                                                self.bandwidth, self.D, self._out.data_ptr(), self._info.data_ptr(), self._elbo_ws.data_ptr(),
+                                                self._elbo_ws.numel() * 8, stream_ptr())
+        if rc == -2:                               # ASVGP_ERR_UNSUPPORTED
+            return None
+        check(rc, "elbo_grad_ahead_1d")
+        return self._h.result_mirror_pending()
+
+    def publish_theta(self, theta=None):
+        """Second half of launch_elbo_ahead(): hand the waiting launch its (variance, lengthscale, noise variance) - the model's own when
+        theta is None - and run the host forward pass of the prior chain for it."""
+        v, l, s = self.theta() if theta is None else theta
+        check(self._publish(self._h.ptr, v, l, s), "elbo_publish_theta")
 
     def read_elbo_host(self, token, check_pd=True, poll_seconds=0.05):
         """Second half: [e, dv, dl, ds] as Python floats.  token != 0: the launch writes the pinned mirror - asvgp_result_mirror_read polls

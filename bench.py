@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the overlapped schedules (the chain workgroups need free CUs)")
     ap.add_argument("--no-three-sets", action="store_true", help="skip the extra dependent schedule with three buffer sets")
     ap.add_argument("--worker-forward", action="store_true", help="dependent schedules: the host forward pass of the Kuu chain on the handle's worker thread (asvgp_set_deferred_forward_pass(h, 2))")
+    ap.add_argument("--no-launch-ahead", action="store_true", help="dependent schedules: launch the ELBO kernel only once theta is known (round 3's order) instead of ahead of it")
     ap.add_argument("--no-mirror", action="store_true", help="dependent schedule: read results through the stream (D2H copy + sync) instead of the pinned mirror")
     ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
     ap.add_argument("--phase-events", type=int, default=25, help="one-at-a-time schedule: per-phase events on every n-th step (0 = never)")
@@ -391,7 +392,7 @@ def main():
     # of a process took 100-130 us per step instead of 72, its Phi kernel "70 us" - waiting behind the ELBO launch).
     stream_pool = {"n": torch.cuda.Stream(), "m": torch.cuda.Stream(priority=-1), "m2": torch.cuda.Stream(priority=-1)}
 
-    def dependent_schedule(n_sets, n_points=None, prior_forward=0):
+    def dependent_schedule(n_sets, n_points=None, prior_forward=0, launch_ahead_mode=False):
         lanes = [new_model(N, overlapped=True, defer=(n_sets == 2), n_points=n_points, prior_forward=prior_forward) for _ in range(n_sets)]
         if args.worker_forward and not args.no_mirror:
             for ln in lanes:
@@ -413,32 +414,54 @@ def main():
                     dist.all_reduce(lanes[k]._stats, op=dist.ReduceOp.SUM)
             ev_stats[k].record(s_n)
 
+        ahead_ok = launch_ahead_mode and not args.no_launch_ahead and not args.no_mirror and not prior_forward and not args.worker_forward
+        if ahead_ok:
+            for ln in lanes:
+                ln._h.set_deferred_forward_pass(1)                 # publish_theta() fills the box only; publish_forward() runs the pass
+
+        def launch_ahead(k):                                       # the NEXT evaluation's launch, enqueued before its theta exists
+            if not ahead_ok:
+                return None
+            if not ev_stats[k].query():
+                s_m.wait_event(ev_stats[k])
+            _lib.set_stream(s_m)
+            return lanes[k].launch_elbo_ahead()                    # (None: the matrix-core launch does not apply - the ordinary launch follows)
+
         def block(k):
             if not state["primed"]:
                 for j in range(ahead):
                     n_side_kernel((state["i"] + j) % n_sets)
                     n_side_rest((state["i"] + j) % n_sets)
                 state["primed"] = True
-            for _ in range(k):
+            if state.get("tok") is None:                            # (no launch is left waiting across a block boundary: the timed region
+                state["tok"] = launch_ahead(state["i"] % n_sets)    #  ends with a device synchronisation)
+            for it in range(k):
                 i = state["i"]
                 ln, nxt = lanes[i % n_sets], (i + ahead) % n_sets
                 t0 = time.perf_counter()
+                tok = state.get("tok")
+                if tok is not None:
+                    state["n_ahead"] = state.get("n_ahead", 0) + 1
+                    ln.publish_theta(state["theta"])                # the launch is out already (resident, waiting): theta box FIRST (a few us) ...
                 if n_sets == 2:
-                    n_side_kernel(nxt)                              # its buffer set was released by the result just read; needs no theta
+                    n_side_kernel(nxt)                              # ... then the Phi kernel of step i+1 (its buffer set was released by the result just read) ...
+                if tok is not None:
+                    ln._h.publish_forward()                         # ... then the host's long-double forward pass for the waiting Kuu workgroup (~19 us)
                 if args.no_mirror:
                     set_theta(ln, state["theta"])
-                if not ev_stats[i % n_sets].query():                # (complete unless the N side is the slower one: then the launch waits in-stream)
-                    s_m.wait_event(ev_stats[i % n_sets])
-                _lib.set_stream(s_m)
-                if args.no_mirror:
-                    ln._launch_elbo()
-                    tok = None
-                else:
-                    tok = ln.launch_elbo_host(state["theta"])       # (the trial point goes straight into the launch)
+                if tok is None:
+                    if not ev_stats[i % n_sets].query():            # (complete unless the N side is the slower one: then the launch waits in-stream)
+                        s_m.wait_event(ev_stats[i % n_sets])
+                    _lib.set_stream(s_m)
+                    if args.no_mirror:
+                        ln._launch_elbo()
+                    else:
+                        tok = ln.launch_elbo_host(state["theta"])   # (the trial point goes straight into the launch)
                 t1 = time.perf_counter()
                 if n_sets != 2:
                     n_side_kernel(nxt)
                 n_side_rest(nxt)
+                state["tok"] = launch_ahead((i + 1) % n_sets) if it + 1 < k else None   # step i+1's launch: behind step i's kernel and the statistics of its set
                 t2 = time.perf_counter()
                 if tok is None:
                     with torch.cuda.stream(s_m):
@@ -457,7 +480,7 @@ def main():
 
         ms, kern_us, launches = timed_blocks(block, lanes[0]._h)
         n_acc = max(state["n"], 1)
-        out = {"ms": ms, "kern_us": kern_us, "launches": launches, "last": state["last"],
+        out = {"ms": ms, "kern_us": kern_us, "launches": launches, "last": state["last"], "launch_ahead": bool(ahead_ok and state.get("n_ahead", 0) > 0), "ahead_launches": state.get("n_ahead", 0),
                "fallbacks": sum(getattr(ln, "fused_launch_fallbacks", 0) for ln in lanes),
                "host_us": {("phi_kernel_enqueue_theta_and_elbo_launch" if n_sets == 2 else "theta_and_elbo_launch"): state["t_a"] / n_acc * 1e6,
                            ("reduce_and_event_enqueue" if n_sets == 2 else "n_side_enqueue"): state["t_b"] / n_acc * 1e6,
@@ -548,11 +571,16 @@ def main():
         except Exception as exc:
             extras["dependent_steps_all_gpu_error"] = repr(exc)[:300]
             _lib.set_stream(None)
+        try:
+            extras["dependent_steps_launch_ahead"] = dependent_schedule(3, launch_ahead_mode=True)
+        except Exception as exc:
+            extras["dependent_steps_launch_ahead_error"] = repr(exc)[:300]
+            _lib.set_stream(None)
         shards = {}
         for div in tuple(int(v) for v in os.environ.get("ASVGP_BENCH_SHARDS", "2,4,8").split(",")):
             try:
                 npts = (n_local // div) & ~1
-                res = dependent_schedule(2, n_points=npts)
+                res = dependent_schedule(2, n_points=npts, launch_ahead_mode=True)
                 shards[str(div)] = {"res": res, "points": npts}
             except Exception as exc:
                 shards[str(div)] = {"error": repr(exc)[:300]}
@@ -659,6 +687,19 @@ def main():
                         "(prior_dd.hip) instead of the host's x87 long double - no host arithmetic inside the step"}
         if "dependent_steps_all_gpu_error" in extras:
             line["dependent_steps_all_gpu_error"] = extras["dependent_steps_all_gpu_error"]
+        if "dependent_steps_launch_ahead" in extras:
+            ea = extras["dependent_steps_launch_ahead"]
+            asp = spread(ea["ms"])
+            line["dependent_steps_launch_ahead"] = {
+                "value": mp(asp["median"]), "unit": "Mpoints/s", "ms_per_step": asp, "host_us_per_step": ea["host_us"], "launch_ahead_used": ea["launch_ahead"],
+                "fused_launch_fallbacks": ea["fallbacks"], "rel_diff_elbo_vs_fixed_theta": abs(ea["last"][0] - out4[0]) / abs(out4[0]),
+                "note": "the same dependent steps (three buffer sets) with the ELBO + gradient kernel of step i+1 LAUNCHED AHEAD of its theta "
+                        "(asvgp_elbo_grad_ahead_1d): it is resident, waiting on the handle's pinned theta box, when the host has read result i and "
+                        "publishes theta_{i+1} (asvgp_elbo_publish_theta: box first, Phi enqueue, then the host forward pass) - the launch path and "
+                        "dispatch latency leave the critical path; nothing that needs theta is computed earlier.  It pays where the M side bounds the "
+                        "step (sorted input, small shards); on the unsorted headline the N side bounds and the extra host calls cost more than they save"}
+        if "dependent_steps_launch_ahead_error" in extras:
+            line["dependent_steps_launch_ahead_error"] = extras["dependent_steps_launch_ahead_error"]
         if "emulated_shard" in extras:
             es = {}
             for div, e in extras["emulated_shard"].items():
@@ -668,8 +709,9 @@ def main():
                                            "whole_job_value_if_all_ranks_did_this": N / (sp["median"] * 1e-3) / 1e6}
                 else:
                     es["1_of_%s" % div] = e
-            es["note"] = ("the `value` schedule on the first N/2, N/4, N/8 points with the global N in the bound (world size 1, no collective): one "
-                          "rank's step of a 2 / 4 / 8-rank strong-scaling run before any collective latency; not a multi-GPU measurement")
+            es["note"] = ("the `value` schedule (two buffer sets) WITH launch-ahead on the first N/2, N/4, N/8 points with the global N in the bound (world size 1, "
+                          "no collective): one rank's step of a 2 / 4 / 8-rank strong-scaling run before any collective latency; not a multi-GPU "
+                          "measurement (without launch-ahead these read 69-70 us)")
             line["emulated_shard"] = es
         if ind is not None:
             isp = spread(ind["ms"])

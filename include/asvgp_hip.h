@@ -115,6 +115,16 @@ uint64_t asvgp_result_mirror_pending(asvgp_handle_t handle);
  * stream then).  asvgp_elbo_grad_host_1d = asvgp_elbo_grad_1d with the mirror armed + that read: ONE call per optimiser evaluation
  * (example.py:31-32: the next theta depends on this result). */
 int asvgp_result_mirror_read(asvgp_handle_t handle, uint64_t token, double* result10, double timeout_seconds);
+/* Launch-ahead (matrix-core launch only: k = 4, D = 1, M <= 2048, planned prior chain with the host forward pass; else
+ * ASVGP_ERR_UNSUPPORTED and nothing is launched).  An optimiser's evaluations are dependent: theta of the next one comes from this one's
+ * result (example.py:31-32).  asvgp_elbo_grad_ahead_1d enqueues the NEXT evaluation's launch before its theta exists - the kernel becomes
+ * resident and waits (bounded, ASVGP_SPIN_LIMIT) on the handle's pinned theta box - and asvgp_elbo_publish_theta hands it theta (coefficients,
+ * closed-form Kuu tables, the scalars of the bound) and then runs the host forward pass: the launch path and dispatch latency (~8-10 us)
+ * are spent while the host still reads the previous result.  Result: `out` / the result mirror (asvgp_result_mirror_pending after the
+ * ahead call).  One launch may wait per handle; asvgp_destroy withdraws it; a launch whose theta never came gives up (info[1] < 0). */
+int asvgp_elbo_grad_ahead_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, int64_t N, int64_t M, int k,
+                             int64_t D, double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream);
+int asvgp_elbo_publish_theta(asvgp_handle_t handle, double variance, double lengthscale, double noise_variance);
 int asvgp_elbo_grad_host_1d(asvgp_handle_t handle, const double* stats, const double* static_bands, int kind, double variance,
                             double lengthscale, double noise_variance, int64_t N, int64_t M, int k, int64_t D,
                             double* out, int* info, void* workspace, size_t workspace_bytes, asvgp_stream_t stream,

@@ -2,6 +2,7 @@
 Tolerances (SURVEY 8d): indices/structure bit-exact; band/rhs/yy rel 1e-12; ELBO rel 1e-9; gradient rel 1e-6;
 posterior abs 1e-8."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1623,6 +1624,43 @@ def test_fused_launch_that_gives_up_waiting_falls_back_to_the_multi_launch_path(
     model._check_pd(model._launch_elbo)                         # the hook is off again: the retry is the fused launch itself
     assert model.fused_launch_fallbacks == before + 1 and model._h.band_algorithm == 0
     np.testing.assert_allclose(model._out[:4].cpu().numpy(), good, rtol=1e-12)
+
+
+def test_launch_ahead_of_theta_gives_the_ordinary_launch_numbers(A):
+    """asvgp_elbo_grad_ahead_1d / asvgp_elbo_publish_theta (an optimiser's dependent evaluations, example.py:31-32): the launch goes out
+    before its theta exists, waits resident on the handle's pinned theta box and computes the SAME bound and gradient as the ordinary
+    launch once it has it - for several thetas in a row, on the time-series instantiation's statistics too; a model the matrix-core
+    launch does not apply to reports None and launches nothing; a launch left waiting is withdrawn when the handle is closed."""
+    rng = np.random.default_rng(11)
+    N, M = 60000, 2048
+    x = rng.uniform(1e-9, 1 - 1e-9, N)
+    y = (np.sin(20 * x) + 0.1 * rng.normal(size=N)).reshape(-1, 1)
+    model = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B4Spline(0, 1, M))
+    model.likelihood.variance.assign(0.01)
+    for th in ((1.0, 0.05, 0.01), (0.8, 0.03, 0.02), (1.3, 0.08, 0.005)):
+        ref = model.read_elbo_host(model.launch_elbo_host(th))
+        tok = model.launch_elbo_ahead()
+        assert tok                                              # the matrix-core launch applies: a token for the mirror
+        time.sleep(0.002)                                       # the kernel is resident and waiting by now
+        model.publish_theta(th)
+        got = model.read_elbo_host(tok)
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+    ob = O.Basis(4, 0, 1, M)
+    Ab, b, yy = O.sufficient_stats_direct(ob, x, y)
+    ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN32, Ab, b, yy, N, 1.3, 0.08, 0.005)
+    assert abs(got[0] - ee) <= 1e-9 * abs(ee)
+    np.testing.assert_allclose(got[1:4], ge, rtol=1e-6)
+    # a second launch while one waits is refused; closing the handle withdraws the waiting launch (no hang, nothing left on the device)
+    tok = model.launch_elbo_ahead()
+    with pytest.raises(A._lib.AsvgpError):
+        model.launch_elbo_ahead()
+    model.close()
+    torch.cuda.synchronize()
+    # bandwidth 3: no matrix-core launch - nothing is launched ahead
+    m3 = A.GPR_1d((x.reshape(-1, 1), y), A.Matern32(variance=1.0, lengthscales=0.05), A.B3Spline(0, 1, 200))
+    assert m3.launch_elbo_ahead() is None
+    r3 = m3.elbo_and_grad_host()
+    assert np.isfinite(r3).all()
 
 
 def test_host_result_mirror_gives_the_stream_path_numbers(A):
