@@ -70,6 +70,7 @@ SIGNATURES = {
     "asvgp_elbo_data_chain_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _L, _I, _L, _P, _P, _P, _Z, _P]),
     "asvgp_posterior_prepare_1d": (_I, [_P, _P, _P, _I, _D, _D, _D, _L, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "asvgp_predict_1d": (_I, [_P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),
+    "asvgp_predict_1d_h": (_I, [_P, _P, _L, _P, _L, _D, _I, _L, _P, _P, _D, _L, _P, _P, _P]),
     "asvgp_profile_enable": (_I, [_P, _I]),
     "asvgp_profile_read": (_I, [_P, _c.POINTER(_D), _c.POINTER(_L)]),
     "asvgp_kron_stats_doubles": (_Z, [_L, _L, _I]),

@@ -399,6 +399,16 @@ __device__ __forceinline__ void bb_rsqrt(double x, double& inv, double& root) {
   root = g;
 }
 
+__device__ __forceinline__ double bb_rsqrt1(double x) {           // 1/sqrt(x) alone (two Newton steps on v_rsq_f64)
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
+
 // one update C -= L[rows, p] L[c rows, p]^T on the NT row tiles rt = R0 + ST * t of the calling wave
 template <int NT, int ST, bool FAST, bool RHS_ROW>
 __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, double& tacc1, const double* __restrict__ Pb,
@@ -613,6 +623,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       asm volatile("" : "+v"(r));   // opaque per block column: the lane predicates (r == j, r >= cc) below are otherwise hoisted out
                                     // of the column loop as loop invariants - 700 spilled SGPRs, reloaded through v_readlane
       double t = ys[r];
+      double dinv = 1.0;                                // lane j < 32: 1 / L_jj
       int bad = 0;
       double a[16];
 #pragma unroll
@@ -621,15 +632,15 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       for (int j = 0; j < 16; ++j) {
         const double piv = readlane_f64(a[j], j);
         if (!(piv > 0.0) && !bad) bad = j + 1;
-        double inv, ljj;
-        bb_rsqrt(piv, inv, ljj);
-        a[j] = (r == j) ? ljj : a[j] * inv;              // (rows above j hold zeros in column j)
+        const double inv = bb_rsqrt1(piv);
+        if (lane == j) dinv = inv;                        // 1 / L_jj for the inverse below
+        a[j] *= inv;                                      // (lane j: piv / sqrt(piv) = L_jj to an ulp; rows above j carry values nobody reads)
         const double yj = readlane_f64(t, j) * inv;       // forward substitution rides along
-        t = (r == j) ? yj : fma(-a[j], yj, t);
+        t = (r > j) ? fma(-a[j], yj, t) : ((r == j) ? yj : t);
 #pragma unroll
-        for (int cc = j + 1; cc < 16; ++cc) {
+        for (int cc = j + 1; cc < 16; ++cc) {             // no row predicate: the entries above the diagonal are never read (2 v_readlane + 1 FMA)
           const double lcj = readlane_f64(a[j], cc);
-          a[cc] = (r >= cc) ? fma(-a[j], lcj, a[cc]) : a[cc];
+          a[cc] = fma(-a[j], lcj, a[cc]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -656,15 +667,15 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       for (int j = 0; j < 16; ++j) {
         const double piv = readlane_f64(b2[j], 16 + j);
         if (!(piv > 0.0) && !bad) bad = 16 + j + 1;
-        double inv, ljj;
-        bb_rsqrt(piv, inv, ljj);
-        b2[j] = (r == 16 + j) ? ljj : b2[j] * inv;
+        const double inv = bb_rsqrt1(piv);
+        if (lane == 16 + j) dinv = inv;
+        b2[j] *= inv;
         const double yj = readlane_f64(t, 16 + j) * inv;
-        t = (r == 16 + j) ? yj : ((r > 16 + j) ? fma(-b2[j], yj, t) : t);
+        t = (r > 16 + j) ? fma(-b2[j], yj, t) : ((r == 16 + j) ? yj : t);
 #pragma unroll
         for (int cc = j + 1; cc < 16; ++cc) {
           const double lcj = readlane_f64(b2[j], 16 + cc);
-          b2[cc] = (r >= 16 + cc) ? fma(-b2[j], lcj, b2[cc]) : b2[cc];
+          b2[cc] = fma(-b2[j], lcj, b2[cc]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -672,6 +683,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) Ld[r * (BB_NB + 1) + 16 + cc] = (r >= 16 && 16 + cc <= r) ? b2[cc] : 0.0;
         if (rhs && r < nbk) rhs[j0 + r] = t;
+        ys[BB_NB + lane] = dinv;
       }
       if (lane == 0 && bad) atomicCAS(info, 0, (int)(j0 + bad));
       BBP_STAMP(5);
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
         for (int q = 0; q < 16; ++q) x[q] = (q == jj) ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          x[q] = x[q] / Ld[(o + q) * (BB_NB + 1) + o + q];
+          x[q] *= ys[BB_NB + o + q];                      // (the reciprocal pivots of the factorisation: no divisions)
 #pragma unroll
           for (int rr = q + 1; rr < 16; ++rr) x[rr] = fma(-Ld[(o + rr) * (BB_NB + 1) + o + q], x[q], x[rr]);
         }

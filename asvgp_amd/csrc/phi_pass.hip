@@ -555,6 +555,124 @@ __global__ __launch_bounds__(1024) void predict_kernel(const double* __restrict_
   }
 }
 
+// Posterior moments through a per-CELL polynomial table (D == 1, large n*, a mesh that is an exact numpy.linspace).
+// Inside cell c the variance is a polynomial of degree 2k in the centred coordinate s = t - 1/2:
+//   var(s) = v + sum_ij v_i(s) v_j(s) W_ij = sum_p Q_c[p] s^p,   Q_c[p] = [p = 0] v + sum_i pair[i][i][p] W_ii + 2 sum_{i<j} pair[i][j][p] W_ij
+// (pair[i][j][.]: the exact integer-ratio product tables of the Phi pass, phi_tables.hpp).  Every workgroup builds the table of all cells
+// into its LDS straight from band(W) - 15 (k = 4) coalesced reads and 9 x 15 FMAs per cell, ~2 us - next to alpha; a point then costs
+// 2k+1 CONTIGUOUS table doubles (ds_read2_b64) + k+1 of alpha = 8 LDS instructions and 112 B, instead of the 23 scattered 8-byte reads
+// (3 mesh, 15 W, 5 alpha; 184 B) of predict_kernel, and a Horner chain instead of the 15 products.  The cell comes from arithmetic on the
+// verified linspace (no mesh table: at k = 4, M = 2048 the table and alpha fill 163 552 of the 163 840 B); a point within rounding of a
+// knot, outside the mesh, or any point of a mesh that is not that linspace takes the exact table rule against the global mesh.
+// The mean is the sum predict_kernel forms, from the same t.  8 B in, 16 B out per point.
+template <int K> constexpr size_t predict_poly_lds_bytes(int n_mesh, int M) {
+  return sizeof(double) * ((size_t)(n_mesh - 1) * (2 * K + 1) + (size_t)M + 1);
+}
+template <int K>
+__global__ __launch_bounds__(1024) void predict_poly_kernel(const double* __restrict__ xnew, long n, const double* __restrict__ mesh_g, int n_mesh,
+                                                            double inv_delta, int M, const double* __restrict__ alpha_g,
+                                                            const double* __restrict__ W_g, double variance, int pairs_ok,
+                                                            double* __restrict__ mean, double* __restrict__ var) {
+  extern __shared__ double lds[];
+  constexpr int NQ = 2 * K + 1;
+  const int ncells = n_mesh - 1, tid = threadIdx.x;
+  double* Q = lds;                                   // [ncells][NQ]
+  double* alpha = lds + (size_t)ncells * NQ;         // [M]
+  int* flag = reinterpret_cast<int*>(alpha + M);     // != 0: the mesh is not the linspace of its end points
+  if (tid == 0) *flag = 0;
+  typedef double pp_d2 __attribute__((ext_vector_type(2)));
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long nq = n >> 1;
+  long qi = (long)blockIdx.x * blockDim.x + tid;
+  pp_d2 xa = {0.0, 0.0};
+  if (pairs_ok && qi < nq) xa = __builtin_nontemporal_load(reinterpret_cast<const pp_d2*>(xnew) + qi);   // the first pair travels under the table build
+  const double m0 = mesh_g[0], m_last = mesh_g[n_mesh - 1];
+  const double step = (m_last - m0) / (double)(n_mesh - 1);
+  __syncthreads();
+  {
+    bool okm = step > 0.0;
+    for (int i = tid; i < n_mesh - 1; i += blockDim.x) okm = okm && (mesh_g[i] == mq_linspace_knot(i, step, m0));
+    if (!okm) atomicOr(flag, 1);
+  }
+  for (int c = tid; c < ncells; c += blockDim.x) {
+    double w[K + 1][K + 1];
+#pragma unroll
+    for (int i = 0; i <= K; ++i)
+#pragma unroll
+      for (int j = i; j <= K; ++j) w[i][j] = ((i == j) ? 1.0 : 2.0) * W_g[(size_t)(j - i) * M + c + K - j];   // rows c+K-i, c+K-j: W[d = j-i][the smaller row]
+#pragma unroll
+    for (int p = 0; p < NQ; ++p) {
+      double q = (p == 0) ? variance : 0.0;
+#pragma unroll
+      for (int i = 0; i <= K; ++i)
+#pragma unroll
+        for (int j = i; j <= K; ++j) q = fma(MomCoef<K>::tab.pair[i][j][p], w[i][j], q);
+      Q[(size_t)c * NQ + p] = q;
+    }
+  }
+  for (int e = tid; e < M; e += blockDim.x) alpha[e] = alpha_g[e];
+  __syncthreads();
+  const double amax = fabs(m0) > fabs(m_last) ? fabs(m0) : fabs(m_last);
+  const double margin = 16.0 * 2.220446049250313e-16 * amax * inv_delta + 1e-12;     // knot rounding over delta (as launch_phi_sort)
+  const bool regular = (*flag == 0) && margin < 0.125;
+  const double smax_fast = regular ? 0.5 - margin : -1.0;                            // (-1: every point takes the table rule)
+  auto point = [&](double x, double& mo, double& vo) __attribute__((always_inline)) {
+    const double g = floor((x - m0) * inv_delta);
+    int c = __double2int_rz(g);                                                      // (saturating; NaN -> 0)
+    double u0;
+    {
+#pragma clang fp contract(off)
+      const double tk = g * step;                                                    // numpy.linspace's knot: i * step rounded, THEN + start rounded
+      u0 = tk + m0;
+    }
+    double t = (x - u0) * inv_delta;
+    if (!((unsigned)c < (unsigned)ncells && fabs(t - 0.5) <= smax_fast)) {           // rare: the exact table rule (basis.py:58-59), clamped as predict_kernel
+      c = neighbour_index(x, mesh_g, n_mesh, m0, inv_delta);
+      t = (x - mesh_g[c]) * inv_delta;
+    }
+    const double sc = t - 0.5;
+    const double* __restrict__ q = Q + (size_t)c * NQ;
+    double qv[NQ], av[K + 1];
+#pragma unroll
+    for (int p = 0; p < NQ; ++p) qv[p] = q[p];
+#pragma unroll
+    for (int i = 0; i <= K; ++i) av[i] = alpha[c + i];
+    double acc = qv[NQ - 1];
+#pragma unroll
+    for (int p = NQ - 2; p >= 0; --p) acc = fma(acc, sc, qv[p]);
+    vo = acc;
+    double v[K + 1];
+    bspline_pieces<K>(t, v);
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i <= K; ++i) m = fma(v[i], av[K - i], m);                        // row_i = c + K - i, in predict_kernel's order
+    mo = m;
+  };
+  if (pairs_ok) {                                    // 16-byte aligned xnew / mean / var: two points per lane and iteration, the next pair in flight
+    const pp_d2* x2 = reinterpret_cast<const pp_d2*>(xnew);
+    pp_d2* mean2 = reinterpret_cast<pp_d2*>(mean);
+    pp_d2* var2 = reinterpret_cast<pp_d2*>(var);
+    for (; qi < nq; qi += stride) {
+      const double xs0 = xa.x, xs1 = xa.y;
+      if (qi + stride < nq) xa = __builtin_nontemporal_load(x2 + qi + stride);
+      double m0v, v0v, m1v, v1v;
+      point(xs0, m0v, v0v);
+      point(xs1, m1v, v1v);
+      __builtin_nontemporal_store(pp_d2{v0v, v1v}, var2 + qi);
+      __builtin_nontemporal_store(pp_d2{m0v, m1v}, mean2 + qi);
+    }
+    const long pl = 2 * nq + (long)blockIdx.x * blockDim.x + tid;                    // the odd last point
+    if (pl < n) { double mo, vo; point(xnew[pl], mo, vo); var[pl] = vo; mean[pl] = mo; }
+  } else {
+    for (long pi = (long)blockIdx.x * blockDim.x + tid; pi < n; pi += stride) {
+      double mo, vo;
+      point(xnew[pi], mo, vo);
+      var[pi] = vo;
+      mean[pi] = mo;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -925,14 +1043,30 @@ extern "C" int asvgp_phi_evaluate_1d(const double* x, int64_t N, const double* m
 }
 
 template <int K>
-static int launch_predict(const double* xnew, long n, const double* mesh, int n_mesh, double delta, int M,
+static int launch_predict(Handle* h, const double* xnew, long n, const double* mesh, int n_mesh, double delta, int M,
                           const double* alpha, const double* W, double variance, int D, double* mean, double* var,
                           hipStream_t st) {
   size_t lds_bytes = sizeof(double) * ((size_t)(K + 2) * M + n_mesh);
-  int stage = (D == 1 && lds_bytes <= PHI_LDS_BUDGET && n >= 65536) ? 1 : 0;
-  int threads = stage ? 1024 : 256;
   const bool vec4 = (D == 1) && n >= 4 && (((reinterpret_cast<uintptr_t>(xnew) | reinterpret_cast<uintptr_t>(mean) |
                                             reinterpret_cast<uintptr_t>(var)) & 15) == 0);
+  static const int poly_mode = getenv("ASVGP_PREDICT_POLY") ? atoi(getenv("ASVGP_PREDICT_POLY")) : 1;   // (0: the table-read kernel always - diagnostic)
+  const size_t poly_bytes = predict_poly_lds_bytes<K>(n_mesh, M);
+  double lin_step = 0.0;
+  if (h && poly_mode && D == 1 && n >= 262144 && poly_bytes <= 160 * 1024 - 64 && n_mesh >= 2 &&
+      handle_mesh_is_linspace(h, mesh, n_mesh, st, &lin_step, nullptr, nullptr)) {      // (verdict cached per mesh pointer; the kernel re-checks)
+    auto pk = predict_poly_kernel<K>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)poly_bytes);
+    if (e == hipSuccess) {
+      long blocks = ((vec4 ? (n + 1) / 2 : n) + 1023) / 1024;
+      if (blocks > 256) blocks = 256;
+      hipLaunchKernelGGL(pk, dim3((unsigned)blocks), dim3(1024), poly_bytes, st, xnew, n, mesh, n_mesh, 1.0 / delta, M, alpha, W, variance,
+                         vec4 ? 1 : 0, mean, var);
+      return check_launch("predict_1d (cell polynomials)");
+    }
+    (void)hipGetLastError();
+  }
+  int stage = (D == 1 && lds_bytes <= PHI_LDS_BUDGET && n >= 65536) ? 1 : 0;
+  int threads = stage ? 1024 : 256;
   long blocks = ((vec4 ? (n + 1) / 2 : n) + threads - 1) / threads;
   long cap = stage ? 256 : 2048;
   if (blocks > cap) blocks = cap;
@@ -947,7 +1081,7 @@ static int launch_predict(const double* xnew, long n, const double* mesh, int n_
   return check_launch("predict_1d");
 }
 
-extern "C" int asvgp_predict_1d(const double* xnew, int64_t n, const double* mesh, int64_t n_mesh, double delta,
+static int predict_1d_entry(Handle* h, const double* xnew, int64_t n, const double* mesh, int64_t n_mesh, double delta,
                                 int order, int64_t M, const double* alpha, const double* W, double variance,
                                 int64_t D, double* mean, double* var, asvgp_stream_t stream) {
   if (!xnew || !mesh || !alpha || !W || !mean || !var || n < 0 || D < 1 || !(delta > 0.0) || n_mesh != M - order + 1) {
@@ -958,11 +1092,27 @@ extern "C" int asvgp_predict_1d(const double* xnew, int64_t n, const double* mes
   if (n == 0) return ASVGP_OK;
   hipStream_t st = as_stream(stream);
   switch (order) {
-    case 1: return launch_predict<1>(xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
-    case 2: return launch_predict<2>(xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
-    case 3: return launch_predict<3>(xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
-    case 4: return launch_predict<4>(xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
-    case 5: return launch_predict<5>(xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
-    default: return launch_predict<6>(xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
+    case 1: return launch_predict<1>(h, xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
+    case 2: return launch_predict<2>(h, xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
+    case 3: return launch_predict<3>(h, xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
+    case 4: return launch_predict<4>(h, xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
+    case 5: return launch_predict<5>(h, xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
+    default: return launch_predict<6>(h, xnew, n, mesh, (int)n_mesh, delta, (int)M, alpha, W, variance, (int)D, mean, var, st);
   }
+}
+
+extern "C" int asvgp_predict_1d(const double* xnew, int64_t n, const double* mesh, int64_t n_mesh, double delta,
+                                int order, int64_t M, const double* alpha, const double* W, double variance,
+                                int64_t D, double* mean, double* var, asvgp_stream_t stream) {
+  return predict_1d_entry(nullptr, xnew, n, mesh, n_mesh, delta, order, M, alpha, W, variance, D, mean, var, stream);
+}
+
+// The same with the model's handle: the handle remembers whether the mesh is an exact numpy.linspace, which lets large D = 1 batches
+// take the cell-polynomial kernel (predict_poly_kernel).
+extern "C" int asvgp_predict_1d_h(asvgp_handle_t handle, const double* xnew, int64_t n, const double* mesh, int64_t n_mesh, double delta,
+                                  int order, int64_t M, const double* alpha, const double* W, double variance,
+                                  int64_t D, double* mean, double* var, asvgp_stream_t stream) {
+  Handle* h = as_handle(handle);
+  if (!h) { set_error("predict_1d_h: bad handle"); return ASVGP_ERR_BAD_ARG; }
+  return predict_1d_entry(h, xnew, n, mesh, n_mesh, delta, order, M, alpha, W, variance, D, mean, var, stream);
 }

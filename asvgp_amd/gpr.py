@@ -401,9 +401,9 @@ class GPR_1d(_GPModelSurface, _ShardedStats):
         n = x.shape[0]
         mean = torch.empty((n, self.D), dtype=torch.float64, device=x.device)
         var = torch.empty((n, 1), dtype=torch.float64, device=x.device)
-        check(get_lib().asvgp_predict_1d(x.data_ptr(), n, b.mesh.data_ptr(), b.mesh.shape[0], b.delta_np, b.order, b.m,
-                                         alpha.data_ptr(), W.data_ptr(), float(self.kernel.variance), self.D,
-                                         mean.data_ptr(), var.data_ptr(), stream_ptr()), "predict_1d")
+        check(get_lib().asvgp_predict_1d_h(self._h.ptr, x.data_ptr(), n, b.mesh.data_ptr(), b.mesh.shape[0], b.delta_np, b.order, b.m,
+                                           alpha.data_ptr(), W.data_ptr(), float(self.kernel.variance), self.D,
+                                           mean.data_ptr(), var.data_ptr(), stream_ptr()), "predict_1d")
         return mean, var
 
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False, batch=False):

@@ -1391,6 +1391,55 @@ def test_predict_paths_odd_counts_unaligned_and_staged(A, S):
                 np.testing.assert_allclose(var.cpu().numpy()[sub], ov2, rtol=0, atol=1e-8)
 
 
+def test_predict_cell_polynomial_kernel_equals_the_table_kernel_and_the_oracle(A):
+    """predict_poly_kernel (n* >= 262 144, D = 1, exact-linspace mesh): per-cell variance polynomials built in the LDS.  Against the
+    table-read kernel (the same points in chunks below its threshold): means to an ulp, variances to 1e-12 of the prior variance;
+    against the banded oracle on a sample: 1e-8 absolute (the gate of every predict test).  Planted points: on knots, on both ends of
+    the mesh, an ulp either side of a knot.  A float32-linspace mesh (Python-float end points, basis.py:17) must keep to the table
+    kernel and give the same numbers as its own small batches."""
+    rng = np.random.default_rng(21)
+    for order, m, n_data, nstar in ((4, 2048, 200_000, 400_001), (3, 300, 20_000, 262_144), (1, 50, 5_000, 300_000), (5, 128, 20_000, 262_145)):
+        Bs = {1: A.B1Spline, 3: A.B3Spline, 4: A.B4Spline, 5: A.B5Spline}[order]
+        x = rng.uniform(1e-9, 1 - 1e-9, n_data); y = np.sin(20 * x) + 0.1 * rng.standard_normal(n_data)
+        bs = Bs(0, 1, m)
+        kind, Kern = (0, A.Matern12) if order == 1 else (1, A.Matern32)      # (B1 carries the Matern-1/2 bands only, as in the reference)
+        model = A.GPR_1d((dev(x).reshape(-1, 1), dev(y).reshape(-1, 1)), Kern(variance=1.3, lengthscales=0.1), bs)
+        model.likelihood.variance.assign(0.02)
+        xs = rng.uniform(0.0, 1.0, nstar)
+        mesh = bs.mesh_np
+        planted = np.concatenate([mesh[[0, 1, 2, len(mesh) // 2, -2, -1]], np.nextafter(mesh[3:6], 0.0), np.nextafter(mesh[3:6], 1.0)])
+        xs[: len(planted)] = planted
+        xd = dev(xs)
+        mean, var = model.predict_f_device(xd.reshape(-1, 1))
+        assert mean.shape == (nstar, 1) and var.shape == (nstar, 1)
+        # the table kernel on the same points, 50 000 at a time (below both thresholds)
+        mt, vt = [], []
+        for lo in range(0, nstar, 50_000):
+            a_, b_ = model.predict_f_device(xd[lo:lo + 50_000].clone().reshape(-1, 1))
+            mt.append(a_); vt.append(b_)
+        mt, vt = torch.cat(mt), torch.cat(vt)
+        dm = (mean - mt).abs().max().item()                                # (the same sum from the same t; hipcc contracts the two kernels' k = 1 code differently: 1 ulp)
+        assert dm <= 4e-16 * max(1.0, mt.abs().max().item()), "order %d: means differ from the table kernel by %.3e" % (order, dm)
+        dv = (var - vt).abs().max().item()
+        assert dv <= 1e-12 * 1.3, "order %d: variances differ from the table kernel by %.3e" % (order, dv)
+        ob = O.Basis(order, 0, 1, m)
+        Ab, b, yy = O.sufficient_stats_direct(ob, x, y.reshape(-1, 1))
+        sel = np.concatenate([np.arange(len(planted)), rng.integers(0, nstar, 300)])
+        om, ov = O.predict_f_1d_banded(ob, kind, Ab, b, 1.3, 0.1, 0.02, xs[sel].reshape(-1, 1))
+        np.testing.assert_allclose(mean.cpu().numpy()[sel], om, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(var.cpu().numpy()[sel], ov, rtol=0, atol=1e-8)
+        model.close()
+    # float32-linspace mesh: not an exact fp64 linspace - the handle keeps such a mesh on the table kernel
+    x = rng.uniform(-3.4, 10.4, 20_000); y = np.sin(x) + 0.1 * rng.standard_normal(20_000)
+    bs = A.B3Spline(-3.5, 10.5, 100)
+    model = A.GPR_1d((dev(x).reshape(-1, 1), dev(y).reshape(-1, 1)), A.Matern32(variance=0.8, lengthscales=1.0), bs)
+    model.likelihood.variance.assign(0.08)
+    xs = dev(rng.uniform(-3.5, 10.5, 300_000))
+    mean, var = model.predict_f_device(xs.reshape(-1, 1))
+    m2, v2 = model.predict_f_device(xs[:50_000].clone().reshape(-1, 1))
+    assert torch.equal(mean[:50_000], m2) and torch.equal(var[:50_000], v2)
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE headline size
 def test_headline_config_parity_n10m(A):
     """BASELINE.json north star, exactly as bench.py runs it: N = 10M, M = 2048, B4, Matern-3/2, theta = (1, 0.05, 0.01),
