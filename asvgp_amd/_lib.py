@@ -85,6 +85,9 @@ SIGNATURES = {
     "asvgp_blockband_to_blocks": (_I, [_P, _L, _L, _L, _P, _P, _P]),
     "asvgp_kron_grad_terms": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _P, _P]),
     "asvgp_predict_kron2d_var": (_I, [_P, _L, _P, _L, _D, _P, _L, _D, _L, _I, _P, _P, _L, _P, _P]),
+    "asvgp_kron_assemble_twisted": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _D, _L, _L, _L, _L, _L, _P, _P, _P, _P]),
+    "asvgp_kron_grad_terms_twisted": (_I, [_P, _P, _L, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _P, _P]),
+    "asvgp_predict_kron2d_var_twisted": (_I, [_P, _L, _P, _L, _D, _P, _L, _D, _L, _L, _I, _P, _P, _L, _L, _L, _L, _L, _P, _P]),
     "asvgp_phi_cross_workspace_bytes": (_Z, [_L, _L]),
     "asvgp_phi_cross_2d": (_I, [_P, _P, _L, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P, _Z, _P]),
 }

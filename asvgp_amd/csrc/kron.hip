@@ -245,6 +245,52 @@ __global__ void kron_assemble_kernel(const double* __restrict__ K1, const double
   }
 }
 
+// The same P written as the TWO systems of the two-sided ("twisted") factorisation.  The chain of the band Cholesky is strictly
+// sequential in the block columns (512 of them at 128 x 128), so P is split at a separator [h, h + Bb) at least a bandwidth wide:
+//   top system    Pt: `padt` identity columns, then original columns 0 .. h + Bb - 1               (nb Bb columns)
+//   bottom system Pr: `padb` identity columns, then original columns M - 1 down to h (REVERSED)     (nb Bb columns)
+// Each is an ordinary lower band with the separator as its last Bb columns; the two factorisations are independent (they run
+// concurrently, half the chain each) and what couples them is the separator's Schur complement
+//   S = L_ss L_ss^T + J L'_ss L'_ss^T J - P_ss        (L_ss, L'_ss: the last diagonal super-blocks of the two factors, J: reversal),
+// a dense Bb x Bb block factored last.  Entry (r, c), r >= c, of the band goes to Pt[(c + padt) LD + r - c] when r < h + Bb and to
+// Pr[(off - r) LD + r - c] (off = padb + M - 1; reversal swaps the triangle) when c >= h; separator entries go to both.
+__global__ void kron_assemble_twisted_kernel(const double* __restrict__ K1, const double* __restrict__ K2,
+                                             const double* __restrict__ S1, const double* __restrict__ S2,
+                                             const double* __restrict__ Ablk, int k, int m1, int m2, double s, long LD,
+                                             long h, long top_end, long padt, long padb,
+                                             double* __restrict__ Pt, double* __restrict__ Pr, double* __restrict__ trace_out) {
+  __shared__ double scratch[16];
+  const long Mtot = (long)m1 * m2;
+  const int noff = kron_noff(k);
+  const long off = padb + Mtot - 1;
+  double tr = 0.0;
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long)gridDim.x * blockDim.x;
+  for (long u = gtid; u < padt; u += gstride) Pt[u * LD] = 1.0;
+  for (long u = gtid; u < padb; u += gstride) Pr[u * LD] = 1.0;
+  for (long t = gtid; t < Mtot * noff; t += gstride) {
+    const int o = (int)(t / Mtot);
+    const long c = t - (long)o * Mtot;
+    int d1, d2;
+    if (o <= k) { d1 = 0; d2 = o; } else { int q = o - (k + 1); d1 = 1 + q / (2 * k + 1); d2 = q % (2 * k + 1) - k; }
+    const int i1 = (int)(c / m2), i2 = (int)(c - (long)i1 * m2);
+    if (i1 + d1 >= m1 || i2 + d2 < 0 || i2 + d2 >= m2) continue;
+    const double a = Ablk[t];
+    const double kv = K1[(long)d1 * m1 + i1] * band_sym(K2, m2, i2, d2);
+    const long d = (long)d1 * m2 + d2, r = c + d;
+    const double pv = kv + a / s;
+    if (r < top_end) Pt[(c + padt) * LD + d] = pv;
+    if (c >= h) Pr[(off - r) * LD + d] = pv;
+    if (S1) {
+      const double sv = S1[(long)d1 * m1 + i1] * band_sym(S2, m2, i2, d2);
+      tr = fma((o == 0) ? 1.0 : 2.0, sv * a, tr);
+    }
+  }
+  if (trace_out) {
+    double tot = block_sum(tr, scratch);
+    if (threadIdx.x == 0 && tot != 0.0) __hip_atomic_fetch_add(trace_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Blocked band Cholesky, column-major lower band Pb[c*LD + (r-c)], bandwidth bw, block NB.
 // panel kernel (one workgroup): factor the NB x NB diagonal block in LDS, solve the rows below (one thread per row),
@@ -976,11 +1022,26 @@ __device__ __forceinline__ double sig_read(const double* __restrict__ SigD, cons
   const int r = (int)(row - bi * Bb), c = (int)(col - bj * Bb);
   return (bi == bj) ? SigD[bi * per + (long)r * Bb + c] : SigS[bj * per + (long)r * Bb + c];
 }
+// The band-restricted inverse as the selected inverse leaves it.  Plain layout (nb = 0): super-blocks of Bb anchored at column 0.
+// Twisted layout (two-sided factorisation, asvgp_kron_assemble_twisted): two stacks of nb super-blocks, SigD [2][nb][Bb][Bb] and
+// SigS [2][nb-1][Bb][Bb].  Stack 0 holds the TOP system - original columns [0, top_end) shifted down by `padt` identity columns, the
+// separator [top_end - Bb, top_end) its last block; stack 1 the BOTTOM system in reversed order - system index u <-> original column
+// off - u - whose last block is the same separator.  An entry with row < top_end is read from stack 0, any other from stack 1 (both
+// of its indices are then >= top_end - Bb, i.e. inside the bottom system: the separator is at least a bandwidth wide).
+struct SigView {
+  const double* D; const double* S; int Bb; long nb, top_end, padt, off;
+  __device__ __forceinline__ double at(long row, long col) const {
+    if (nb == 0) return sig_read(D, S, Bb, row, col);
+    const long per = (long)Bb * Bb;
+    if (row < top_end) return sig_read(D, S, Bb, row + padt, col + padt);
+    return sig_read(D + nb * per, S + (nb - 1) * per, Bb, off - col, off - row);      // reversal swaps the triangle: (row, col) -> (off - col, off - row)
+  }
+};
 
 // 11 contractions over the block band (full symmetric sums: off-diagonal entries count twice):
 //  0 tr(Sig A)  1 a^T A a  2 tr(Sig X1) 3 a^T X1 a  4 tr(Sig X2) 5 a^T X2 a  6 tr(Sig Kuu) 7 a^T Kuu a
 //  8 tr((Z1 (x) S2) A)  9 tr((S1 (x) Z2) A)  10 tr((S1 (x) S2) A)      X1 = dK1 (x) K2,  X2 = K1 (x) dK2
-__global__ void kron_grad_terms_kernel(const double* __restrict__ SigD, const double* __restrict__ SigS, int Bb,
+__global__ void kron_grad_terms_kernel(SigView sig,
                                        const double* __restrict__ alpha, const double* __restrict__ Ablk,
                                        const double* __restrict__ K1, const double* __restrict__ K2,
                                        const double* __restrict__ dK1, const double* __restrict__ dK2,
@@ -1003,7 +1064,7 @@ __global__ void kron_grad_terms_kernel(const double* __restrict__ SigD, const do
     const long row = c + (long)d1 * m2 + d2;
     const double w = (o == 0) ? 1.0 : 2.0;
     const double a = Ablk[t];
-    const double sg = sig_read(SigD, SigS, Bb, row, c);
+    const double sg = sig.at(row, c);
     const double aa = alpha[row] * alpha[c];
     const double k1 = K1[(long)d1 * m1 + i1], k2 = band_sym(K2, m2, i2, d2);
     const double x1 = dK1[(long)d1 * m1 + i1] * k2, x2 = k1 * band_sym(dK2, m2, i2, d2), ku = k1 * k2;
@@ -1032,8 +1093,7 @@ __global__ void kron_grad_terms_kernel(const double* __restrict__ SigD, const do
 template <int K>
 __global__ void predict_kron2d_var_kernel(const double* __restrict__ X, long n, const double* __restrict__ mesh1, int n1,
                                           double id1, const double* __restrict__ mesh2, int n2, double id2, int m2,
-                                          const double* __restrict__ SigD, const double* __restrict__ SigS, int Bb,
-                                          double* __restrict__ qp) {
+                                          SigView sig, double* __restrict__ qp) {
   long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const double2 xv = *reinterpret_cast<const double2*>(X + 2 * p);
@@ -1055,7 +1115,7 @@ __global__ void predict_kron2d_var_kernel(const double* __restrict__ X, long n, 
         for (int b2 = 0; b2 <= K; ++b2) {
           const long rb = (long)(i1 + K - a2) * m2 + (i2 + K - b2);
           if (rb > ra) continue;   // lower triangle, doubled below
-          const double sg = sig_read(SigD, SigS, Bb, ra, rb);
+          const double sg = sig.at(ra, rb);
           q = fma((rb == ra ? 1.0 : 2.0) * wa * v1[a2] * v2[b2], sg, q);
         }
     }
@@ -1143,6 +1203,33 @@ extern "C" int asvgp_kron_assemble(const double* K1, const double* K2, const dou
   hipLaunchKernelGGL(kron_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, K1, K2, trace_out ? S1 : nullptr, S2,
                      Ablk, k, (int)m1, (int)m2, noise_variance, LD, Pb, trace_out);
   return check_launch("kron_assemble");
+}
+
+static bool twist_ok(int64_t M, int64_t Bb, int64_t nb, int64_t top_end, int64_t padt, int64_t padb);
+
+// P as the two systems of the two-sided factorisation (kron_assemble_twisted_kernel): Pt and Pr, each (nb Bb) x (bw + 1) doubles.
+// top_end = h + Bb (end of the separator), padt = nb Bb - top_end, padb = nb Bb - (M - h).
+extern "C" int asvgp_kron_assemble_twisted(const double* K1, const double* K2, const double* S1, const double* S2,
+                                           const double* Ablk, int k, int64_t m1, int64_t m2, double noise_variance, int64_t Bb, int64_t nb,
+                                           int64_t top_end, int64_t padt, int64_t padb, double* Pt, double* Pr, double* trace_out,
+                                           asvgp_stream_t stream) {
+  if (!K1 || !K2 || !Ablk || k < 1 || k > ASVGP_MAX_ORDER || m1 < 1 || m2 < 1 || !(noise_variance > 0) || !Pt || !Pr ||
+      (trace_out && (!S1 || !S2)) || Bb < (int64_t)k * m2 + k || !twist_ok(m1 * m2, Bb, nb, top_end, padt, padb)) {
+    set_error("kron_assemble_twisted: bad argument");
+    return ASVGP_ERR_BAD_ARG;
+  }
+  hipStream_t st = as_stream(stream);
+  const long LD = (long)k * m2 + k + 1, Ms = (long)nb * Bb;
+  hipError_t e = hipMemsetAsync(Pt, 0, sizeof(double) * Ms * LD, st);
+  if (e == hipSuccess) e = hipMemsetAsync(Pr, 0, sizeof(double) * Ms * LD, st);
+  if (e == hipSuccess && trace_out) e = hipMemsetAsync(trace_out, 0, sizeof(double), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+  long total = (long)m1 * m2 * kron_noff(k);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(kron_assemble_twisted_kernel, dim3((unsigned)blocks), dim3(256), 0, st, K1, K2, trace_out ? S1 : nullptr, S2,
+                     Ablk, k, (int)m1, (int)m2, noise_variance, LD, (long)(top_end - Bb), (long)top_end, (long)padt, (long)padb, Pt, Pr, trace_out);
+  return check_launch("kron_assemble_twisted");
 }
 
 extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, double* rhs, double* logdet, int* info,
@@ -1241,37 +1328,73 @@ extern "C" int asvgp_blockband_to_blocks(const double* Lb, int64_t M, int64_t bw
   return check_launch("blockband_to_blocks");
 }
 
-extern "C" int asvgp_kron_grad_terms(const double* SigD, const double* SigS, int64_t Bb, const double* alpha,
-                                     const double* Ablk, const double* K1, const double* K2, const double* dK1,
-                                     const double* dK2, const double* S1, const double* S2, const double* Z1,
-                                     const double* Z2, int k, int64_t m1, int64_t m2, double* out11, asvgp_stream_t stream) {
-  if (!SigD || !alpha || !Ablk || !K1 || !K2 || !dK1 || !dK2 || !S1 || !S2 || !Z1 || !Z2 || !out11 || k < 1 || k > ASVGP_MAX_ORDER ||
-      m1 < 1 || m2 < 1 || Bb < (int64_t)k * m2 + k) { set_error("kron_grad_terms: bad argument"); return ASVGP_ERR_BAD_ARG; }
-  if (((m1 * m2 + Bb - 1) / Bb) > 1 && !SigS) { set_error("kron_grad_terms: SigS is null"); return ASVGP_ERR_BAD_ARG; }
+static int kron_grad_terms_entry(SigView sig, const double* alpha,
+                                 const double* Ablk, const double* K1, const double* K2, const double* dK1,
+                                 const double* dK2, const double* S1, const double* S2, const double* Z1,
+                                 const double* Z2, int k, int64_t m1, int64_t m2, double* out11, asvgp_stream_t stream) {
+  if (!sig.D || !alpha || !Ablk || !K1 || !K2 || !dK1 || !dK2 || !S1 || !S2 || !Z1 || !Z2 || !out11 || k < 1 || k > ASVGP_MAX_ORDER ||
+      m1 < 1 || m2 < 1 || sig.Bb < (int64_t)k * m2 + k) { set_error("kron_grad_terms: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  if ((sig.nb > 1 || ((m1 * m2 + sig.Bb - 1) / sig.Bb) > 1) && !sig.S) { set_error("kron_grad_terms: SigS is null"); return ASVGP_ERR_BAD_ARG; }
   hipStream_t st = as_stream(stream);
   hipError_t e = hipMemsetAsync(out11, 0, 11 * sizeof(double), st);
   if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
   const long total = (long)m1 * m2 * kron_noff(k);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(kron_grad_terms_kernel, dim3((unsigned)blocks), dim3(256), 0, st, SigD, SigS, (int)Bb, alpha, Ablk, K1, K2,
+  hipLaunchKernelGGL(kron_grad_terms_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sig, alpha, Ablk, K1, K2,
                      dK1, dK2, S1, S2, Z1, Z2, k, (int)m1, (int)m2, out11);
   return check_launch("kron_grad_terms");
+}
+
+extern "C" int asvgp_kron_grad_terms(const double* SigD, const double* SigS, int64_t Bb, const double* alpha,
+                                     const double* Ablk, const double* K1, const double* K2, const double* dK1,
+                                     const double* dK2, const double* S1, const double* S2, const double* Z1,
+                                     const double* Z2, int k, int64_t m1, int64_t m2, double* out11, asvgp_stream_t stream) {
+  return kron_grad_terms_entry(SigView{SigD, SigS, (int)Bb, 0, 0, 0, 0}, alpha, Ablk, K1, K2, dK1, dK2, S1, S2, Z1, Z2, k, m1, m2, out11, stream);
+}
+
+static bool twist_ok(int64_t M, int64_t Bb, int64_t nb, int64_t top_end, int64_t padt, int64_t padb) {
+  return nb >= 2 && top_end >= Bb && top_end <= M && padt >= 0 && padb >= 0 && top_end + padt == nb * Bb && (M - (top_end - Bb)) + padb == nb * Bb;
+}
+
+extern "C" int asvgp_kron_grad_terms_twisted(const double* SigD, const double* SigS, int64_t Bb, int64_t nb, int64_t top_end, int64_t padt,
+                                             int64_t padb, const double* alpha,
+                                             const double* Ablk, const double* K1, const double* K2, const double* dK1,
+                                             const double* dK2, const double* S1, const double* S2, const double* Z1,
+                                             const double* Z2, int k, int64_t m1, int64_t m2, double* out11, asvgp_stream_t stream) {
+  if (!twist_ok(m1 * m2, Bb, nb, top_end, padt, padb)) { set_error("kron_grad_terms_twisted: inconsistent layout"); return ASVGP_ERR_BAD_ARG; }
+  return kron_grad_terms_entry(SigView{SigD, SigS, (int)Bb, (long)nb, (long)top_end, (long)padt, (long)(padb + m1 * m2 - 1)}, alpha, Ablk, K1, K2, dK1, dK2,
+                               S1, S2, Z1, Z2, k, m1, m2, out11, stream);
+}
+
+static int predict_kron2d_var_entry(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
+                                    const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                    SigView sig, double* qp, asvgp_stream_t stream) {
+  if ((n > 0 && !Xnew) || !mesh1 || !mesh2 || !sig.D || !qp || n < 0 || order < 1 || order > ASVGP_MAX_ORDER ||
+      sig.Bb < (int64_t)order * m2 + order) { set_error("predict_kron2d_var: bad argument"); return ASVGP_ERR_BAD_ARG; }
+  if (n == 0) return ASVGP_OK;
+  if ((reinterpret_cast<uintptr_t>(Xnew) & 15) != 0) { set_error("predict_kron2d_var: Xnew must be 16-byte aligned (n,2) row-major"); return ASVGP_ERR_BAD_ARG; }
+  hipStream_t st = as_stream(stream);
+  KRON_DISPATCH(order, hipLaunchKernelGGL(predict_kron2d_var_kernel<K>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, Xnew,
+                                          (long)n, mesh1, (int)n_mesh1, 1.0 / delta1, mesh2, (int)n_mesh2, 1.0 / delta2, (int)m2,
+                                          sig, qp));
+  return check_launch("predict_kron2d_var");
 }
 
 extern "C" int asvgp_predict_kron2d_var(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
                                         const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
                                         const double* SigD, const double* SigS, int64_t Bb, double* qp,
                                         asvgp_stream_t stream) {
-  if ((n > 0 && !Xnew) || !mesh1 || !mesh2 || !SigD || !qp || n < 0 || order < 1 || order > ASVGP_MAX_ORDER ||
-      Bb < (int64_t)order * m2 + order) { set_error("predict_kron2d_var: bad argument"); return ASVGP_ERR_BAD_ARG; }
-  if (n == 0) return ASVGP_OK;
-  if ((reinterpret_cast<uintptr_t>(Xnew) & 15) != 0) { set_error("predict_kron2d_var: Xnew must be 16-byte aligned (n,2) row-major"); return ASVGP_ERR_BAD_ARG; }
-  hipStream_t st = as_stream(stream);
-  KRON_DISPATCH(order, hipLaunchKernelGGL(predict_kron2d_var_kernel<K>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, Xnew,
-                                          (long)n, mesh1, (int)n_mesh1, 1.0 / delta1, mesh2, (int)n_mesh2, 1.0 / delta2, (int)m2,
-                                          SigD, SigS, (int)Bb, qp));
-  return check_launch("predict_kron2d_var");
+  return predict_kron2d_var_entry(Xnew, n, mesh1, n_mesh1, delta1, mesh2, n_mesh2, delta2, m2, order, SigView{SigD, SigS, (int)Bb, 0, 0, 0, 0}, qp, stream);
+}
+
+extern "C" int asvgp_predict_kron2d_var_twisted(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
+                                                const double* mesh2, int64_t n_mesh2, double delta2, int64_t m1, int64_t m2, int order,
+                                                const double* SigD, const double* SigS, int64_t Bb, int64_t nb, int64_t top_end,
+                                                int64_t padt, int64_t padb, double* qp, asvgp_stream_t stream) {
+  if (!twist_ok(m1 * m2, Bb, nb, top_end, padt, padb)) { set_error("predict_kron2d_var_twisted: inconsistent layout"); return ASVGP_ERR_BAD_ARG; }
+  return predict_kron2d_var_entry(Xnew, n, mesh1, n_mesh1, delta1, mesh2, n_mesh2, delta2, m2, order,
+                                  SigView{SigD, SigS, (int)Bb, (long)nb, (long)top_end, (long)padt, (long)(padb + m1 * m2 - 1)}, qp, stream);
 }
 
 extern "C" int asvgp_kron_cell_index(const double* X, int64_t N, const double* mesh1, int64_t n_mesh1, double delta1,

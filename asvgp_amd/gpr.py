@@ -7,6 +7,7 @@ Additions (not in the reference): elbo_and_grad() (analytic gradient, replacing 
 banded_matrices op gradients), fit() (L-BFGS-B driver, replacing gpflow.optimizers.Scipy), process_group= for
 N-sharded construction over RCCL.
 """
+import ctypes
 import math
 import time
 
@@ -663,6 +664,22 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
     def theta(self):
         return [(float(k.variance), float(k.lengthscales)) for k in self.kernels], float(self.likelihood.variance)
 
+    twisted = None            # None: two-sided factorisation when P has >= 6 super-blocks; False / True force it off / on (>= 3 blocks per side)
+
+    def _twist_layout(self):
+        """Separator and padding of the two-sided factorisation (asvgp_kron_assemble_twisted), or None for the one-sided band Cholesky."""
+        m2, k, M = self.bases[1].m, self.order, self.Mtot
+        bw = k * m2 + k
+        Bb = ((max(bw, 1) + 31) // 32) * 32
+        nb = -(-(M + Bb) // (2 * Bb))
+        if self.twisted is False or nb < 3 or (self.twisted is None and -(-M // Bb) < 6):
+            return None
+        padt = (2 * nb * Bb - Bb - M) // 2
+        top_end = nb * Bb - padt
+        h = top_end - Bb
+        padb = nb * Bb - (M - h)
+        return dict(Bb=Bb, nb=nb, top_end=top_end, h=h, padt=padt, padb=padb, bw=bw)
+
     def _factor(self, want_alpha):
         """Kuu factors per dimension, trace term, wide-band Cholesky of P with the rhs riding along."""
         from . import banded
@@ -682,6 +699,9 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         logdet_K = m2 * lds[0][0] + m1 * lds[1][0]
         bw = k * m2 + k
         dev = self._stats.device
+        lay = self._twist_layout()
+        if lay is not None:
+            return self._factor_twisted(lay, dict(Ks=Ks, dKs=dKs, Ss=Ss, dSs=dSs, logdet_K=logdet_K, s=s, bw=bw))
         Pb = torch.empty(self.Mtot * (bw + 1), dtype=torch.float64, device=dev)
         tr = torch.zeros(1, dtype=torch.float64, device=dev)
         check(lib.asvgp_kron_assemble(Ks[0].data_ptr(), Ks[1].data_ptr(), Ss[0].data_ptr(), Ss[1].data_ptr(),
@@ -702,8 +722,79 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
             check(lib.asvgp_blockband_backsolve(Pb.data_ptr(), self.Mtot, bw, alpha.data_ptr(), stream_ptr()),
                   "blockband_backsolve")
             alpha = alpha / s
-        return dict(Ks=Ks, dKs=dKs, Ss=Ss, dSs=dSs, logdet_K=logdet_K, logdet_P=logdet_P[0], trace=tr[0], c=c / s, Lb=Pb, bw=bw,
-                    alpha=alpha, s=s)
+        return dict(Ks=Ks, dKs=dKs, Ss=Ss, dSs=dSs, logdet_K=logdet_K, logdet_P=logdet_P[0], trace=tr[0], c=c / s, cc=((c / s) ** 2).sum(),
+                    Lb=Pb, bw=bw, alpha=alpha, s=s)
+
+    def _factor_twisted(self, lay, f):
+        """Two-sided band Cholesky of P (include/asvgp_hip.h, asvgp_kron_assemble_twisted): the top system and the reversed bottom system
+        are factored concurrently on two streams - half the sequential chain each - and meet in the separator's Schur complement
+        S = L_ss L_ss^T + J L'_ss L'_ss^T J - P_ss, a dense Bb x Bb block factored last by the same band kernel (bw = Bb - 1).
+        log|P| = interior pivots of both + log|S|;  c^T P^-1 c = |y_top|^2 + |y_bottom|^2 + |L_S^-1 r_s|^2 with
+        r_s = L_ss y_s + J L'_ss y'_s - c_s (each one-sided sweep has already subtracted its half from c_s)."""
+        lib = get_lib()
+        b1, b2 = self.bases
+        m1, m2, k = b1.m, b2.m, self.order
+        s, bw = f["s"], f["bw"]
+        Bb, nb, top_end, h, padt, padb = lay["Bb"], lay["nb"], lay["top_end"], lay["h"], lay["padt"], lay["padb"]
+        dev = self._stats.device
+        M, Ms, LD = self.Mtot, nb * Bb, bw + 1
+        f64 = dict(dtype=torch.float64, device=dev)
+        Pt, Pr = torch.empty(Ms * LD, **f64), torch.empty(Ms * LD, **f64)
+        tr = torch.zeros(1, **f64)
+        check(lib.asvgp_kron_assemble_twisted(f["Ks"][0].data_ptr(), f["Ks"][1].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(),
+                                              self.KufKfu_blockband.data_ptr(), k, m1, m2, s, Bb, nb, top_end, padt, padb,
+                                              Pt.data_ptr(), Pr.data_ptr(), tr.data_ptr(), stream_ptr()), "kron_assemble_twisted")
+        cache = getattr(self, "_twist_cache", None)
+        if cache is None or cache["key"] != (Bb, nb, bw):
+            r = torch.arange(Bb, device=dev).view(-1, 1).expand(Bb, Bb)
+            c = torch.arange(Bb, device=dev).view(1, -1).expand(Bb, Bb)
+            low = (r >= c) & (r - c <= bw)
+            idx_ss = torch.where(low, (Ms - Bb + c) * LD + (r - c), torch.zeros_like(r))     # P_ss[r, c] inside the top band
+            cc_, dd_ = torch.arange(Bb, device=dev).view(-1, 1).expand(Bb, Bb), torch.arange(Bb, device=dev).view(1, -1).expand(Bb, Bb)
+            inside = cc_ + dd_ < Bb
+            idx_pack = torch.where(inside, (cc_ + dd_) * Bb + cc_, torch.zeros_like(cc_))   # band slot (column cc, offset dd) <- S[cc + dd, cc]
+            cache = self._twist_cache = dict(key=(Bb, nb, bw), low=low, idx_ss=idx_ss, inside=inside, idx_pack=idx_pack,
+                                             eye=torch.eye(Bb, **f64), side=torch.cuda.Stream(device=dev),
+                                             info=torch.zeros(3, dtype=torch.int32, device=dev))
+        Pss = torch.where(cache["low"], Pt[cache["idx_ss"]], torch.zeros((), **f64))
+        Pss = Pss + Pss.t() - torch.diag(torch.diagonal(Pss))
+        c_full = self.Kuf_y.reshape(-1)
+        ct, cr = torch.zeros(Ms, **f64), torch.zeros(Ms, **f64)
+        ct[padt:] = c_full[:top_end]
+        cr[padb:] = c_full[h:].flip(0)
+        info = cache["info"]
+        cur, side = torch.cuda.current_stream(dev), cache["side"]
+        side.wait_stream(cur)
+        check(lib.asvgp_blockband_cholesky(Pt.data_ptr(), Ms, bw, ct.data_ptr(), None, info.data_ptr(), stream_ptr()), "blockband_cholesky (top)")
+        check(lib.asvgp_blockband_cholesky(Pr.data_ptr(), Ms, bw, cr.data_ptr(), None, info[1:].data_ptr(), ctypes.c_void_p(side.cuda_stream)),
+              "blockband_cholesky (bottom)")
+        cur.wait_stream(side)
+        blocks = torch.empty((2, 2 * nb - 1, Bb, Bb), **f64)
+        diag, sub = blocks[:, :nb], blocks[:, nb:]
+        for i, Lb in enumerate((Pt, Pr)):
+            check(lib.asvgp_blockband_to_blocks(Lb.data_ptr(), Ms, bw, Bb, diag[i].data_ptr(), sub[i].data_ptr(), stream_ptr()), "blockband_to_blocks")
+        Lss, Lrs = diag[0, nb - 1], diag[1, nb - 1]
+        S = Lss @ Lss.t() + (Lrs @ Lrs.t()).flip(0, 1) - Pss
+        r_s = Lss @ ct[Ms - Bb:] + (Lrs @ cr[Ms - Bb:]).flip(0) - c_full[h:top_end]
+        Sb = torch.where(cache["inside"], S.reshape(-1)[cache["idx_pack"]], torch.zeros((), **f64)).reshape(-1).contiguous()
+        y_S = r_s.clone()
+        ld_S = torch.zeros(1, **f64)
+        check(lib.asvgp_blockband_cholesky(Sb.data_ptr(), Bb, Bb - 1, y_S.data_ptr(), ld_S.data_ptr(), info[2:].data_ptr(), stream_ptr()),
+              "blockband_cholesky (separator)")
+        L_S = torch.empty((2, Bb, Bb), **f64)                        # ([1]: the unused sub-diagonal slot of a one-block unpack)
+        check(lib.asvgp_blockband_to_blocks(Sb.data_ptr(), Bb, Bb - 1, Bb, L_S[0].data_ptr(), L_S[1].data_ptr(), stream_ptr()), "blockband_to_blocks")
+        codes = info.tolist()
+        if min(codes) < 0:
+            raise AsvgpError("blockband_cholesky gave up waiting for a block column (its workgroup never became resident): results discarded")
+        if any(codes):
+            where = ("top system, column %d" % (codes[0] - 1 - padt)) if codes[0] else (("bottom system (reversed), column %d" % (codes[1] - 1 - padb)) if codes[1]
+                                                                                    else "separator, column %d" % (h + codes[2] - 1))
+            raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite (%s)" % where)
+        Ptv, Prv = Pt.view(Ms, LD), Pr.view(Ms, LD)
+        logdet_P = 2.0 * (torch.log(Ptv[:Ms - Bb, 0]).sum() + torch.log(Prv[:Ms - Bb, 0]).sum()) + ld_S[0]
+        cc = ((ct[:Ms - Bb] ** 2).sum() + (cr[:Ms - Bb] ** 2).sum() + (y_S ** 2).sum()) / s ** 2
+        f.update(logdet_P=logdet_P, trace=tr[0], cc=cc, alpha=None, twist=lay, diag=diag, sub=sub, L_S=L_S[0], y_top=ct, y_bot=cr, y_S=y_S)
+        return f
 
     def elbo(self):
         """gpr.py:282-308."""
@@ -717,7 +808,7 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
             vprod *= float(kern.variance)                    # gpr.py:284: prod of K_diag
         elbo = -0.5 * N * math.log(2 * math.pi * s)
         elbo = elbo - 0.5 * f["logdet_P"] + 0.5 * f["logdet_K"] - 0.5 * self.tr_yTy / s
-        elbo = elbo + 0.5 * (f["c"] ** 2).sum() - 0.5 * N * vprod / s + 0.5 * f["trace"] / s
+        elbo = elbo + 0.5 * f["cc"] - 0.5 * N * vprod / s + 0.5 * f["trace"] / s
         return elbo
 
     def maximum_log_likelihood_objective(self):
@@ -738,6 +829,8 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         TRSM / GEMM): SigD[i] = Sigma_ii, SigS[i] = Sigma_{i+1,i}, block size Bb = bw rounded up to a multiple of 32."""
         lib = get_lib()
         dev = self._stats.device
+        if f.get("twist") is not None:
+            return self._selinv_twisted(f)
         bw, M = f["bw"], self.Mtot
         Bb = ((max(bw, 1) + 31) // 32) * 32
         nblk = (M + Bb - 1) // Bb
@@ -766,6 +859,52 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
             f["alpha"] = ab.reshape(-1)[:M].contiguous()
         return SigD, SigS, Bb
 
+    def _selinv_twisted(self, f):
+        """The same recursion run OUTWARDS from the separator in both systems at once (batch of two): Sigma_ss = S^-1 seeds the top
+        stack, its reversal the bottom stack; nb - 1 dependent steps instead of ceil(M / Bb) - 1.  alpha = P^-1 c / s likewise."""
+        lay, s, M = f["twist"], f["s"], self.Mtot
+        Bb, nb, top_end, padt, padb = lay["Bb"], lay["nb"], lay["top_end"], lay["padt"], lay["padb"]
+        diag, sub = f["diag"], f["sub"]
+        eye = self._twist_cache["eye"]
+        Linv = torch.linalg.solve_triangular(diag[:, :nb - 1], eye.expand(2, nb - 1, Bb, Bb), upper=False)
+        Dinv = Linv.transpose(-1, -2) @ Linv
+        G = sub @ Linv                                            # G_i = L_{i+1,i} L_ii^-1
+        LSinv = torch.linalg.solve_triangular(f["L_S"], eye, upper=False)
+        Sig_ss = LSinv.t() @ LSinv
+        SigD = torch.empty((2, nb, Bb, Bb), dtype=torch.float64, device=diag.device)
+        SigS = torch.empty((2, nb - 1, Bb, Bb), dtype=torch.float64, device=diag.device)
+        SigD[0, nb - 1] = Sig_ss
+        SigD[1, nb - 1] = Sig_ss.flip(0, 1)
+        a_s = LSinv.t() @ (f["y_S"] / s)
+        yb = torch.stack((f["y_top"], f["y_bot"])).view(2, nb, Bb) / s
+        ab = torch.empty_like(yb)
+        ab[0, nb - 1] = a_s
+        ab[1, nb - 1] = a_s.flip(0)
+        for i in range(nb - 2, -1, -1):
+            SigS[:, i] = -(SigD[:, i + 1] @ G[:, i])
+            SigD[:, i] = Dinv[:, i] - G[:, i].transpose(-1, -2) @ SigS[:, i]
+            t = yb[:, i] - (sub[:, i].transpose(-1, -2) @ ab[:, i + 1].unsqueeze(-1)).squeeze(-1)
+            ab[:, i] = (Linv[:, i].transpose(-1, -2) @ t.unsqueeze(-1)).squeeze(-1)
+        alpha = torch.empty(M, dtype=torch.float64, device=diag.device)
+        alpha[:top_end] = ab[0].reshape(-1)[padt:]
+        alpha[top_end:] = ab[1].reshape(-1)[padb:padb + (M - top_end)].flip(0)
+        f["alpha"] = alpha
+        return SigD, SigS, Bb
+
+    def _grad_terms(self, f, SigD, SigS, Bb, Zs, out):
+        lib = get_lib()
+        b1, b2 = self.bases
+        dKs = f["dKs"]
+        tail = (f["alpha"].data_ptr(), self.KufKfu_blockband.data_ptr(), f["Ks"][0].data_ptr(), f["Ks"][1].data_ptr(),
+                dKs[0].data_ptr(), dKs[1].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(),
+                Zs[0].data_ptr(), Zs[1].data_ptr(), self.order, b1.m, b2.m, out.data_ptr(), stream_ptr())
+        lay = f.get("twist")
+        if lay is None:
+            check(lib.asvgp_kron_grad_terms(SigD.data_ptr(), SigS.data_ptr(), Bb, *tail), "kron_grad_terms")
+        else:
+            check(lib.asvgp_kron_grad_terms_twisted(SigD.data_ptr(), SigS.data_ptr(), Bb, lay["nb"], lay["top_end"], lay["padt"], lay["padb"], *tail),
+                  "kron_grad_terms_twisted")
+
     def elbo_and_grad(self):
         """(elbo, d elbo / d [v1, l1, v2, l2, sigma2]) - the gradient TF autodiff gives the reference (eNATL60.py:89), here
         analytic: tr(P^-1 dKuu), alpha^T dKuu alpha and tr(Kuu^-1 dKuu Kuu^-1 A) contracted over the block band
@@ -784,14 +923,10 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         Zs = [-dS for dS in f["dSs"]]                           # band(K^-1 dK K^-1) = -d band(K^-1)/dl: the exact tangent of the 1-D chain
         out = torch.empty(11, dtype=torch.float64, device=self._stats.device)
         b1, b2 = self.bases
-        check(lib.asvgp_kron_grad_terms(SigD.data_ptr(), SigS.data_ptr(), Bb, f["alpha"].data_ptr(),
-                                        self.KufKfu_blockband.data_ptr(), f["Ks"][0].data_ptr(), f["Ks"][1].data_ptr(),
-                                        dKs[0].data_ptr(), dKs[1].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(),
-                                        Zs[0].data_ptr(), Zs[1].data_ptr(), self.order, b1.m, b2.m, out.data_ptr(),
-                                        stream_ptr()), "kron_grad_terms")
+        self._grad_terms(f, SigD, SigS, Bb, Zs, out)
         tPA, aAa, tPX1, aX1a, tPX2, aX2a, tPK, aKa, tZ1A, tZ2A, tSA = out.tolist()
         trK = [float(banded.band_trace_sym(S, dK)) for S, dK in zip(f["Ss"], dKs)]      # tr(K_i^-1 dK_i)
-        cc = float((f["c"] ** 2).sum())
+        cc = float(f["cc"])
         yy = float(self.tr_yTy)
         vprod = vs[0] * vs[1]
         elbo = (-0.5 * N * math.log(2 * math.pi * s) - 0.5 * float(f["logdet_P"]) + 0.5 * float(f["logdet_K"]) - 0.5 * yy / s
@@ -861,10 +996,17 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
                                        f["alpha"].data_ptr(), f["Ss"][0].data_ptr(), f["Ss"][1].data_ptr(), mean.data_ptr(),
                                        qk.data_ptr(), stream_ptr()), "predict_kron2d")
         # phi*^T P^-1 phi* (= |L_P^-1 phi*|^2, gpr.py:320-330) straight from the band-restricted inverse
-        check(lib.asvgp_predict_kron2d_var(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np,
-                                           b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
-                                           SigD.data_ptr(), SigS.data_ptr(), Bb, qp.data_ptr(), stream_ptr()),
-              "predict_kron2d_var")
+        lay = f.get("twist")
+        if lay is None:
+            check(lib.asvgp_predict_kron2d_var(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np,
+                                               b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                                               SigD.data_ptr(), SigS.data_ptr(), Bb, qp.data_ptr(), stream_ptr()),
+                  "predict_kron2d_var")
+        else:
+            check(lib.asvgp_predict_kron2d_var_twisted(X.data_ptr(), n, b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np,
+                                                       b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b1.m, b2.m, self.order,
+                                                       SigD.data_ptr(), SigS.data_ptr(), Bb, lay["nb"], lay["top_end"], lay["padt"], lay["padb"],
+                                                       qp.data_ptr(), stream_ptr()), "predict_kron2d_var_twisted")
         vprod = 1.0
         for kern in self.kernels:
             vprod *= float(kern.variance)

@@ -385,6 +385,27 @@ int asvgp_kron_grad_terms(const double* SigD, const double* SigS, int64_t Bb, co
 int asvgp_predict_kron2d_var(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
                              const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
                              const double* SigD, const double* SigS, int64_t Bb, double* qp, asvgp_stream_t stream);
+/* Two-sided ("twisted") factorisation of P: the chain of the band Cholesky is sequential in its M/32 block columns, so P is split at a
+ * separator [h, h + Bb) one super-block wide (Bb >= bw) into a TOP system (padt identity columns, then original columns 0 .. h+Bb-1)
+ * and a BOTTOM system in REVERSED order (padb identity columns, then original columns M-1 .. h), both nb Bb columns long with the
+ * separator as their last super-block.  asvgp_kron_assemble_twisted writes the two bands (Pt, Pr: (nb Bb)(bw+1) doubles each, zeroed
+ * here), asvgp_blockband_cholesky factors them independently (concurrently on two streams: half the chain each), and the separator's
+ * Schur complement  S = L_ss L_ss^T + J L'_ss L'_ss^T J - P_ss  (J: reversal) is factored last.  top_end = h + Bb,
+ * padt = nb Bb - top_end, padb = nb Bb - (M - h).  The selected inverse then runs outwards from S^-1 in both systems at once
+ * (SigD [2][nb][Bb][Bb], SigS [2][nb-1][Bb][Bb]: stack 0 = top, stack 1 = bottom, reversed) and the _twisted forms of the two
+ * consumers read that layout. */
+int asvgp_kron_assemble_twisted(const double* K1, const double* K2, const double* S1, const double* S2, const double* Ablk, int k,
+                                int64_t m1, int64_t m2, double noise_variance, int64_t Bb, int64_t nb, int64_t top_end, int64_t padt,
+                                int64_t padb, double* Pt, double* Pr, double* trace_out, asvgp_stream_t stream);
+int asvgp_kron_grad_terms_twisted(const double* SigD, const double* SigS, int64_t Bb, int64_t nb, int64_t top_end, int64_t padt,
+                                  int64_t padb, const double* alpha, const double* Ablk, const double* K1, const double* K2,
+                                  const double* dK1, const double* dK2, const double* S1, const double* S2, const double* Z1,
+                                  const double* Z2, int k, int64_t m1, int64_t m2, double* out11, asvgp_stream_t stream);
+int asvgp_predict_kron2d_var_twisted(const double* Xnew, int64_t n, const double* mesh1, int64_t n_mesh1, double delta1,
+                                     const double* mesh2, int64_t n_mesh2, double delta2, int64_t m1, int64_t m2, int order,
+                                     const double* SigD, const double* SigS, int64_t Bb, int64_t nb, int64_t top_end, int64_t padt,
+                                     int64_t padb, double* qp, asvgp_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Additive model (GPR_additive, gpr.py:139-236): Kuf = vstack(Kuf_1 .. Kuf_d), so Kuf Kuf^T (gpr.py:170-171) has the

@@ -1280,6 +1280,7 @@ def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
     kerns = [A.Matern32(variance=th[0][0], lengthscales=th[0][1]), A.Matern32(variance=th[1][0], lengthscales=th[1][1])]
     model = A.GPR_kron((X, y), kerns, bases)
     model.likelihood.variance.assign(s)
+    model.twisted = False                                      # (the one-sided factorisation and its block layout; the two-sided one has its own test)
     obases = [O.Basis(order, 0, 1, m1), O.Basis(order, -1, 2, m2)]
     oe, parts = O.elbo_kron(obases, [1, 1], th, s, X, y)
     # selected inverse
@@ -1305,6 +1306,71 @@ def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
 
     _, og = O.elbo_grad_kron(obases, [1, 1], th, s, X, y)     # the analytic dense gradient (what TF autodiff gives the reference)
     np.testing.assert_allclose(g, og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
+
+
+@pytest.mark.parametrize("order,m1,m2,N", [(2, 40, 12, 6000), (3, 30, 9, 5000), (4, 26, 14, 7000), (1, 50, 31, 8000)])
+def test_kron_two_sided_factorisation_equals_the_one_sided_and_the_dense_oracle(A, order, m1, m2, N):
+    """The two-sided ("twisted") band Cholesky of P - top system and reversed bottom system factored concurrently, joined by the
+    separator's Schur complement - against (a) the dense oracle: bound (the suite's gate) and analytic gradient (1e-6), the
+    band-restricted inverse entry by entry from the two block stacks (1e-9 of the largest entry of P^-1), alpha; (b) the
+    one-sided factorisation of the same model: bound 1e-11, gradient 1e-8, posterior mean / variance 1e-10."""
+    rng = np.random.default_rng(m1 * 131 + m2)
+    X = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(-0.999, 1.999, N)], axis=1)
+    y = (np.sin(6 * X[:, :1]) * np.cos(2 * X[:, 1:]) + 0.1 * rng.normal(size=(N, 1)))
+    B = getattr(A, "B%dSpline" % order)
+    bases = [B(0, 1, m1), B(-1, 2, m2)]
+    th = [(1.1, 0.3), (0.7, 0.6)]
+    s = 0.05
+    Kern, kind = (A.Matern12, 0) if order == 1 else (A.Matern32, 1)
+    mk = lambda: [Kern(variance=th[0][0], lengthscales=th[0][1]), Kern(variance=th[1][0], lengthscales=th[1][1])]
+    model = A.GPR_kron((X, y), mk(), bases)
+    model.likelihood.variance.assign(s)
+    lay = model._twist_layout()
+    assert lay is not None and lay["nb"] >= 3, lay
+    plain = A.GPR_kron((X, y), mk(), bases)
+    plain.likelihood.variance.assign(s)
+    plain.twisted = False
+    assert plain._twist_layout() is None
+    obases = [O.Basis(order, 0, 1, m1), O.Basis(order, -1, 2, m2)]
+    oe, parts = O.elbo_kron(obases, [kind, kind], th, s, X, y)
+    e, g = model.elbo_and_grad()
+    ep, gp = plain.elbo_and_grad()
+    yy = float(np.sum(y * y))
+    assert abs(e - oe) <= elbo_tol(oe, N, th[0][0] * th[1][0], s, yy, bcr=True), (e, oe)
+    assert abs(model.elbo().item() - e) <= 1e-11 * abs(e)
+    assert abs(e - ep) <= 1e-11 * abs(ep), (e, ep)
+    np.testing.assert_allclose(g, gp, rtol=1e-8, atol=1e-8 * np.max(np.abs(gp)))
+    _, og = O.elbo_grad_kron(obases, [kind, kind], th, s, X, y)
+    np.testing.assert_allclose(g, og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
+    # the two block stacks against the dense inverse
+    f = model._factor(want_alpha=False)
+    SigD, SigS, Bb = model._selinv(f)
+    nb, top_end, padt, padb = lay["nb"], lay["top_end"], lay["padt"], lay["padb"]
+    M = m1 * m2
+    Pinv = np.linalg.inv(parts["P"])
+    sc = np.max(np.abs(Pinv))
+    top = np.eye(nb * Bb); top[padt:, padt:] = Pinv[:top_end, :top_end]
+    h = top_end - Bb
+    rev = np.eye(nb * Bb); rev[padb:, padb:] = Pinv[h:, h:][::-1, ::-1]
+    for st, ref in enumerate((top, rev)):
+        for i in range(nb):
+            np.testing.assert_allclose(SigD[st, i].cpu().numpy(), ref[i * Bb:(i + 1) * Bb, i * Bb:(i + 1) * Bb], rtol=0, atol=1e-9 * sc)
+            if i + 1 < nb:
+                np.testing.assert_allclose(SigS[st, i].cpu().numpy(), ref[(i + 1) * Bb:(i + 2) * Bb, i * Bb:(i + 1) * Bb], rtol=0, atol=1e-9 * sc)
+    a_ref = Pinv @ np.asarray(parts["b"]).reshape(-1)
+    np.testing.assert_allclose(f["alpha"].cpu().numpy() * s, a_ref, rtol=0, atol=1e-9 * np.max(np.abs(a_ref)))
+    # posterior: both factorisations, 3000 points (the variance reads the stacks through the twisted accessor)
+    Xs = np.stack([rng.uniform(0.01, 0.99, 3000), rng.uniform(-0.99, 1.99, 3000)], axis=1)
+    m_t, v_t = model.predict_f(Xs)
+    m_p, v_p = plain.predict_f(Xs)
+    np.testing.assert_allclose(m_t, m_p, rtol=0, atol=1e-10 * max(1.0, np.max(np.abs(m_p))))
+    np.testing.assert_allclose(v_t, v_p, rtol=0, atol=1e-10)
+    # a P that is not positive definite is reported, not factored
+    bad = A.GPR_kron((X, y), mk(), bases)
+    bad.likelihood.variance.assign(s)
+    bad._stats[:bad.noff * bad.Mtot].mul_(-1.0)
+    with pytest.raises(A.NotPositiveDefiniteError if hasattr(A, "NotPositiveDefiniteError") else Exception):
+        bad.elbo()
 
 
 @pytest.mark.parametrize("order,m1,m2,N", [(1, 7, 9, 3000), (2, 9, 8, 4001), (3, 12, 10, 20000), (4, 14, 15, 30000), (5, 16, 15, 8000),

@@ -11,6 +11,9 @@ bases = [A.B3Spline(0, 1, m), A.B3Spline(0, 1, m)]
 kern = [A.Matern32(variance=1.0, lengthscales=0.2), A.Matern32(variance=1.0, lengthscales=0.2)]
 torch.cuda.synchronize(); t0 = time.perf_counter()
 model = A.GPR_kron((Xd, yd), kern, bases); model.likelihood.variance.assign(0.01)
+if os.environ.get("KTWIST") is not None:
+    model.twisted = bool(int(os.environ["KTWIST"]))            # KTWIST=0: the one-sided band Cholesky
+print("factorisation:", "two-sided %s" % model._twist_layout() if model._twist_layout() else "one-sided")
 torch.cuda.synchronize(); t1 = time.perf_counter()
 for _ in range(2): model.phi_pass()
 torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -27,6 +30,11 @@ torch.cuda.synchronize(); t8 = time.perf_counter()
 mean, var = model.predict_f_device(Xl); torch.cuda.synchronize(); t9 = time.perf_counter()
 eg = model.elbo_and_grad(); torch.cuda.synchronize(); t10 = time.perf_counter()
 eg = model.elbo_and_grad(); torch.cuda.synchronize(); t11 = time.perf_counter()
+reps = []
+for _ in range(5):
+    ta = time.perf_counter(); model.elbo().item(); tb = time.perf_counter(); model.elbo_and_grad(); tc = time.perf_counter()
+    reps.append((tb - ta, tc - tb))
+print("5 repeats: elbo %s ms | elbo+grad %s ms" % ([round(a * 1e3, 2) for a, _ in reps], [round(b * 1e3, 2) for _, b in reps]))
 f = model._factor(want_alpha=True); torch.cuda.synchronize(); t12 = time.perf_counter()
 model._selinv(f); torch.cuda.synchronize(); t13 = time.perf_counter()
 print("predict 10k (cached factor) %.2f ms | predict 1M %.1f ms | elbo+grad %.1f ms | factor %.1f ms | selected inverse %.1f ms | grad %s" % (
