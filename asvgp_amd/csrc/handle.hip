@@ -4,6 +4,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -13,7 +14,7 @@
 namespace asvgp {
 
 static DebugEnv g_dbg;
-static bool g_dbg_loaded = false;
+static std::once_flag g_dbg_once;            // (handles may be driven from two host threads: the first callers race for the load)
 static void debug_env_load() {
   g_dbg.no_assembly = getenv("ASVGP_DEBUG_NO_ASSEMBLY") ? 1 : 0;   // test hook: the helpers never report -> the chains give up waiting
   g_dbg.chain_stamps = getenv("ASVGP_CHAIN_STAMPS") ? 1 : 0;
@@ -22,10 +23,9 @@ static void debug_env_load() {
   g_dbg.plan_first = getenv("ASVGP_PLAN_FIRST") ? 1 : 0;
   g_dbg.bcr_stamps = getenv("ASVGP_BCR_STAMPS") ? atoi(getenv("ASVGP_BCR_STAMPS")) : 0;
   g_dbg.no_split = getenv("ASVGP_NO_SPLIT") ? atoi(getenv("ASVGP_NO_SPLIT")) : 0;   // the matrix-core P chain on ONE workgroup (measurement aid)
-  g_dbg_loaded = true;
 }
 const DebugEnv& debug_env() {
-  if (!g_dbg_loaded) debug_env_load();
+  std::call_once(g_dbg_once, debug_env_load);
   return g_dbg;
 }
 
@@ -78,8 +78,17 @@ static void plan_release(Handle* h) {
 static void worker_wait_idle(Handle* h) {
   while (__atomic_load_n(&h->wstate, __ATOMIC_ACQUIRE) == 1) sched_yield();
 }
+// The worker spins while jobs keep coming (a post is then seen within a pause instruction); after ~2 ms without one it parks on the
+// handle's condition variable - a model kept alive after fit() costs no host core - and the next post wakes it (one futex call).
+struct WorkerPark {
+  std::mutex mu;
+  std::condition_variable cv;
+  int parked = 0;                            // (written under mu)
+};
+static WorkerPark* park_of(Handle* h) { return static_cast<WorkerPark*>(h->worker_park); }
 static void worker_main(Handle* h) {
   long idle = 0;
+  WorkerPark* pk = park_of(h);
   for (;;) {
     const int st = __atomic_load_n(&h->wstate, __ATOMIC_ACQUIRE);
     if (st == 2) return;
@@ -88,24 +97,40 @@ static void worker_main(Handle* h) {
       __atomic_store_n(h->ready_host + h->fwd.slot, h->fwd.seq, __ATOMIC_RELEASE);
       __atomic_store_n(&h->wstate, 0, __ATOMIC_RELEASE);
       idle = 0;
-    } else if (++idle > 200000) {
-      sched_yield();                         // (a model that has stopped stepping: give the core away between looks)
+    } else if (++idle > 200000) {            // (~2 ms of pauses) a model that has stopped stepping: sleep until the next post
+      std::unique_lock<std::mutex> lk(pk->mu);
+      pk->parked = 1;
+      pk->cv.wait(lk, [&] { return __atomic_load_n(&h->wstate, __ATOMIC_ACQUIRE) != 0; });
+      pk->parked = 0;
+      idle = 0;
     } else {
       __builtin_ia32_pause();
     }
   }
 }
+static void worker_signal(Handle* h, int state) {
+  WorkerPark* pk = park_of(h);
+  __atomic_store_n(&h->wstate, state, __ATOMIC_SEQ_CST);
+  bool wake;
+  { std::lock_guard<std::mutex> lk(pk->mu); wake = pk->parked != 0; }   // (the worker sets `parked` and re-tests the state under the same lock)
+  if (wake) pk->cv.notify_one();
+}
 void handle_post_forward(Handle* h) {
-  if (!h->worker) h->worker = new std::thread(worker_main, h);
-  __atomic_store_n(&h->wstate, 1, __ATOMIC_RELEASE);
+  if (!h->worker) {
+    h->worker_park = new WorkerPark;
+    h->worker = new std::thread(worker_main, h);
+  }
+  worker_signal(h, 1);
 }
 static void worker_stop(Handle* h) {
   if (!h->worker) return;
   worker_wait_idle(h);
-  __atomic_store_n(&h->wstate, 2, __ATOMIC_RELEASE);
+  worker_signal(h, 2);
   std::thread* t = static_cast<std::thread*>(h->worker);
   t->join();
   delete t;
+  delete park_of(h);
+  h->worker_park = nullptr;
   h->worker = nullptr;
   h->wstate = 0;
 }

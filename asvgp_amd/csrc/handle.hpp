@@ -44,9 +44,10 @@ struct Handle {
   // forward pass for it and sets the slot's ready word (the next ELBO call or the handle's teardown does it if the caller did not)
   bool defer_forward = false;
   // ... or runs on the handle's own worker thread (asvgp_set_deferred_forward_pass(h, 2)): posted BEFORE the launch call, so the ~19 us of
-  // long-double arithmetic overlap the launch path and the caller's next enqueues; the worker spins while idle (one host core)
+  // long-double arithmetic overlap the launch path and the caller's next enqueues; the worker spins while jobs keep coming and parks on a condition variable after ~2 ms without one
   bool fwd_worker = false;
   void* worker = nullptr;                 // std::thread*
+  void* worker_park = nullptr;            // condition variable the idle worker sleeps on (handle.hip)
   int wstate = 0;                         // 0 idle, 1 job posted, 2 exit  (accessed with __atomic builtins)
   struct PendingForward { bool valid; double coef[ASVGP_MAX_KUU_TERMS], dcoef[ASVGP_MAX_KUU_TERMS]; double* tab; int slot; unsigned long long seq; } fwd = {false, {0}, {0}, nullptr, 0, 0};
   // forward pass on the GPU in double-double (asvgp_set_prior_forward(h, 1); prior_dd.hip): device image of the plan, device table ring

@@ -97,7 +97,8 @@ int asvgp_debug_reload_env(void);
  * (bounded) for the table; the next ELBO call, asvgp_set_deferred_forward_pass(h, 0) and asvgp_destroy publish a forgotten one.
  * on = 2: the pass runs on a worker thread the handle owns, posted BEFORE the launch call - it overlaps the launch path and whatever the
  * caller enqueues next, and the table is published ~20 us after the call was entered (on = 1 in bench.py's order: ~38 us).  The worker
- * spins while idle (one host core per handle, yielding after ~1 ms without work); asvgp_prior_publish then only waits for it. */
+ * spins while jobs keep coming and sleeps on a condition variable after ~2 ms without one (the next post wakes it);
+ * asvgp_prior_publish then only waits for it. */
 int asvgp_set_deferred_forward_pass(asvgp_handle_t handle, int on);
 int asvgp_prior_publish(asvgp_handle_t handle);
 /* Result mirror: 16 pinned host doubles owned by the handle.  While enabled, the fused ELBO + gradient launch (band algorithm 0 / 4 where
