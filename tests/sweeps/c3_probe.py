@@ -25,9 +25,13 @@ print("statistics: max |diff| / max |ref| = %.2e" % (np.max(np.abs(model._stats.
 oe, og, _ = O.elbo_grad_1d(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
 ee, ge = O.elbo_grad_1d_extended(ob, O.MATERN52, Ab, b, yy, N, v, l, s)
 print("oracle fp64 %.6f  long double %.6f  (|diff| %.3g)" % (oe, ee, abs(oe - ee)))
+names = ("d/dv", "d/dl", "d/ds2")
+print("gradient, per component, relative to the long-double gradient %s:" % np.array2string(np.asarray(ge, dtype=np.float64), precision=6))
+print("  fp64 oracle (reference elimination order): " + "  ".join("%s %.2e" % (nm, abs(a - b) / abs(b)) for nm, a, b in zip(names, og, ge)))
 for algo in (0, 1, 2, 3):
     A.set_band_algorithm(algo)
     r = model.elbo_and_grad().cpu().numpy()
     print("band algorithm %d: elbo+grad %.1f us | ELBO - long double %+.3e | gradient rel %.2e" % (
         algo, t(lambda: model.elbo_and_grad(check_pd=False)), r[0] - ee, np.max(np.abs(r[1:4] - ge) / np.abs(ge))), flush=True)
+    print("  per component: " + "  ".join("%s %.2e" % (nm, abs(a - b) / abs(b)) for nm, a, b in zip(names, r[1:4], ge)), flush=True)
 A.set_band_algorithm(0)

@@ -28,8 +28,12 @@ timeout -k 10 200 python3 tools/phi_probe.py 1250000 > $O/phi_probe_1250k.txt 2>
 timeout -k 10 200 python3 tools/vjp_probe.py > $O/vjp_probe.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/prior_dd_probe.py > $O/prior_dd_probe.txt 2>&1 || exit 1
 timeout -k 10 400 python3 tools/dep_probe.py > $O/dep_probe.txt 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kron -- python3 tools/kron_probe.py > $O/kron.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kron -- python3 tools/kron_trace.py > $O/kron.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/predict -- python3 tools/predict_probe.py > $O/predict.log 2>&1 || exit 1
+timeout -k 10 200 python3 tools/ahead_probe.py > $O/ahead_probe.txt 2>&1 || exit 1
+timeout -k 10 300 python3 tools/kron_probe.py > $O/kron_probe_untraced.txt 2>&1 || exit 1
+KTWIST=0 timeout -k 10 300 python3 tools/kron_probe.py > $O/kron_probe_onesided.txt 2>&1 || exit 1
+timeout -k 10 100 tools/micro/bin/reduce_bench > $O/reduce_bench.txt 2>&1 || exit 1
 timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --sorted > $O/bench_sorted.json 2> $O/bench_sorted.err || exit 1
 find $O -name "*kernel_trace.csv" -size +8M -delete

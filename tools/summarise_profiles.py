@@ -47,12 +47,17 @@ copy("phi_probe_1250k.txt", tag + "_phi_probe_n1250k.txt")
 copy("vjp_probe.txt", tag + "_vjp_probe.txt")
 copy("prior_dd_probe.txt", tag + "_prior_dd_probe.txt")
 copy("dep_probe.txt", tag + "_dependent_step_ablation.txt")
+copy("ahead_probe.txt", tag + "_ahead_probe.txt")
+copy("reduce_bench.txt", tag + "_reduce_bench.txt")
+copy("kron_probe_onesided.txt", tag + "_kron_probe_onesided.txt")
 for sub in ("kron", "predict"):          # kernel-trace stats of tools/kron_probe.py / tools/predict_probe.py + the probes' own output
     fs = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if fs:
         shutil.copy(fs[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, sub)))
         log = [ln for ln in open(os.path.join(src, sub + ".log")).read().splitlines() if "amdgpu.ids" not in ln and not ln.startswith("W2") and not ln.startswith("E20")]
         open(os.path.join(dst, "%s_%s_probe.txt" % (tag, sub)), "w").write("\n".join(log[-12:]) + "\n")
+copy("kron_probe_untraced.txt", tag + "_kron_probe.txt")          # (the Kronecker probe's own timings: untraced; the trace above is tools/kron_trace.py)
+
 # the bench runs its schedules in one process: split the Phi kernel's launches by grid size (256 workgroups = one step at a time and
 # construction, fewer = the overlapped schedules) so that each average can be held against the matching figure of the bench line
 kt = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
