@@ -37,7 +37,10 @@ typedef long double ld;
 // The forward pass owes its accuracy (|bound - exact| ~ 3e-11 |bound| at the headline configuration, cond(Kuu) = 3.5e7) to the 64-bit
 // mantissa of the x87 extended format.  A toolchain where long double is plain fp64 (or a software quad) must not build this silently.
 static_assert(LDBL_MANT_DIG == 64, "prior_plan.cpp needs the 80-bit x87 long double (64-bit mantissa)");
-struct Blk { ld v[MAXB][MAXB]; double d[MAXB][MAXB]; };   // value (long double) + tangent d / d lengthscale (double)
+// Tangent arithmetic: double by default (the x87 unit then carries a third of the flops of a (long double, long double) dual number);
+// ASVGP_PRIOR_TANGENT_LD=1 in the environment carries the tangents in long double as well (what the
+// d / d lengthscale component gains from it at cond(Kuu) ~ 1e9).
+template <typename td> struct BlkT { ld v[MAXB][MAXB]; td d[MAXB][MAXB]; };   // value (long double) + tangent d / d lengthscale (td)
 
 struct Level {
   std::vector<std::array<int, 3>> node_in;   // per node class: (D class of i, E class of (a, i), E class of (i, b) or -1)
@@ -280,7 +283,9 @@ static inline void kuu_entry(const PriorPlan& p, const double* c, const double* 
   kv = acc; dv = dacc;
 }
 
-int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef, double* tab) {
+template <typename td>
+static int prior_plan_eval_t(const PriorPlan* pp, const double* coef, const double* dcoef, double* tab) {
+  typedef BlkT<td> Blk;
   // Values in long double; tangents (d / d lengthscale: the gradient is gated at 1e-6) in double from the rounded values -
   // two separate recurrences, so the x87 unit carries a third of the flops of a (long double, long double) dual number.
   const PriorPlan& p = *pp;
@@ -314,10 +319,10 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
       }
   }
   ld logdet = 0.0L;
-  double dlogdet = 0.0;
+  td dlogdet = 0.0;
   int bad = 0;
   // Cholesky in place (lower part of D becomes L), inv = 1 / diag(L); then the tangent recurrence on the rounded factor
-  auto chol = [&](Blk& D, ld (&inv)[MAXB], double (&Ld)[MAXB][MAXB], double (&invd)[MAXB], double (&dinv)[MAXB], int col0) {
+  auto chol = [&](Blk& D, ld (&inv)[MAXB], td (&Ld)[MAXB][MAXB], td (&invd)[MAXB], td (&dinv)[MAXB], int col0) {
     for (int j = 0; j < B; ++j) {
       ld s = D.v[j][j];
       for (int q = 0; q < j; ++q) s -= D.v[j][q] * D.v[j][q];
@@ -331,16 +336,16 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
         D.v[i][j] = t * inv[j];
       }
     }
-    for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { if (c > r) D.v[r][c] = 0.0L; Ld[r][c] = (double)D.v[r][c]; }
+    for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { if (c > r) D.v[r][c] = 0.0L; Ld[r][c] = (td)D.v[r][c]; }
     for (int j = 0; j < B; ++j) {
-      invd[j] = (double)inv[j];
-      double ds = D.d[j][j];
+      invd[j] = (td)inv[j];
+      td ds = D.d[j][j];
       for (int q = 0; q < j; ++q) ds -= 2.0 * D.d[j][q] * Ld[j][q];
-      const double dl = 0.5 * ds * invd[j];
+      const td dl = 0.5 * ds * invd[j];
       D.d[j][j] = dl;
       dinv[j] = -dl * invd[j] * invd[j];
       for (int i = j + 1; i < B; ++i) {
-        double dt = D.d[i][j];
+        td dt = D.d[i][j];
         for (int q = 0; q < j; ++q) dt -= D.d[i][q] * Ld[j][q] + Ld[i][q] * D.d[j][q];
         D.d[i][j] = (dt - Ld[i][j] * dl) * invd[j];
       }
@@ -348,25 +353,25 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
     for (int r = 0; r < B; ++r) for (int c = r + 1; c < B; ++c) D.d[r][c] = 0.0;
   };
   // X <- L^-1 X with its tangent
-  auto solveL = [&](const Blk& L, const ld (&inv)[MAXB], const double (&Ld)[MAXB][MAXB], const double (&invd)[MAXB], Blk& X) {
-    double Xd[MAXB][MAXB];
+  auto solveL = [&](const Blk& L, const ld (&inv)[MAXB], const td (&Ld)[MAXB][MAXB], const td (&invd)[MAXB], Blk& X) {
+    td Xd[MAXB][MAXB];
     for (int c = 0; c < B; ++c)
       for (int i = 0; i < B; ++i) {
         ld t = X.v[i][c];
         for (int q = 0; q < i; ++q) t -= L.v[i][q] * X.v[q][c];
         X.v[i][c] = t * inv[i];
-        Xd[i][c] = (double)X.v[i][c];
+        Xd[i][c] = (td)X.v[i][c];
       }
     for (int c = 0; c < B; ++c)
       for (int i = 0; i < B; ++i) {
-        double dt = X.d[i][c];
+        td dt = X.d[i][c];
         for (int q = 0; q < i; ++q) dt -= L.d[i][q] * Xd[q][c] + Ld[i][q] * X.d[q][c];
         X.d[i][c] = (dt - L.d[i][i] * Xd[i][c]) * invd[i];
       }
   };
-  auto put = [&](int rec, int f, ld x, double dx) { val[(size_t)rec * W + f] = (double)x; tan[(size_t)rec * W + f] = dx; };
+  auto put = [&](int rec, int f, ld x, td dx) { val[(size_t)rec * W + f] = (double)x; tan[(size_t)rec * W + f] = (double)dx; };
   ld inv[MAXB];
-  double Ld[MAXB][MAXB], invd[MAXB], dinv[MAXB];
+  td Ld[MAXB][MAXB], invd[MAXB], dinv[MAXB];
   for (int l = 0; l < p.levels; ++l) {
     const Level& L = p.lv[l];
     const int nq = (int)L.node_in.size();
@@ -381,34 +386,35 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
       solveL(D, inv, Ld, invd, Ua);
       if (hasb) solveL(D, inv, Ld, invd, Ub);
       const int rec = p.lvl_off[l] + q;
-      double ua[MAXB][MAXB], ub[MAXB][MAXB], prod = 1.0;
+      td ua[MAXB][MAXB], ub[MAXB][MAXB];
+      double prod = 1.0;
       for (int r = 0; r < B; ++r) {
         put(rec, prior_f_I(B) + r, inv[r], dinv[r]);
-        prod *= Ld[r][r];                                      // (B <= 6 factors between ~1e-4 and ~1e4: no range problem)
-        dlogdet += (double)L.node_count[q] * 2.0 * D.d[r][r] * invd[r];
+        prod *= (double)Ld[r][r];                              // (B <= 6 factors between ~1e-4 and ~1e4: no range problem)
+        dlogdet += (td)L.node_count[q] * 2.0 * D.d[r][r] * invd[r];
         for (int c = 0; c < B; ++c) {
           put(rec, prior_f_L(B) + r * B + c, D.v[r][c], D.d[r][c]);
           put(rec, prior_f_UA(B) + r * B + c, Ua.v[r][c], Ua.d[r][c]);
           put(rec, prior_f_UB(B) + r * B + c, Ub.v[r][c], Ub.d[r][c]);
-          ua[r][c] = (double)Ua.v[r][c]; ub[r][c] = (double)Ub.v[r][c];
+          ua[r][c] = (td)Ua.v[r][c]; ub[r][c] = (td)Ub.v[r][c];
         }
       }
       {   // L^-1 (long double) with its tangent d L^-1 = -L^-1 dL L^-1, then G_a^T = U_a^T L^-1, G_b^T = U_b^T L^-1, D^-1 = L^-T L^-1
         ld Li[MAXB][MAXB];
-        double Lid[MAXB][MAXB], dLi[MAXB][MAXB], tmp[MAXB][MAXB];
+        td Lid[MAXB][MAXB], dLi[MAXB][MAXB], tmp[MAXB][MAXB];
         for (int c = 0; c < B; ++c)
           for (int r = 0; r < B; ++r) {
             ld t = (r == c) ? 1.0L : 0.0L;
             for (int q2 = 0; q2 < r; ++q2) t -= D.v[r][q2] * Li[q2][c];
             Li[r][c] = (r >= c) ? t * inv[r] : 0.0L;
-            Lid[r][c] = (double)Li[r][c];
+            Lid[r][c] = (td)Li[r][c];
           }
-        for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { double t = 0.0; for (int q2 = 0; q2 < B; ++q2) t += D.d[r][q2] * Lid[q2][c]; tmp[r][c] = t; }
-        for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { double t = 0.0; for (int q2 = 0; q2 < B; ++q2) t -= Lid[r][q2] * tmp[q2][c]; dLi[r][c] = t; }
+        for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { td t = 0.0; for (int q2 = 0; q2 < B; ++q2) t += D.d[r][q2] * Lid[q2][c]; tmp[r][c] = t; }
+        for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { td t = 0.0; for (int q2 = 0; q2 < B; ++q2) t -= Lid[r][q2] * tmp[q2][c]; dLi[r][c] = t; }
         for (int r = 0; r < B; ++r)
           for (int c = 0; c < B; ++c) {
             ld ga = 0.0L, gb = 0.0L, di = 0.0L;
-            double dga = 0.0, dgb = 0.0, ddi = 0.0;
+            td dga = 0.0, dgb = 0.0, ddi = 0.0;
             for (int q2 = 0; q2 < B; ++q2) {
               ga += Ua.v[q2][r] * Li[q2][c];
               gb += Ub.v[q2][r] * Li[q2][c];
@@ -427,7 +433,7 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
       for (int r = 0; r < B; ++r)
         for (int c = 0; c < B; ++c) {
           ld a = 0.0L, b = 0.0L, e = 0.0L;
-          double da = 0.0, db = 0.0, de = 0.0;
+          td da = 0.0, db = 0.0, de = 0.0;
           for (int q2 = 0; q2 < B; ++q2) {
             a += Ua.v[q2][r] * Ua.v[q2][c];
             da += Ua.d[q2][r] * ua[q2][c] + ua[q2][r] * Ua.d[q2][c];
@@ -461,17 +467,17 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
     Blk X;
     for (int r = 0; r < B; ++r) for (int c = 0; c < B; ++c) { X.v[r][c] = (r == c) ? 1.0L : 0.0L; X.d[r][c] = 0.0; }
     solveL(D, inv, Ld, invd, X);
-    double Xd[MAXB][MAXB];
+    td Xd[MAXB][MAXB];
     for (int c = 0; c < B; ++c)                                // X <- L^-T X
       for (int i = B - 1; i >= 0; --i) {
         ld t = X.v[i][c];
         for (int q = i + 1; q < B; ++q) t -= D.v[q][i] * X.v[q][c];
         X.v[i][c] = t * inv[i];
-        Xd[i][c] = (double)X.v[i][c];
+        Xd[i][c] = (td)X.v[i][c];
       }
     for (int c = 0; c < B; ++c)
       for (int i = B - 1; i >= 0; --i) {
-        double dt = X.d[i][c];
+        td dt = X.d[i][c];
         for (int q = i + 1; q < B; ++q) dt -= D.d[q][i] * Xd[q][c] + Ld[q][i] * X.d[q][c];
         X.d[i][c] = (dt - D.d[i][i] * Xd[i][c]) * invd[i];
       }
@@ -479,7 +485,7 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
     double prod = 1.0;
     for (int r = 0; r < B; ++r) {
       put(rec, prior_f_I(B) + r, inv[r], dinv[r]);
-      prod *= Ld[r][r];
+      prod *= (double)Ld[r][r];
       dlogdet += 2.0 * D.d[r][r] * invd[r];
       for (int c = 0; c < B; ++c) {
         put(rec, prior_f_L(B) + r * B + c, D.v[r][c], D.d[r][c]);
@@ -490,8 +496,13 @@ int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef
     logdet += 2.0L * (ld)log(prod);
   }
   // padding rows contribute log(1) = 0; header: [logdet, dlogdet/dl, first failing column + 1, n_rec]
-  tab[0] = (double)logdet; tab[1] = dlogdet; tab[2] = (double)bad; tab[3] = (double)R;
+  tab[0] = (double)logdet; tab[1] = (double)dlogdet; tab[2] = (double)bad; tab[3] = (double)R;
   return bad;
+}
+
+int prior_plan_eval(const PriorPlan* pp, const double* coef, const double* dcoef, double* tab) {
+  static const bool tangent_ld = getenv("ASVGP_PRIOR_TANGENT_LD") && atoi(getenv("ASVGP_PRIOR_TANGENT_LD")) != 0;
+  return tangent_ld ? prior_plan_eval_t<long double>(pp, coef, dcoef, tab) : prior_plan_eval_t<double>(pp, coef, dcoef, tab);
 }
 
 }  // namespace asvgp

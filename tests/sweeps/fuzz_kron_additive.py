@@ -30,6 +30,7 @@ for case in range(n_cases):
         yy = float(np.sum(y * y))
         if kron:
             model = A.GPR_kron((X, y), kerns, bases); model.likelihood.variance.assign(s)
+            model.twisted = [None, True, False][int(rng.integers(0, 3))]      # two-sided factorisation: by size / wherever it fits / never
             oe, parts = O.elbo_kron(obases, kds, th, s, X, y)
             e, g = model.elbo_and_grad()
             om, ov = O.predict_f_kron(obases, kds, th, s, X, y, Xs)
