@@ -175,6 +175,224 @@ __global__ __launch_bounds__(256) void phi_kron2d_cells_kernel(
   if (tid == 0 && tot != 0.0) __hip_atomic_fetch_add(yy_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same statistics on the fp64 MATRIX CORE, without statistic atomics (round 4; the default).  Measured on the per-cell kernel
+// above: 177 us for 1M points at 128 x 128 WITHOUT its atomics (rocprofv3; 164 us with them) - it is not the 2.45 M atomics that
+// cost, it is one workgroup per cell: 62 points keep 62 of 256 threads busy in the staging phase, two barriers per chunk, two LDS
+// reads per FMA in the walk (2.4 GB of LDS traffic), and the cell's loads are not overlapped with anything.
+// A cell's contribution is a small Gram matrix: with phi_m = v1[a] v2[b] (m = a (k+1) + b, (k+1)^2 values per point) the entry
+// (a, a2, b, b2) is sum_points phi_m phi_n, i.e. G = Phi_c^T Phi_c with Phi_c (points x (k+1)^2) - a rank-4 update per
+// v_mfma_f64_16x16x4 (16 basis functions per tile: one tile at k <= 3, 2 x 2 at k = 4, upper-triangular tile pairs only).  ONE WAVE
+// owns a cell: lane (ln, lg) evaluates ITS basis function ln of point lg from its two piece polynomials (2k FMAs, coefficients in
+// registers) - the same register is the A operand (A[m][k] = phi_m(point k)) and the B operand - and the wave walks the cell four
+// points per step; the rhs sums ride along on the VALU.  No barrier inside a cell.  A workgroup of eight waves takes a STRIP of 8
+// consecutive cells (one per wave), parks the cells' results in the LDS and writes them entry-major -
+// cellsum[entry][cell], 64-byte pieces - into a staging buffer; phi_kron2d_gather_kernel then forms every output (block-band offset,
+// column) from the <= (k+1)^2 cells that touch it, in a fixed order: deterministic sums.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KRON_STRIP = 8;
+typedef double kron_d4 __attribute__((ext_vector_type(4)));
+template <int K>
+__global__ __launch_bounds__(64 * KRON_STRIP) void phi_kron2d_mfma_kernel(
+    const double* __restrict__ X, const double* __restrict__ y, const long long* __restrict__ cell_start, int ncell, int ncell_pad,
+    const double* __restrict__ mesh1, double id1, const double* __restrict__ mesh2, int n2, double id2,
+    double* __restrict__ cellsum, double* __restrict__ yy_out) {
+  using KO = KronOut<K>;
+  constexpr int NB = (K + 1) * (K + 1), NT = (NB + 15) / 16, NTT = NT * (NT + 1) / 2;
+  __shared__ double res[KO::NOUT * KRON_STRIP];
+  __shared__ double2 stage_x[64 * KRON_STRIP];
+  __shared__ double stage_y[64 * KRON_STRIP];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lg = lane >> 4;
+  // this lane's basis function per tile: m = 16 t + ln -> (a, b), the two piece polynomials (zeros past the last basis function)
+  double ca[NT][K + 1], cb[NT][K + 1];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int m = 16 * t + ln, a = m / (K + 1), b = m % (K + 1);
+#pragma unroll
+    for (int q = 0; q <= K; ++q) { ca[t][q] = 0.0; cb[t][q] = 0.0; }
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+      if (m < NB && i == a) {
+#pragma unroll
+        for (int q = 0; q <= K; ++q) ca[t][q] = piece_coef<K, 0>(i, q);
+      }
+      if (m < NB && i == b) {
+#pragma unroll
+        for (int q = 0; q <= K; ++q) cb[t][q] = piece_coef<K, 0>(i, q);
+      }
+    }
+  }
+  // where this lane's accumulator values go: tile pair (tm <= tn), value i: row m = 16 tm + lg + 4 i, column n = 16 tn + ln
+  short tgt[NTT][4];
+  {
+    int qi = 0;
+#pragma unroll
+    for (int tm = 0; tm < NT; ++tm)
+#pragma unroll
+      for (int tn = tm; tn < NT; ++tn, ++qi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * tm + lg + 4 * i, n = 16 * tn + ln;
+          int e = -1;
+          if (m < NB && n < NB) {
+            const int a = m / (K + 1), b = m % (K + 1), a2 = n / (K + 1), b2 = n % (K + 1);
+            if (a < a2 || (a == a2 && b <= b2)) {
+              e = 0;                                            // entries before (a, a2, b, b2) in the list order of KronOut
+              for (int x = 0; x < a; ++x) e += (K + 1) * (K + 2) / 2 + (K - x) * (K + 1) * (K + 1);
+              if (a2 > a) e += (K + 1) * (K + 2) / 2 + (a2 - a - 1) * (K + 1) * (K + 1) + b * (K + 1) + b2;
+              else { for (int x = 0; x < b; ++x) e += K + 1 - x; e += b2 - b; }
+            }
+          }
+          tgt[qi][i] = (short)e;
+        }
+  }
+  // The walk.  Wave w of the workgroup owns cell c0 + w of every strip the workgroup takes.  Its points come in chunks of 64: ONE coalesced
+  // load per lane (its own point: 16 B + 8 B), parked in a wave-private 1.5 KB LDS buffer, read back four points per step as broadcasts;
+  // the loads of the NEXT chunk (of this cell, or the first of the wave's next cell) are issued before the 16 steps of this one.
+  double2* xs = stage_x + wv * 64;
+  double* ys = stage_y + wv * 64;
+  double yy = 0.0;
+  int strip = blockIdx.x;
+  auto cell_range = [&](int st, long long& a0, long long& a1) __attribute__((always_inline)) {
+    const int c = st * KRON_STRIP + wv;
+    const bool in = st * KRON_STRIP < ncell_pad && c < ncell;
+    a0 = in ? cell_start[c] : 0;
+    a1 = in ? cell_start[c + 1] : 0;
+  };
+  long long p0, p1e;
+  cell_range(strip, p0, p1e);
+  double2 xn = make_double2(0.0, 0.0);
+  double yn = 0.0;
+  if (p0 + lane < p1e) { xn = *reinterpret_cast<const double2*>(X + 2 * (p0 + lane)); yn = y[p0 + lane]; }
+  for (; strip * KRON_STRIP < ncell_pad; strip += gridDim.x) {
+    const int c0 = strip * KRON_STRIP, c = c0 + wv;
+    kron_d4 acc[NTT];
+    double r[NT];
+#pragma unroll
+    for (int q = 0; q < NTT; ++q) acc[q] = kron_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r[t] = 0.0;
+    long long q0, q1e;                                            // the wave's next cell
+    cell_range(strip + gridDim.x, q0, q1e);
+    if (p1e > p0) {
+      const int i1 = c / (n2 - 1), i2 = c - i1 * (n2 - 1);
+      const double u1 = mesh1[i1], u2 = mesh2[i2];
+      for (long long base = p0; base < p1e; base += 64) {
+        xs[lane] = xn; ys[lane] = yn;                             // (lanes past the cell's end park zeros: masked below)
+        {
+          const long long nb = base + 64 < p1e ? base + 64 + lane : q0 + lane;      // next chunk of this cell, else the next cell's first
+          const long long ne = base + 64 < p1e ? p1e : q1e;
+          if (nb < ne) { xn = *reinterpret_cast<const double2*>(X + 2 * nb); yn = y[nb]; } else { xn = make_double2(0.0, 0.0); yn = 0.0; }
+        }
+        const int np = (int)(p1e - base < 64 ? p1e - base : 64);
+        auto step = [&](int st4, bool masked) __attribute__((always_inline)) {
+          const int pi = 4 * st4 + lg;
+          const bool ok = !masked || pi < np;
+          const double2 xv = xs[pi];
+          const double yv = ok ? ys[pi] : 0.0;
+          const double t1 = (xv.x - u1) * id1, t2 = (xv.y - u2) * id2;
+          double phi[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            double va = ca[t][K], vb = cb[t][K];
+#pragma unroll
+            for (int q = K - 1; q >= 0; --q) { va = fma(va, t1, ca[t][q]); vb = fma(vb, t2, cb[t][q]); }
+            phi[t] = ok ? va * vb : 0.0;
+            r[t] = fma(phi[t], yv, r[t]);
+          }
+          yy = fma(yv, yv, yy);                                   // (every one of the 16 lanes of a point: divided out at the end)
+          int qi = 0;
+#pragma unroll
+          for (int tm = 0; tm < NT; ++tm)
+#pragma unroll
+            for (int tn = tm; tn < NT; ++tn, ++qi) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[tm], phi[tn], acc[qi], 0, 0, 0);
+        };
+        const int nfull = np >> 2;                                  // steps whose four points all exist: no masks
+        for (int st4 = 0; st4 < nfull; ++st4) step(st4, false);
+        if (np & 3) step(nfull, true);
+      }
+    } else if (q1e > q0) {
+      // (an empty cell: the prefetch of the next cell was never issued - nothing was walked)
+      if (q0 + lane < q1e) { xn = *reinterpret_cast<const double2*>(X + 2 * (q0 + lane)); yn = y[q0 + lane]; } else { xn = make_double2(0.0, 0.0); yn = 0.0; }
+    }
+    p0 = q0; p1e = q1e;
+#pragma unroll
+    for (int q = 0; q < NTT; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (tgt[q][i] >= 0) res[(int)tgt[q][i] * KRON_STRIP + wv] = acc[q][i];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double v = r[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && 16 * t + ln < NB) res[(KO::NBAND + 16 * t + ln) * KRON_STRIP + wv] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < KO::NOUT * KRON_STRIP; idx += 64 * KRON_STRIP) {
+      const int o = idx / KRON_STRIP, cc = idx % KRON_STRIP;
+      cellsum[(size_t)o * ncell_pad + c0 + cc] = res[idx];
+    }
+    __syncthreads();
+  }
+  double tot = block_sum(yy, scratch) * 0.0625;
+  if (tid == 0 && tot != 0.0) __hip_atomic_fetch_add(yy_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// gather: one thread per output (plane, column); plane < noff: block-band offset (d1, d2); plane == noff: the rhs
+template <int K>
+__global__ __launch_bounds__(256) void phi_kron2d_gather_kernel(const double* __restrict__ cellsum, int ncell_pad, int nc1, int nc2, int m1, int m2,
+                                                                double* __restrict__ Ablk, double* __restrict__ rhs) {
+  using KO = KronOut<K>;
+  __shared__ short etab[K + 1][K + 1][K + 1][K + 1];      // (a, a2 >= a, b, b2) -> entry index of the cell's list
+  if (threadIdx.x == 0) {
+    int e = 0;
+    for (int a = 0; a <= K; ++a)
+      for (int a2 = a; a2 <= K; ++a2)
+        for (int b = 0; b <= K; ++b)
+          for (int b2 = 0; b2 <= K; ++b2) {
+            if (a2 == a && b2 < b) { etab[a][a2][b][b2] = -1; continue; }
+            etab[a][a2][b][b2] = (short)(e++);
+          }
+  }
+  __syncthreads();
+  const long Mtot = (long)m1 * m2;
+  const int noff = kron_noff(K);
+  const long total = (long)(noff + 1) * Mtot;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(t / Mtot);
+    const long col = t - (long)o * Mtot;
+    const int j1 = (int)(col / m2), j2 = (int)(col - (long)j1 * m2);
+    double sum = 0.0;
+    if (o < noff) {
+      int d1, d2;
+      if (o <= K) { d1 = 0; d2 = o; } else { const int q = o - (K + 1); d1 = 1 + q / (2 * K + 1); d2 = q % (2 * K + 1) - K; }
+      for (int a2 = d1; a2 <= K; ++a2) {
+        const int a = a2 - d1, i1 = j1 - K + a2;
+        if (i1 < 0 || i1 >= nc1) continue;
+        for (int b2 = (d2 > 0 ? d2 : 0); b2 <= K && b2 - d2 <= K; ++b2) {
+          const int b = b2 - d2, i2 = j2 - K + b2;
+          if (i2 < 0 || i2 >= nc2) continue;
+          sum += cellsum[(size_t)etab[a][a2][b][b2] * ncell_pad + (size_t)i1 * nc2 + i2];
+        }
+      }
+      Ablk[t] = sum;
+    } else {
+      for (int a = 0; a <= K; ++a) {
+        const int i1 = j1 - K + a;
+        if (i1 < 0 || i1 >= nc1) continue;
+        for (int b = 0; b <= K; ++b) {
+          const int i2 = j2 - K + b;
+          if (i2 < 0 || i2 >= nc2) continue;
+          sum += cellsum[(size_t)(KO::NBAND + a * (K + 1) + b) * ncell_pad + (size_t)i1 * nc2 + i2];
+        }
+      }
+      rhs[col] = sum;
+    }
+  }
+}
+
 // 2-D cell id per point: i1 * (n2 - 1) + i2  (basis.py:58-59 index rule per dimension)
 __global__ void kron_cell_index_kernel(const double* __restrict__ X, long N, const double* __restrict__ mesh1, int n1,
                                        double id1, const double* __restrict__ mesh2, int n2, double id2,
@@ -1421,14 +1639,47 @@ extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double
   if ((reinterpret_cast<uintptr_t>(Xs) & 15) != 0) { set_error("phi_accumulate_kron2d_sorted: Xs must be 16-byte aligned (N,2) row-major"); return ASVGP_ERR_BAD_ARG; }
   hipStream_t st = as_stream(stream);
   const size_t nd = asvgp_kron_stats_doubles(m1, m2, order);
-  hipError_t e = hipMemsetAsync(stats, 0, nd * sizeof(double), st);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
-  if (N == 0) return ASVGP_OK;
+  hipError_t e = hipSuccess;
+  if (N == 0) {
+    e = hipMemsetAsync(stats, 0, nd * sizeof(double), st);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return ASVGP_ERR_HIP; }
+    return ASVGP_OK;
+  }
   const long Mtot = (long)m1 * m2;
   double* Ablk = stats;
   double* rhs = stats + (size_t)kron_noff(order) * Mtot;
   double* yy = rhs + Mtot;
   const long ncell = (long)(n_mesh1 - 1) * (n_mesh2 - 1);
+  static const bool use_atomics = getenv("ASVGP_KRON_PHI_ATOMICS") && atoi(getenv("ASVGP_KRON_PHI_ATOMICS")) != 0;   // (the round-1..3 kernel, for comparison)
+  const long ncell_pad = (ncell + KRON_STRIP - 1) / KRON_STRIP * KRON_STRIP;
+  double* cellsum = nullptr;
+  if (!use_atomics) {
+    size_t nout = 0;
+    KRON_DISPATCH(order, { nout = (size_t)KronOut<K>::NOUT; });
+    if (hipMallocAsync(reinterpret_cast<void**>(&cellsum), nout * (size_t)ncell_pad * sizeof(double), st) != hipSuccess) {
+      (void)hipGetLastError();
+      cellsum = nullptr;                              // (no room for the staging buffer: the atomic kernel needs none)
+    }
+  }
+  e = cellsum ? hipMemsetAsync(yy, 0, sizeof(double), st)            // (the gather overwrites every band and rhs entry)
+              : hipMemsetAsync(stats, 0, nd * sizeof(double), st);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); if (cellsum) (void)hipFreeAsync(cellsum, st); return ASVGP_ERR_HIP; }
+  if (cellsum) {
+    const long strips = ncell_pad / KRON_STRIP;
+    static const long kgrid = getenv("ASVGP_KRON_PHI_GRID") ? atol(getenv("ASVGP_KRON_PHI_GRID")) : 512;   // resident workgroups: each walks several strips, the next cell's points in flight
+    const long total = (long)(kron_noff(order) + 1) * Mtot;
+    long gblocks = (total + 255) / 256;
+    if (gblocks > 8192) gblocks = 8192;
+    KRON_DISPATCH(order, {
+      hipLaunchKernelGGL(phi_kron2d_mfma_kernel<K>, dim3((unsigned)(strips < kgrid ? strips : kgrid)), dim3(64 * KRON_STRIP), 0, st, Xs, ys,
+                         reinterpret_cast<const long long*>(cell_start), (int)ncell, (int)ncell_pad, mesh1, 1.0 / delta1, mesh2,
+                         (int)n_mesh2, 1.0 / delta2, cellsum, yy);
+      hipLaunchKernelGGL(phi_kron2d_gather_kernel<K>, dim3((unsigned)gblocks), dim3(256), 0, st, cellsum, (int)ncell_pad, (int)(n_mesh1 - 1),
+                         (int)(n_mesh2 - 1), (int)m1, (int)m2, Ablk, rhs);
+    });
+    (void)hipFreeAsync(cellsum, st);
+    return check_launch("phi_accumulate_kron2d_sorted (matrix-core cell sums + gather)");
+  }
   long blocks = ncell < 4096 ? ncell : 4096;
   KRON_DISPATCH(order, {
     hipLaunchKernelGGL(phi_kron2d_cells_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, st, Xs, ys,

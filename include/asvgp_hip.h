@@ -359,7 +359,12 @@ int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int
 
 /* The same statistics from CELL-SORTED points: Xs, ys are the rows of X, y permuted so that the 2-D cell id
  * c = i1 * (n_mesh2 - 1) + i2 (asvgp_kron_cell_index; basis.py:58-59 per dimension) is non-decreasing, cell_start[c] (int64,
- * n_cells + 1 entries) the first row of cell c.  One global atomic per block-band entry and CELL instead of per point. */
+ * n_cells + 1 entries) the first row of cell c.  A cell's statistics are a small Gram matrix: one wavefront per cell forms it on
+ * the fp64 matrix core (v_mfma_f64_16x16x4 over the (k+1)^2 basis functions, four points per step), the per-cell results go
+ * entry-major into a stream-ordered staging buffer ((k+1)^2 ((k+1)^2 + 3) / 2-ish doubles per cell, hipMallocAsync on `stream`)
+ * and a gather kernel forms every output from the <= (k+1)^2 cells that touch it: no statistic atomics, deterministic sums.
+ * (ASVGP_KRON_PHI_ATOMICS=1 in the environment, or no room for the staging buffer: the per-cell kernel with one global atomic per
+ * block-band entry and cell.) */
 int asvgp_kron_cell_index(const double* X, int64_t N, const double* mesh1, int64_t n_mesh1, double delta1,
                           const double* mesh2, int64_t n_mesh2, double delta2, int* cell, asvgp_stream_t stream);
 int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double* ys, int64_t N, const int64_t* cell_start,

@@ -1,4 +1,5 @@
-"""Config 3 (M = 4096, Matern-5/2, lengthscale 0.005, cond(Kuu) ~ 1e9): band(Kuu^-1) and its lengthscale tangent from the GPU\n(asvgp_kuu_inverse_band_1d, band algorithms 0 and 1) against the fp64 oracle, entry by entry and contracted with A."""
+"""Config 3 (M = 4096, Matern-5/2, lengthscale 0.005, cond(Kuu) ~ 1e9): band(Kuu^-1) and its lengthscale tangent from the GPU
+(asvgp_kuu_inverse_band_1d, band algorithms 0 and 1) against the fp64 oracle, entry by entry and contracted with A."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A
