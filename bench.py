@@ -590,6 +590,58 @@ def main():
             torch.cuda.synchronize()
         except Exception:
             pass
+        # Two more rows of SURVEY section 8 measured in the same process (rank 0, world size 1 only): the streaming posterior over 10M test
+        # points with this model's theta, and BASELINE configs[3]'s shape (2-D Kronecker, N = 1M, 128 x 128, B3) - Phi pass, bound, bound +
+        # gradient.  Not `value`; they put the kernels' figures into the driver's own record.
+        if world == 1:
+            try:
+                pm = new_model(N, overlapped=False)
+                xs = torch.rand(10_000_000, dtype=torch.float64, device="cuda") * 0.998 + 0.001
+                pm.predict_f_device(xs.reshape(-1, 1)); torch.cuda.synchronize()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+                ev[0].record()
+                for i in range(10):
+                    pm.predict_f_device(xs.reshape(-1, 1)); ev[i + 1].record()
+                torch.cuda.synchronize()
+                ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(10))
+                extras["posterior_10m_points"] = {"us_per_call": ts[5], "min_us": ts[0], "bytes_per_point": 24, "achieved_gbs": 24 * 1e7 / (ts[5] * 1e-6) / 1e9,
+                                                  "frac_of_hbm_peak": 24 * 1e7 / (ts[5] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                  "what": "GPR_1d.predict_f_device on 10M i.i.d. test points (8 B in, 16 B out), posterior cached; HIP events around the calls, median of 10"}
+                pm.close(); del pm, xs
+            except Exception as exc:
+                extras["posterior_10m_points_error"] = repr(exc)[:300]
+            try:
+                g = torch.Generator(device="cuda").manual_seed(4321)
+                Xk = torch.rand((1_000_000, 2), dtype=torch.float64, device="cuda", generator=g) * (1 - 2e-6) + 1e-6
+                yk = torch.sin(12 * Xk[:, :1]) * torch.cos(9 * Xk[:, 1:]) + 0.1 * torch.randn((1_000_000, 1), dtype=torch.float64, device="cuda", generator=g)
+                km = A.GPR_kron((Xk, yk), [A.Matern32(variance=1.0, lengthscales=0.2), A.Matern32(variance=1.0, lengthscales=0.2)], [A.B3Spline(0, 1, 128), A.B3Spline(0, 1, 128)])
+                km.likelihood.variance.assign(0.01)
+
+                def med(f, n=5):
+                    f(); torch.cuda.synchronize()
+                    out = []
+                    for _ in range(n):
+                        t0 = time.perf_counter(); f(); torch.cuda.synchronize(); out.append(time.perf_counter() - t0)
+                    return sorted(out)[n // 2]
+                km.phi_pass(); torch.cuda.synchronize()
+                evk = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+                evk[0].record()
+                for i in range(10):
+                    km.phi_pass(); evk[i + 1].record()
+                torch.cuda.synchronize()
+                tk = sorted(evk[i].elapsed_time(evk[i + 1]) * 1e3 for i in range(10))
+                extras["kronecker_config4_shape"] = {"N": 1_000_000, "basis": "B3Spline 128 x 128 (M_tot = 16384, bandwidth 387)", "dtype": "f64",
+                                                     "phi_pass_us": tk[5], "elbo_ms": med(lambda: km.elbo().item()) * 1e3,
+                                                     "elbo_and_grad_ms": med(km.elbo_and_grad) * 1e3, "elbo": float(km.elbo().item()),
+                                                     "factorisation": "two-sided" if km._twist_layout() else "one-sided",
+                                                     "what": "phi_pass_us: HIP events around the pass (cell-sorted points: matrix-core cell sums + gather), median of 10; elbo / elbo_and_grad: wall clock per call incl. the host-side result read, median of 5 (tools/kron_probe.py measures the same)"}
+                del km, Xk, yk
+            except Exception as exc:
+                extras["kronecker_config4_shape_error"] = repr(exc)[:300]
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
 
     # Extra, N > 1 only: the one-at-a-time step with the BASELINE N on EVERY rank (weak scaling).  `value` stays the strong-scaling figure
     # the metric is quoted on; this field only shows what the replicated band chains cost in the other regime.
@@ -700,6 +752,9 @@ def main():
                         "step (sorted input, small shards); on the unsorted headline the N side bounds and the extra host calls cost more than they save"}
         if "dependent_steps_launch_ahead_error" in extras:
             line["dependent_steps_launch_ahead_error"] = extras["dependent_steps_launch_ahead_error"]
+        for key in ("posterior_10m_points", "posterior_10m_points_error", "kronecker_config4_shape", "kronecker_config4_shape_error"):
+            if key in extras:
+                line[key] = extras[key]
         if "emulated_shard" in extras:
             es = {}
             for div, e in extras["emulated_shard"].items():
