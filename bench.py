@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--phi-workgroups", type=int, default=240, help="Phi grid of the overlapped schedules (the chain workgroups need free CUs)")
     ap.add_argument("--no-three-sets", action="store_true", help="skip the extra dependent schedule with three buffer sets")
     ap.add_argument("--worker-forward", action="store_true", help="dependent schedules: the host forward pass of the Kuu chain on the handle's worker thread (asvgp_set_deferred_forward_pass(h, 2))")
+    ap.add_argument("--value-launch-ahead", type=int, default=0, help="1: the two-set dependent schedule (`value`) with the ELBO launch enqueued ahead of theta")
+    ap.add_argument("--reduce-stream", type=int, default=0, help="1: the Phi pass's cross-workgroup reduce on a third stream in the two-set dependent schedule")
     ap.add_argument("--no-launch-ahead", action="store_true", help="dependent schedules: launch the ELBO kernel only once theta is known (round 3's order) instead of ahead of it")
     ap.add_argument("--no-mirror", action="store_true", help="dependent schedule: read results through the stream (D2H copy + sync) instead of the pinned mirror")
     ap.add_argument("--kernel-events", type=int, default=5, help="HIP events around every n-th Phi kernel launch")
@@ -390,7 +392,7 @@ def main():
     # Streams are made once and shared by every schedule of this process: HIP maps streams onto a handful of hardware queues round robin,
     # and a schedule whose N-side and M-side streams land on the SAME queue runs them in series (measured: the third or fourth schedule
     # of a process took 100-130 us per step instead of 72, its Phi kernel "70 us" - waiting behind the ELBO launch).
-    stream_pool = {"n": torch.cuda.Stream(), "m": torch.cuda.Stream(priority=-1), "m2": torch.cuda.Stream(priority=-1)}
+    stream_pool = {"n": torch.cuda.Stream(), "m": torch.cuda.Stream(priority=-1), "m2": torch.cuda.Stream(priority=-1), "r": torch.cuda.Stream()}
 
     def dependent_schedule(n_sets, n_points=None, prior_forward=0, launch_ahead_mode=False):
         lanes = [new_model(N, overlapped=True, defer=(n_sets == 2), n_points=n_points, prior_forward=prior_forward) for _ in range(n_sets)]
@@ -398,6 +400,10 @@ def main():
             for ln in lanes:
                 ln._h.set_deferred_forward_pass(2)                 # the handle's worker thread runs the host forward pass (measured: no gain in this order)
         s_n, s_m = stream_pool["n"], stream_pool["m"]              # (made ONCE: see stream_pool)
+        # --reduce-stream: the cross-workgroup reduce (+ all-reduce) of a set goes to a THIRD stream behind its Phi kernel, so that the Phi kernel
+        # of the next step is not queued behind it (the reduce is 784 small workgroups that fit beside the Phi kernel's one workgroup per CU)
+        s_r = stream_pool["r"] if (args.reduce_stream and n_sets == 2) else s_n
+        ev_phi = [torch.cuda.Event() for _ in range(n_sets)]
         ev_stats = [torch.cuda.Event() for _ in range(n_sets)]
         ahead = n_sets - 1
         state = {"i": 0, "theta": theta0, "primed": False, "last": None, "t_a": 0.0, "t_b": 0.0, "t_poll": 0.0, "n": 0}
@@ -405,14 +411,18 @@ def main():
         def n_side_kernel(k):                                      # Phi pass (two sets: the streaming kernel alone, its reduce parked)
             _lib.set_stream(s_n)
             lanes[k].phi_pass(allreduce=False)
+            if s_r is not s_n:
+                ev_phi[k].record(s_n)
 
         def n_side_rest(k):                                        # reduce (if parked), [all-reduce], "statistics complete"
-            _lib.set_stream(s_n)
+            if s_r is not s_n:
+                s_r.wait_event(ev_phi[k])
+            _lib.set_stream(s_r)
             lanes[k].phi_reduce()                                  # (a no-op when nothing is parked)
             if world > 1:
-                with torch.cuda.stream(s_n):
+                with torch.cuda.stream(s_r):
                     dist.all_reduce(lanes[k]._stats, op=dist.ReduceOp.SUM)
-            ev_stats[k].record(s_n)
+            ev_stats[k].record(s_r)
 
         ahead_ok = launch_ahead_mode and not args.no_launch_ahead and not args.no_mirror and not prior_forward and not args.worker_forward
         if ahead_ok:
@@ -497,7 +507,7 @@ def main():
     dep, dep_error, dep3, dep3_error = None, None, None, None
     for n_sets in ((2,) if args.no_three_sets else (2, 3)):
         try:
-            res = dependent_schedule(n_sets)
+            res = dependent_schedule(n_sets, launch_ahead_mode=bool(args.value_launch_ahead) and n_sets == 2)
             if n_sets == 2:
                 dep = res
             else:
