@@ -861,31 +861,42 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
 
     def _selinv_twisted(self, f):
         """The same recursion run OUTWARDS from the separator in both systems at once (batch of two): Sigma_ss = S^-1 seeds the top
-        stack, its reversal the bottom stack; nb - 1 dependent steps instead of ceil(M / Bb) - 1.  alpha = P^-1 c / s likewise."""
+        stack, its reversal the bottom stack; nb - 1 dependent steps instead of ceil(M / Bb) - 1.  alpha = P^-1 c / s likewise.
+        Three launches per step: N_i = Sigma_{i+1,i+1} G_i (= -Sigma_{i+1,i}), Sigma_ii = D_i^-1 + G_i^T N_i and
+        alpha_i = L_i^-T y_i - G_i^T alpha_{i+1} (the triangular-solve form needs L_{i+1,i}^T alpha_{i+1} first: two more products)."""
         lay, s, M = f["twist"], f["s"], self.Mtot
         Bb, nb, top_end, padt, padb = lay["Bb"], lay["nb"], lay["top_end"], lay["padt"], lay["padb"]
         diag, sub = f["diag"], f["sub"]
+        dev = diag.device
+        f64 = dict(dtype=torch.float64, device=dev)
         eye = self._twist_cache["eye"]
         Linv = torch.linalg.solve_triangular(diag[:, :nb - 1], eye.expand(2, nb - 1, Bb, Bb), upper=False)
-        Dinv = Linv.transpose(-1, -2) @ Linv
-        G = sub @ Linv                                            # G_i = L_{i+1,i} L_ii^-1
+        LinvT = Linv.transpose(-1, -2)
+        Dinv = (LinvT @ Linv).transpose(0, 1).contiguous()       # step-major [nb-1][2][Bb][Bb]: a step's operands are one contiguous batch
+        Gs = (sub @ Linv).transpose(0, 1).contiguous()            # G_i = L_{i+1,i} L_ii^-1
+        GsT = Gs.transpose(-1, -2)
+        yb = torch.stack((f["y_top"], f["y_bot"])).view(2, nb, Bb) / s
+        Wv = (LinvT @ yb[:, :nb - 1].unsqueeze(-1)).transpose(0, 1).contiguous()        # L_i^-T y_i, [nb-1][2][Bb][1]
         LSinv = torch.linalg.solve_triangular(f["L_S"], eye, upper=False)
         Sig_ss = LSinv.t() @ LSinv
-        SigD = torch.empty((2, nb, Bb, Bb), dtype=torch.float64, device=diag.device)
-        SigS = torch.empty((2, nb - 1, Bb, Bb), dtype=torch.float64, device=diag.device)
-        SigD[0, nb - 1] = Sig_ss
-        SigD[1, nb - 1] = Sig_ss.flip(0, 1)
+        SigDs = torch.empty((nb, 2, Bb, Bb), **f64)
+        Ns = torch.empty((nb - 1, 2, Bb, Bb), **f64)
+        abs_ = torch.empty((nb, 2, Bb, 1), **f64)
+        SigDs[nb - 1, 0] = Sig_ss
+        SigDs[nb - 1, 1] = Sig_ss.flip(0, 1)
         a_s = LSinv.t() @ (f["y_S"] / s)
-        yb = torch.stack((f["y_top"], f["y_bot"])).view(2, nb, Bb) / s
-        ab = torch.empty_like(yb)
-        ab[0, nb - 1] = a_s
-        ab[1, nb - 1] = a_s.flip(0)
+        abs_[nb - 1, 0, :, 0] = a_s
+        abs_[nb - 1, 1, :, 0] = a_s.flip(0)
         for i in range(nb - 2, -1, -1):
-            SigS[:, i] = -(SigD[:, i + 1] @ G[:, i])
-            SigD[:, i] = Dinv[:, i] - G[:, i].transpose(-1, -2) @ SigS[:, i]
-            t = yb[:, i] - (sub[:, i].transpose(-1, -2) @ ab[:, i + 1].unsqueeze(-1)).squeeze(-1)
-            ab[:, i] = (Linv[:, i].transpose(-1, -2) @ t.unsqueeze(-1)).squeeze(-1)
-        alpha = torch.empty(M, dtype=torch.float64, device=diag.device)
+            torch.bmm(SigDs[i + 1], Gs[i], out=Ns[i])
+            torch.baddbmm(Dinv[i], GsT[i], Ns[i], out=SigDs[i])
+            torch.baddbmm(Wv[i], GsT[i], abs_[i + 1], alpha=-1.0, out=abs_[i])
+        SigD = SigDs.transpose(0, 1).contiguous()
+        SigS = Ns.transpose(0, 1).neg()                           # (contiguous result: Sigma_{i+1,i} = -N_i)
+        if not SigS.is_contiguous():
+            SigS = SigS.contiguous()
+        ab = abs_.squeeze(-1).transpose(0, 1).contiguous()
+        alpha = torch.empty(M, **f64)
         alpha[:top_end] = ab[0].reshape(-1)[padt:]
         alpha[top_end:] = ab[1].reshape(-1)[padb:padb + (M - top_end)].flip(0)
         f["alpha"] = alpha
