@@ -643,6 +643,7 @@ typedef double bb_d4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long bbp_stamps[32];   // diagnostic: s_memtime stamps of block column ASVGP_BB_STAMP_COL (tools/bbp_stamps.py)
 #define BBP_STAMP(k) do { if (stamp_col == c && tid == 0) bbp_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
 constexpr int BBP_THREADS = 256;
+constexpr int BBP_NWK = BBP_THREADS / 64 - 1;      // worker waves (wave 0 owns the diagonal block): row tile rt belongs to wave 1 + (rt - 2) % BBP_NWK
 __host__ __device__ inline int bbp_row_tiles(int bw) { return (BB_NB + bw + 15) / 16; }               // 16-row tiles of a panel
 __host__ __device__ inline int bbp_rs(int bw) { return bbp_row_tiles(bw) * 16 + 1; }                  // LDS column stride (odd: bank spread)
 __host__ inline size_t bbp_lds_bytes(int bw) { return sizeof(double) * ((size_t)BB_NB * bbp_rs(bw) + 2 * BB_NB * (BB_NB + 1) + 2 * BB_NB + 16 * 17 + 8); }
@@ -681,7 +682,10 @@ __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, d
   // element (r, p0 + q) of the band sits at Pp[q * (LD - 1) + r]
   const double* __restrict__ Pp = Pb + p0 * (LD - 1);
   const int dj = (int)(j0 - p0);                      // 32 .. 32 * PMAX
-  double breg[2][8];
+  // Every load of the B operand (and of y) is ISSUED before the first value is used: written as one loop, hipcc waited for each pair of
+  // loads before issuing the next (s_waitcnt vmcnt(0) eight times in a row) - eight round trips to memory another CU has just written,
+  // 19 K cycles of the diagonal chain's update by block column c-1 (tools/bbp_stamps.py).
+  double breg[2][8], yreg[8];
 #pragma unroll
   for (int s8 = 0; s8 < 8; ++s8) {
     const int q = 4 * s8 + lg;
@@ -690,22 +694,48 @@ __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, d
     for (int ct = 0; ct < 2; ++ct) {
       const int n = 16 * ct + ln;
       const bool ok = n < nbk && dj + n - q <= bw;
-      const double v = FAST ? bq[16 * ct] : ((ok) ? bq[16 * ct] : 0.0);
-      breg[ct][s8] = ok ? v : 0.0;
+      breg[ct][s8] = FAST ? bq[16 * ct] : ((ok) ? bq[16 * ct] : 0.0);
+    }
+    yreg[s8] = (RHS_ROW && rhs) ? rhs[p0 + 4 * s8 + lg] : 0.0;
+  }
+  // ... and so is the first group of A operands (the only group of the diagonal wave: one round trip for the whole update)
+  constexpr int GT = (NT < 4) ? NT : ((NT % 3 == 0) ? 3 : 4);
+  constexpr bool HOIST = NT <= 2;                       // (the worker waves' nine tiles: 24 more live registers spill)
+  double araw[HOIST ? GT : 1][8];
+  if (HOIST) {
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int q = 4 * s8 + lg;
+      const double* __restrict__ aq = Pp + (long)q * (LD - 1) + j0 + 16 * R0 + ln;
+#pragma unroll
+      for (int u = 0; u < (HOIST ? GT : 1); ++u) {
+        const int rl = 16 * (R0 + ST * u) + ln;
+        const bool ok = (FAST || j0 + rl < M) && dj + rl - q <= bw;
+        araw[u][s8] = FAST ? aq[16 * ST * u] : (ok ? aq[16 * ST * u] : 0.0);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    const int q = 4 * s8 + lg;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int n = 16 * ct + ln;
+      const bool ok = n < nbk && dj + n - q <= bw;
+      breg[ct][s8] = ok ? breg[ct][s8] : 0.0;
     }
   }
   if (RHS_ROW && rhs) {
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
-      const double yv = rhs[p0 + 4 * s8 + lg];
-      tacc0 = fma(breg[0][s8], yv, tacc0);
-      tacc1 = fma(breg[1][s8], yv, tacc1);
+      tacc0 = fma(breg[0][s8], yreg[s8], tacc0);
+      tacc1 = fma(breg[1][s8], yreg[s8], tacc1);
     }
   }
   // A operands in groups of up to 4 row tiles: the group's 32 loads are in flight before its first MFMA waits (with a branch per
   // tile the loads of tile t+1 were issued after the MFMAs of tile t; all tiles at once spill)
   const long r_last = p0 + BB_NB - 1 + bw;            // last row of block column p
-  constexpr int GT = (NT < 4) ? NT : ((NT % 3 == 0) ? 3 : 4);
 #pragma unroll
   for (int g0 = 0; g0 < NT; g0 += GT) {
     double areg[GT][8];
@@ -719,7 +749,7 @@ __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, d
         if (t < NT) {
           const int rl = 16 * (R0 + ST * t) + ln;     // row inside the panel window
           const bool ok = (FAST || j0 + rl < M) && dj + rl - q <= bw;
-          const double v = FAST ? aq[16 * ST * t] : (ok ? aq[16 * ST * t] : 0.0);
+          const double v = (HOIST && g0 == 0) ? araw[HOIST ? u : 0][s8] : (FAST ? aq[16 * ST * t] : (ok ? aq[16 * ST * t] : 0.0));
           areg[u][s8] = ok ? -v : 0.0;
         }
       }
@@ -793,8 +823,9 @@ __device__ __forceinline__ void bbp_acc_store(const bb_d4 (&acc)[NT][2], double*
   }
 }
 
-// Work split inside the workgroup (4 waves): wave 0 owns the two row tiles of the DIAGONAL block, waves 1..3 the tiles below it
-// (rt = 1 + w, 4 + w, ...: NTW each).  After the update by block column c-1 - the one a column has to wait for - wave 0 goes
+// Work split inside the workgroup (BBP_THREADS / 64 = 4 waves; 8 were measured in round 4 - the second wave on wave 0's SIMD slows the
+// single-wave diagonal chain: factor 17 K -> 23 K cycles, bound 7.8 -> 8.5 ms): wave 0 owns the two row tiles of the DIAGONAL block, waves 1..3 the tiles below it
+// (rt = 1 + w, 1 + w + BBP_NWK, ...: NTW each).  After the update by block column c-1 - the one a column has to wait for - wave 0 goes
 // straight to the factorisation of the diagonal block while the others are still on the matrix cores.
 template <int NTW>
 __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double* __restrict__ Pb, long M, int bw, long LD,
@@ -809,7 +840,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
   double* Tt = ys + 2 * BB_NB;                        // [16][17] product staging of the block inverse
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lg = lane >> 4;
   const int PMAX = (BB_NB - 1 + bw) / BB_NB;          // block columns to the left that reach a panel
-  const int R0 = 1 + wv;                              // first row tile of waves 1..3 (stride 3)
+  const int R0 = 1 + wv;                              // first row tile of waves 1..BBP_NWK (stride BBP_NWK)
   // done[0]: block columns completely finished.  done[16]: "early" arrivals, two per block column - the first row tile of wave 1
   // (rt = 2) and of wave 2 (rt = 3), i.e. rows j0+32 .. j0+63: all that the DIAGONAL block of the next column needs of this one.
   // Wave 0 of column c therefore starts its last update, the factorisation and the inverse as soon as column c-1 has published
@@ -825,7 +856,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
     // short last block) -> accumulators in the MFMA C layout.  (Masked loads straight into the C layout needed 112 live exec masks
     // per lane: 700 spilled SGPRs and 200 spilled VGPRs.)
     const int RW = 16 * R16;
-    for (int col = wv; col < BB_NB; col += 4) {       // one column per wave and pass, lanes along the rows
+    for (int col = wv; col < BB_NB; col += BBP_THREADS / 64) {       // one column per wave and pass, lanes along the rows
       const double* __restrict__ src = Pb + (j0 + col) * LD - col;      // element (j0 + rl, j0 + col) at src[rl]
 #pragma unroll 4
       for (int rl = lane; rl < RW; rl += 64) {
@@ -842,7 +873,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       int lno = ln, lgo = lg;
       asm volatile("" : "+v"(lno), "+v"(lgo));
       if (wv == 0) bbp_acc_load<2, 1>(accd, Pan, RS, R16, 0, lno, lgo);
-      else bbp_acc_load<NTW, 3>(acc, Pan, RS, R16, R0, lno, lgo);
+      else bbp_acc_load<NTW, BBP_NWK>(acc, Pan, RS, R16, R0, lno, lgo);
     }
     __syncthreads();                                  // (the window is rewritten after the updates)
     double tacc0 = 0.0, tacc1 = 0.0;
@@ -859,8 +890,8 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
         if (interior) bbp_update<2, 1, true, true>(accd, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, 0, ln, lg);
         else bbp_update<2, 1, false, true>(accd, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, 0, ln, lg);
       } else {
-        if (interior) bbp_update<NTW, 3, true, false>(acc, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, R0, ln, lg);
-        else bbp_update<NTW, 3, false, false>(acc, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, R0, ln, lg);
+        if (interior) bbp_update<NTW, BBP_NWK, true, false>(acc, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, R0, ln, lg);
+        else bbp_update<NTW, BBP_NWK, false, false>(acc, tacc0, tacc1, Pb, rhs, M, bw, LD, j0, p0, nbk, R16, R0, ln, lg);
       }
     }
     BBP_STAMP(3);
@@ -912,6 +943,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) Ld[r * (BB_NB + 1) + cc] = (cc <= r) ? a[cc] : 0.0;
       }
+      BBP_STAMP(13);
       {   // D22 (C layout of the 16 x 16 tile) -= L21 L21^T
         bb_d4 c22;
 #pragma unroll
@@ -924,6 +956,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
 #pragma unroll
         for (int i = 0; i < 4; ++i) Pan[(size_t)(16 + ln) * RS + 16 + lg + 4 * i] = c22[i];
       }
+      BBP_STAMP(14);
       double b2[16];
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) b2[cc] = (r >= 16 && 16 + cc <= r) ? Pan[(size_t)(16 + cc) * RS + r] : 0.0;
@@ -972,6 +1005,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
           }
         }
       }
+      BBP_STAMP(10);
       {   // lower-left block: -L22^-1 (L21 L11^-1)
         bb_d4 T = {0.0, 0.0, 0.0, 0.0}, U = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -985,22 +1019,26 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
 #pragma unroll
         for (int i = 0; i < 4; ++i) Li[(16 + lg + 4 * i) * (BB_NB + 1) + ln] = -U[i];
       }
-      // the diagonal block itself back to the band
-      for (int idx = lane; idx < BB_NB * BB_NB; idx += 64) {
-        const int rr = idx % BB_NB, cc = idx / BB_NB;
-        if (rr >= cc && rr < nbk && cc < nbk && rr - cc <= bw) Pb[(j0 + cc) * LD + (rr - cc)] = Ld[rr * (BB_NB + 1) + cc];
-      }
+      BBP_STAMP(11);
     } else {
       int lno = ln, lgo = lg;
       asm volatile("" : "+v"(lno), "+v"(lgo));
-      bbp_acc_store<NTW, 3>(acc, Pan, RS, R16, R0, lno, lgo);    // (the A operands of the solve are read back in another lane map)
+      bbp_acc_store<NTW, BBP_NWK>(acc, Pan, RS, R16, R0, lno, lgo);    // (the A operands of the solve are read back in another lane map)
     }
+    BBP_STAMP(12);
     __syncthreads();
     BBP_STAMP(6);
     // ---- rows below the diagonal block (waves 1..3): X = Pan Linv^T on the matrix cores, stored straight from the C layout
     // (16 lanes = 16 columns of the band per row: scattered 32-byte pieces, but fire-and-forget; a second pass through the LDS
     // for row-contiguous stores cost a barrier and 13 K cycles of write-completion wait on the critical path)
-    if (wv != 0) {
+    if (wv == 0) {
+      // the diagonal block itself back to the band - AFTER the barrier that releases the other waves into the solve: nothing on this
+      // workgroup's chain reads it from the band (4.6 K cycles that sat between the inverse and the early tiles)
+      for (int idx = lane; idx < BB_NB * BB_NB; idx += 64) {
+        const int rr = idx % BB_NB, cc = idx / BB_NB;
+        if (rr >= cc && rr < nbk && cc < nbk && rr - cc <= bw) Pb[(j0 + cc) * LD + (rr - cc)] = Ld[rr * (BB_NB + 1) + cc];
+      }
+    } else {
       int ln = lane & 15, lg = lane >> 4;             // re-derived per block column and made opaque: the LDS / band addresses below are
       asm volatile("" : "+v"(ln), "+v"(lg));          // loop invariants otherwise, get hoisted out of the column loop, spilled, and come back
                                                       // through scratch loads each followed by s_waitcnt vmcnt(0) (43 K cycles for this phase)
@@ -1018,13 +1056,13 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
         double av[GS][8];                             // a group's A operands first (LDS latency once per group)
 #pragma unroll
         for (int u = 0; u < GS; ++u) {
-          const int rt = (g0 + u < NTW && R0 + 3 * (g0 + u) < R16) ? R0 + 3 * (g0 + u) : 2;
+          const int rt = (g0 + u < NTW && R0 + BBP_NWK * (g0 + u) < R16) ? R0 + BBP_NWK * (g0 + u) : 2;
 #pragma unroll
           for (int s8 = 0; s8 < 8; ++s8) av[u][s8] = Pan[(size_t)(4 * s8 + lg) * RS + 16 * rt + ln];
         }
 #pragma unroll
         for (int u = 0; u < GS; ++u) {
-          const int rt = R0 + 3 * (g0 + u);
+          const int rt = R0 + BBP_NWK * (g0 + u);
           if (g0 + u < NTW && rt < R16 && j0 + 16 * rt < M) {
             bb_d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1037,8 +1075,8 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const int col = 16 * ct + ln, rl = 16 * rt + lg + 4 * i;
-                // element (j0 + rl, j0 + col) = xb[ct][16 * 3 * (g0 + u) + 4 i]: two base pointers per lane, immediate offsets
-                if (col < nbk && j0 + rl < M && rl - col <= bw) xb[ct][48 * (g0 + u) + 4 * i] = (ct == 0) ? x0[i] : x1[i];
+                // element (j0 + rl, j0 + col) = xb[ct][16 * BBP_NWK * (g0 + u) + 4 i]: two base pointers per lane, immediate offsets
+                if (col < nbk && j0 + rl < M && rl - col <= bw) xb[ct][16 * BBP_NWK * (g0 + u) + 4 * i] = (ct == 0) ? x0[i] : x1[i];
               }
           }
           if (g0 + u == 0 && wv <= 2) {               // rows j0+32 .. j0+63 are in the band (or do not exist): early arrival
@@ -1468,7 +1506,7 @@ extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, doubl
     const int nbc = (int)((M + BB_NB - 1) / BB_NB);
     const int G = nbc < 16 ? nbc : 16;
     const size_t lds_bytes = bbp_lds_bytes((int)bw);
-    const int ntw = (R16 - 2 + 2) / 3;                  // row tiles below the diagonal block per wave (waves 1..3)
+    const int ntw = (R16 - 2 + BBP_NWK - 1) / BBP_NWK;  // row tiles below the diagonal block per wave (waves 1..BBP_NWK)
     static const int stamp_col = getenv("ASVGP_BB_STAMP_COL") ? atoi(getenv("ASVGP_BB_STAMP_COL")) : -1;
 #define BBP_LAUNCH(NTW)                                                                                                              \
     {                                                                                                                                \
