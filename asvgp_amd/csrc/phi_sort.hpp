@@ -258,12 +258,6 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
     }
   }
   unsigned nbad = 0;
-  {   // the host chose this kernel from its copy of the mesh; a table that is NOT that linspace here is reported loudly
-    bool okm = true;
-    for (int i = tid; i < n_mesh - 1; i += PS_THREADS) okm = okm && (mesh[i] == mq_linspace_knot(i, step, m0));
-    if (tid == 0) okm = okm && mesh[n_mesh - 1] == m_last;
-    if (!okm) ++nbad;
-  }
   auto knot = [&](int i) __attribute__((always_inline)) -> double { return (i == n_mesh - 1) ? m_last : mq_linspace_knot(i, step, m0); };
   // Exact table rule (basis.py:58-59: idx = max(#{mesh < x} - 1, 0)) for the rare point within rounding of a knot or outside the mesh.
   // On a linspace the arithmetic guess is off by at most one cell for a point of [a, b]: one step either way, then the rule is
@@ -406,6 +400,18 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
   };
 
   load_tile(0);
+  {   // the host chose this kernel from its copy of the mesh; a table that is NOT that linspace here is reported loudly.  (Behind the first
+      // tile's loads: in front of them its two dependent reads of the table were two memory round trips before anything streamed.)
+    int okm = 1;                                                  // (no short circuit, no branch: a load must not wait for a comparison before it)
+    const double last_v = mesh[n_mesh - 1];
+    const int i0 = tid < n_mesh - 1 ? tid : 0, i1 = tid + PS_THREADS < n_mesh - 1 ? tid + PS_THREADS : 0;
+    const double v0 = mesh[i0], v1 = mesh[i1];
+    okm &= (v0 == mq_linspace_knot(i0, step, m0)) ? 1 : 0;
+    okm &= (v1 == mq_linspace_knot(i1, step, m0)) ? 1 : 0;
+    okm &= (last_v == m_last) ? 1 : 0;
+    for (int i = tid + 2 * PS_THREADS; i < n_mesh - 1; i += PS_THREADS) okm &= (mesh[i] == mq_linspace_knot(i, step, m0)) ? 1 : 0;   // (more than 2049 knots: not with M <= 2048)
+    if (!okm) ++nbad;
+  }
   __syncthreads();
   int tile = 0;
   // ---- TIME-SERIES FRONT LOOP (sorted / time-series input; SURVEY 8d's secondary case, the order of the reference's own large 1-D data,
