@@ -782,8 +782,8 @@ __device__ __forceinline__ bool bbp_wait(unsigned& seen, unsigned target, const 
   int ok = 1;
   if (lane == 0) {
     long spins = 0;
-    while ((v = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-      __builtin_amdgcn_s_sleep(2);
+    while ((v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {   // (ONE acquire fence, behind the loop)
+      __builtin_amdgcn_s_sleep(8);
       if ((++spins & 1023) == 0 && (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1L << 25))) {
         __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
@@ -1080,8 +1080,8 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
               }
           }
           if (g0 + u == 0 && wv <= 2) {               // rows j0+32 .. j0+63 are in the band (or do not exist): early arrival
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_fetch_add(early, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // (the wave's stores; the counter itself then needs no second write-back)
+            if (lane == 0) __hip_atomic_fetch_add(early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
     BBP_STAMP(8);
     if (tid == 0) {
       __threadfence();
-      __hip_atomic_store(done, (unsigned)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     BBP_STAMP(9);
   }
