@@ -642,8 +642,11 @@ __global__ __launch_bounds__(256) void bb_update_kernel(double* __restrict__ Pb,
 typedef double bb_d4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long bbp_stamps[32];   // diagnostic: s_memtime stamps of block column ASVGP_BB_STAMP_COL (tools/bbp_stamps.py)
 #define BBP_STAMP(k) do { if (stamp_col == c && tid == 0) bbp_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
-constexpr int BBP_THREADS = 256;
-constexpr int BBP_NWK = BBP_THREADS / 64 - 1;      // worker waves (wave 0 owns the diagonal block): row tile rt belongs to wave 1 + (rt - 2) % BBP_NWK
+constexpr int BBP_THREADS = 512;
+// Eight waves: wave 0 owns the diagonal block and keeps its SIMD to itself - wave 4, which the hardware places on the same SIMD, only
+// loads the panel and takes the barriers (a second busy wave there stretches the single-wave elimination from 17 K to 23 K cycles) -
+// and the six others (1, 2, 3, 5, 6, 7) are the workers: worker index widx = 0..5, row tile rt belongs to worker (rt - 2) % BBP_NWK.
+constexpr int BBP_NWK = 6;
 __host__ __device__ inline int bbp_row_tiles(int bw) { return (BB_NB + bw + 15) / 16; }               // 16-row tiles of a panel
 __host__ __device__ inline int bbp_rs(int bw) { return bbp_row_tiles(bw) * 16 + 1; }                  // LDS column stride (odd: bank spread)
 __host__ inline size_t bbp_lds_bytes(int bw) { return sizeof(double) * ((size_t)BB_NB * bbp_rs(bw) + 2 * BB_NB * (BB_NB + 1) + 2 * BB_NB + 16 * 17 + 8); }
@@ -699,7 +702,7 @@ __device__ __forceinline__ void bbp_update(bb_d4 (&acc)[NT][2], double& tacc0, d
     yreg[s8] = (RHS_ROW && rhs) ? rhs[p0 + 4 * s8 + lg] : 0.0;
   }
   // ... and so is the first group of A operands (the only group of the diagonal wave: one round trip for the whole update)
-  constexpr int GT = (NT < 4) ? NT : ((NT % 3 == 0) ? 3 : 4);
+  constexpr int GT = (NT < 4) ? NT : 3;                 // (groups of three row tiles: four need 16 more registers than 256 leave)
   constexpr bool HOIST = NT <= 2;                       // (the worker waves' nine tiles: 24 more live registers spill)
   double araw[HOIST ? GT : 1][8];
   if (HOIST) {
@@ -840,7 +843,9 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
   double* Tt = ys + 2 * BB_NB;                        // [16][17] product staging of the block inverse
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, lg = lane >> 4;
   const int PMAX = (BB_NB - 1 + bw) / BB_NB;          // block columns to the left that reach a panel
-  const int R0 = 1 + wv;                              // first row tile of waves 1..BBP_NWK (stride BBP_NWK)
+  const int widx = wv < 4 ? wv - 1 : wv - 2;          // worker index of waves 1, 2, 3, 5, 6, 7 (wave 0: the diagonal block; wave 4: idle)
+  const bool worker = wv != 0 && wv != 4;
+  const int R0 = 2 + widx;                            // first row tile of a worker (stride BBP_NWK)
   // done[0]: block columns completely finished.  done[16]: "early" arrivals, two per block column - the first row tile of wave 1
   // (rt = 2) and of wave 2 (rt = 3), i.e. rows j0+32 .. j0+63: all that the DIAGONAL block of the next column needs of this one.
   // Wave 0 of column c therefore starts its last update, the factorisation and the inverse as soon as column c-1 has published
@@ -873,14 +878,14 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
       int lno = ln, lgo = lg;
       asm volatile("" : "+v"(lno), "+v"(lgo));
       if (wv == 0) bbp_acc_load<2, 1>(accd, Pan, RS, R16, 0, lno, lgo);
-      else bbp_acc_load<NTW, BBP_NWK>(acc, Pan, RS, R16, R0, lno, lgo);
+      else if (worker) bbp_acc_load<NTW, BBP_NWK>(acc, Pan, RS, R16, R0, lno, lgo);
     }
     __syncthreads();                                  // (the window is rewritten after the updates)
     double tacc0 = 0.0, tacc1 = 0.0;
     bool gave_up = false;
     BBP_STAMP(1);
     // ---- updates from the finished block columns that reach this one
-    for (int p = (c > PMAX) ? c - PMAX : 0; p < c; ++p) {
+    for (int p = (c > PMAX) ? c - PMAX : 0; p < c && wv != 4; ++p) {
       const bool arrived = (wv == 0 && p == c - 1) ? bbp_wait(seen_early, 2u * (unsigned)c, early, done + 24, lane)
                                                    : bbp_wait(seen, (unsigned)(p + 1), done, done + 24, lane);
       if (!arrived) gave_up = true;                   // (wave-uniform; the column is finished with whatever is there and flagged)
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
         for (int i = 0; i < 4; ++i) Li[(16 + lg + 4 * i) * (BB_NB + 1) + ln] = -U[i];
       }
       BBP_STAMP(11);
-    } else {
+    } else if (worker) {
       int lno = ln, lgo = lg;
       asm volatile("" : "+v"(lno), "+v"(lgo));
       bbp_acc_store<NTW, BBP_NWK>(acc, Pan, RS, R16, R0, lno, lgo);    // (the A operands of the solve are read back in another lane map)
@@ -1038,7 +1043,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
         const int rr = idx % BB_NB, cc = idx / BB_NB;
         if (rr >= cc && rr < nbk && cc < nbk && rr - cc <= bw) Pb[(j0 + cc) * LD + (rr - cc)] = Ld[rr * (BB_NB + 1) + cc];
       }
-    } else {
+    } else if (worker) {
       int ln = lane & 15, lg = lane >> 4;             // re-derived per block column and made opaque: the LDS / band addresses below are
       asm volatile("" : "+v"(ln), "+v"(lg));          // loop invariants otherwise, get hoisted out of the column loop, spilled, and come back
                                                       // through scratch loads each followed by s_waitcnt vmcnt(0) (43 K cycles for this phase)
@@ -1079,7 +1084,7 @@ __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double*
                 if (col < nbk && j0 + rl < M && rl - col <= bw) xb[ct][16 * BBP_NWK * (g0 + u) + 4 * i] = (ct == 0) ? x0[i] : x1[i];
               }
           }
-          if (g0 + u == 0 && wv <= 2) {               // rows j0+32 .. j0+63 are in the band (or do not exist): early arrival
+          if (g0 + u == 0 && widx <= 1) {             // rows j0+32 .. j0+63 are in the band (or do not exist): early arrival
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // (the wave's stores; the counter itself then needs no second write-back)
             if (lane == 0) __hip_atomic_fetch_add(early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -1515,7 +1520,7 @@ extern "C" int asvgp_blockband_cholesky(double* Pb, int64_t M, int64_t bw, doubl
       if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); (void)hipFreeAsync(done, st); return ASVGP_ERR_LDS_CAPACITY; } \
       hipLaunchKernelGGL(bb_chol_persistent_kernel<NTW>, dim3(G), dim3(BBP_THREADS), lds_bytes, st, Pb, (long)M, (int)bw, LD, rhs, info, done, nbc, stamp_col); \
     }
-    if (ntw <= 3) BBP_LAUNCH(3) else if (ntw <= 6) BBP_LAUNCH(6) else BBP_LAUNCH(9)
+    if (ntw <= 3) BBP_LAUNCH(3) else BBP_LAUNCH(5)      // (R16 <= 29: at most 27 tiles below the diagonal block, 5 per worker wave)
 #undef BBP_LAUNCH
     (void)hipFreeAsync(done, st);
   } else
