@@ -826,10 +826,12 @@ __device__ __forceinline__ void bbp_acc_store(const bb_d4 (&acc)[NT][2], double*
   }
 }
 
-// Work split inside the workgroup (BBP_THREADS / 64 = 4 waves; 8 were measured in round 4 - the second wave on wave 0's SIMD slows the
-// single-wave diagonal chain: factor 17 K -> 23 K cycles, bound 7.8 -> 8.5 ms): wave 0 owns the two row tiles of the DIAGONAL block, waves 1..3 the tiles below it
-// (rt = 1 + w, 1 + w + BBP_NWK, ...: NTW each).  After the update by block column c-1 - the one a column has to wait for - wave 0 goes
-// straight to the factorisation of the diagonal block while the others are still on the matrix cores.
+// Work split inside the workgroup (eight waves, see BBP_NWK): wave 0 owns the two row tiles of the DIAGONAL block, the six workers
+// (waves 1, 2, 3, 5, 6, 7) the tiles below it (worker widx: rt = 2 + widx, 2 + widx + 6, ...: NTW each), wave 4 - wave 0's SIMD neighbour -
+// only loads the panel.  After the update by block column c-1 - the one a column has to wait for - wave 0 goes straight to the
+// factorisation of the diagonal block while the others are still on the matrix cores.  (Four waves, three workers of nine tiles: the
+// diagonal wave waited 11 K cycles per column at the barrier before the solve; eight waves with wave 4 working: the single-wave
+// elimination stretched from 17 K to 23 K cycles.)
 template <int NTW>
 __global__ __launch_bounds__(BBP_THREADS) void bb_chol_persistent_kernel(double* __restrict__ Pb, long M, int bw, long LD,
                                                                          double* __restrict__ rhs, int* __restrict__ info,
