@@ -588,7 +588,7 @@ __device__ __attribute__((always_inline)) void bcr_mfma_backward_pre(const doubl
     // `seq` in this slot (pinned memory, one 8-byte system-scope load per poll).  Bounded: *gave_up (LDS) is set and the caller leaves.
     if (tid == 0) {
       long spins = 0;
-      while (__hip_atomic_load(ready_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      while (__hip_atomic_load(ready_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {   // (relaxed polls; the acquire fence follows the loop)
         __builtin_amdgcn_s_sleep(8);
         if (++spins > spin_limit) { *gave_up = 1; break; }
       }

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
       long spins = 0;                                 // bounded: helpers that never became resident must not hang the device
-      while (__hip_atomic_load(fin.assembled, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) {
+      while (__hip_atomic_load(fin.assembled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fin.n_helpers) {   // (relaxed polls: ONE acquire fence behind the loop - an acquire per poll is a cache invalidation per poll)
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1L << 25)) { gave_up = 1; break; }
       }
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BCR_THREADS) void elbo_chains_kernel(const double* 
   }
   if (threadIdx.x == 0) {
     long spins = 0;                                   // bounded like the wait above; the bound is minutes of chain time
-    while (__hip_atomic_load(fin.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+    while (__hip_atomic_load(fin.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
       __builtin_amdgcn_s_sleep(8);
       if (++spins > (1L << 25)) { gave_up = 1; break; }
     }
