@@ -571,7 +571,7 @@ def main():
     # double-double (no host arithmetic in the step), and with one rank's share of 2 / 4 / 8 ranks (the first N/2, N/4, N/8 points; world
     # size 1, no collective): what a rank of a strong-scaling run does per step before any collective latency.
     extras = {}
-    if dep is not None and not args.no_extras:
+    if dep is not None and not args.no_extras and world == 1:   # (the extras are rows of the N = 1 line; a multi-rank run keeps to the contract's schedules)
         try:
             res = dependent_schedule(2, prior_forward=1)
             mg = new_model(N, overlapped=False, prior_forward=1)
