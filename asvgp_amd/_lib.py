@@ -82,6 +82,7 @@ SIGNATURES = {
     "asvgp_predict_kron2d": (_I, [_P, _L, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P, _P, _P, _P, _P]),
     "asvgp_kron_cell_index": (_I, [_P, _L, _P, _L, _D, _P, _L, _D, _P, _P]),
     "asvgp_phi_accumulate_kron2d_sorted": (_I, [_P, _P, _L, _P, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P]),
+    "asvgp_phi_accumulate_kron2d_sorted_f32": (_I, [_P, _P, _L, _P, _P, _L, _D, _L, _P, _L, _D, _L, _I, _P, _P]),
     "asvgp_blockband_to_blocks": (_I, [_P, _L, _L, _L, _P, _P, _P]),
     "asvgp_kron_grad_terms": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _P, _P]),
     "asvgp_predict_kron2d_var": (_I, [_P, _L, _P, _L, _D, _P, _L, _D, _L, _I, _P, _P, _L, _P, _P]),

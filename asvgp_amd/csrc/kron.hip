@@ -192,9 +192,18 @@ __global__ __launch_bounds__(256) void phi_kron2d_cells_kernel(
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KRON_STRIP = 8;
 typedef double kron_d4 __attribute__((ext_vector_type(4)));
-template <int K>
+// TIN: storage type of the (cell-sorted) points - double, or float for BASELINE config 4's fp32 data (12 B per point streamed; the
+// values are widened exactly in registers, every operation after that is the fp64 one: the statistics equal those of the upcast data).
+template <typename TIN> struct KronIn;
+template <> struct KronIn<double> {
+  static __device__ __forceinline__ double2 xy(const double* X, long long p) { return *reinterpret_cast<const double2*>(X + 2 * p); }
+};
+template <> struct KronIn<float> {
+  static __device__ __forceinline__ double2 xy(const float* X, long long p) { const float2 v = *reinterpret_cast<const float2*>(X + 2 * p); return make_double2((double)v.x, (double)v.y); }
+};
+template <int K, typename TIN>
 __global__ __launch_bounds__(64 * KRON_STRIP) void phi_kron2d_mfma_kernel(
-    const double* __restrict__ X, const double* __restrict__ y, const long long* __restrict__ cell_start, int ncell, int ncell_pad,
+    const TIN* __restrict__ X, const TIN* __restrict__ y, const long long* __restrict__ cell_start, int ncell, int ncell_pad,
     const double* __restrict__ mesh1, double id1, const double* __restrict__ mesh2, int n2, double id2,
     double* __restrict__ cellsum, double* __restrict__ yy_out) {
   using KO = KronOut<K>;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(64 * KRON_STRIP) void phi_kron2d_mfma_kernel(
   cell_range(strip, p0, p1e);
   double2 xn = make_double2(0.0, 0.0);
   double yn = 0.0;
-  if (p0 + lane < p1e) { xn = *reinterpret_cast<const double2*>(X + 2 * (p0 + lane)); yn = y[p0 + lane]; }
+  if (p0 + lane < p1e) { xn = KronIn<TIN>::xy(X, p0 + lane); yn = (double)y[p0 + lane]; }
   for (; strip * KRON_STRIP < ncell_pad; strip += gridDim.x) {
     const int c0 = strip * KRON_STRIP, c = c0 + wv;
     kron_d4 acc[NTT];
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(64 * KRON_STRIP) void phi_kron2d_mfma_kernel(
         {
           const long long nb = base + 64 < p1e ? base + 64 + lane : q0 + lane;      // next chunk of this cell, else the next cell's first
           const long long ne = base + 64 < p1e ? p1e : q1e;
-          if (nb < ne) { xn = *reinterpret_cast<const double2*>(X + 2 * nb); yn = y[nb]; } else { xn = make_double2(0.0, 0.0); yn = 0.0; }
+          if (nb < ne) { xn = KronIn<TIN>::xy(X, nb); yn = (double)y[nb]; } else { xn = make_double2(0.0, 0.0); yn = 0.0; }
         }
         const int np = (int)(p1e - base < 64 ? p1e - base : 64);
         auto step = [&](int st4, bool masked) __attribute__((always_inline)) {
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(64 * KRON_STRIP) void phi_kron2d_mfma_kernel(
       }
     } else if (q1e > q0) {
       // (an empty cell: the prefetch of the next cell was never issued - nothing was walked)
-      if (q0 + lane < q1e) { xn = *reinterpret_cast<const double2*>(X + 2 * (q0 + lane)); yn = y[q0 + lane]; } else { xn = make_double2(0.0, 0.0); yn = 0.0; }
+      if (q0 + lane < q1e) { xn = KronIn<TIN>::xy(X, q0 + lane); yn = (double)y[q0 + lane]; } else { xn = make_double2(0.0, 0.0); yn = 0.0; }
     }
     p0 = q0; p1e = q1e;
 #pragma unroll
@@ -1671,7 +1680,8 @@ extern "C" int asvgp_kron_cell_index(const double* X, int64_t N, const double* m
   return check_launch("kron_cell_index");
 }
 
-extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double* ys, int64_t N, const int64_t* cell_start,
+template <typename TIN>
+static int phi_accumulate_kron2d_sorted_entry(const TIN* Xs, const TIN* ys, int64_t N, const int64_t* cell_start,
                                                   const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
                                                   const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
                                                   double* stats, asvgp_stream_t stream) {
@@ -1681,7 +1691,7 @@ extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double
     return ASVGP_ERR_BAD_ARG;
   }
   if (order < 1 || order > ASVGP_MAX_ORDER) { set_error("phi_accumulate_kron2d_sorted: order %d unsupported", order); return ASVGP_ERR_UNSUPPORTED; }
-  if ((reinterpret_cast<uintptr_t>(Xs) & 15) != 0) { set_error("phi_accumulate_kron2d_sorted: Xs must be 16-byte aligned (N,2) row-major"); return ASVGP_ERR_BAD_ARG; }
+  if ((reinterpret_cast<uintptr_t>(Xs) & (2 * sizeof(TIN) - 1)) != 0) { set_error("phi_accumulate_kron2d_sorted: Xs must be aligned to one (x1, x2) pair, (N,2) row-major"); return ASVGP_ERR_BAD_ARG; }
   hipStream_t st = as_stream(stream);
   const size_t nd = asvgp_kron_stats_doubles(m1, m2, order);
   hipError_t e = hipSuccess;
@@ -1695,7 +1705,8 @@ extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double
   double* rhs = stats + (size_t)kron_noff(order) * Mtot;
   double* yy = rhs + Mtot;
   const long ncell = (long)(n_mesh1 - 1) * (n_mesh2 - 1);
-  static const bool use_atomics = getenv("ASVGP_KRON_PHI_ATOMICS") && atoi(getenv("ASVGP_KRON_PHI_ATOMICS")) != 0;   // (the round-1..3 kernel, for comparison)
+  static const bool use_atomics_env = getenv("ASVGP_KRON_PHI_ATOMICS") && atoi(getenv("ASVGP_KRON_PHI_ATOMICS")) != 0;   // (the round-1..3 kernel, for comparison)
+  const bool use_atomics = use_atomics_env && sizeof(TIN) == sizeof(double);
   const long ncell_pad = (ncell + KRON_STRIP - 1) / KRON_STRIP * KRON_STRIP;
   double* cellsum = nullptr;
   if (!use_atomics) {
@@ -1716,7 +1727,7 @@ extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double
     long gblocks = (total + 255) / 256;
     if (gblocks > 8192) gblocks = 8192;
     KRON_DISPATCH(order, {
-      hipLaunchKernelGGL(phi_kron2d_mfma_kernel<K>, dim3((unsigned)(strips < kgrid ? strips : kgrid)), dim3(64 * KRON_STRIP), 0, st, Xs, ys,
+      hipLaunchKernelGGL((phi_kron2d_mfma_kernel<K, TIN>), dim3((unsigned)(strips < kgrid ? strips : kgrid)), dim3(64 * KRON_STRIP), 0, st, Xs, ys,
                          reinterpret_cast<const long long*>(cell_start), (int)ncell, (int)ncell_pad, mesh1, 1.0 / delta1, mesh2,
                          (int)n_mesh2, 1.0 / delta2, cellsum, yy);
       hipLaunchKernelGGL(phi_kron2d_gather_kernel<K>, dim3((unsigned)gblocks), dim3(256), 0, st, cellsum, (int)ncell_pad, (int)(n_mesh1 - 1),
@@ -1725,6 +1736,10 @@ extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double
     (void)hipFreeAsync(cellsum, st);
     return check_launch("phi_accumulate_kron2d_sorted (matrix-core cell sums + gather)");
   }
+  if constexpr (sizeof(TIN) != sizeof(double)) {
+    set_error("phi_accumulate_kron2d_sorted_f32: no room for the staging buffer (%ld cells)", ncell);
+    return ASVGP_ERR_HIP;
+  } else {
   long blocks = ncell < 4096 ? ncell : 4096;
   KRON_DISPATCH(order, {
     hipLaunchKernelGGL(phi_kron2d_cells_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, st, Xs, ys,
@@ -1732,4 +1747,20 @@ extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double
                        (int)n_mesh2, 1.0 / delta2, (int)m2, Ablk, rhs, yy);
   });
   return check_launch("phi_accumulate_kron2d_sorted");
+  }
+}
+
+extern "C" int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double* ys, int64_t N, const int64_t* cell_start,
+                                                  const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
+                                                  const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                                  double* stats, asvgp_stream_t stream) {
+  return phi_accumulate_kron2d_sorted_entry<double>(Xs, ys, N, cell_start, mesh1, n_mesh1, delta1, m1, mesh2, n_mesh2, delta2, m2, order, stats, stream);
+}
+
+// fp32 STORAGE of the cell-sorted points (BASELINE config 4): 12 B per point streamed, widened exactly, fp64 arithmetic
+extern "C" int asvgp_phi_accumulate_kron2d_sorted_f32(const float* Xs, const float* ys, int64_t N, const int64_t* cell_start,
+                                                      const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
+                                                      const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
+                                                      double* stats, asvgp_stream_t stream) {
+  return phi_accumulate_kron2d_sorted_entry<float>(Xs, ys, N, cell_start, mesh1, n_mesh1, delta1, m1, mesh2, n_mesh2, delta2, m2, order, stats, stream);
 }

@@ -437,6 +437,9 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
 
     def __init__(self, data, kernels, bases, process_group=None, distributed=None):
         dev = bases[0].device
+        # fp32 data (BASELINE configs[3]): the cell-sorted copy the Phi pass streams stays fp32 (12 B per point); X / y themselves are
+        # widened once, as the reference does (basis.py:54) - the widening is exact, so the statistics are those of the fp64 data
+        self._fp32_storage = (torch.as_tensor(data[0]).dtype == torch.float32 and torch.as_tensor(data[1]).dtype == torch.float32)
         self.X, self.y = _to_device(data[0], dev), _to_device(data[1], dev)
         require_cuda(self.X, self.y)                         # (both routes below hand raw device pointers to the library)
         self.n, self.d = self.X.shape[0], self.X.shape[1]
@@ -599,7 +602,10 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         counts = torch.bincount(cell, minlength=ncell)
         start = torch.zeros(ncell + 1, dtype=torch.int64, device=dev)
         start[1:] = torch.cumsum(counts, 0)
-        return self.X[order].contiguous(), self.y[order].contiguous(), start
+        Xs, ys = self.X[order].contiguous(), self.y[order].contiguous()
+        if getattr(self, "_fp32_storage", False):
+            Xs, ys = Xs.to(torch.float32), ys.to(torch.float32)   # (exact: the data WERE fp32)
+        return Xs, ys, start
 
     def _phi_pass_local(self, sorted_cells=True):
         """The N-dependent pass over this rank's rows -> [block band | Kuf y | y^T y].  Default: cell-sorted accumulation (one atomic per band entry and
@@ -612,10 +618,11 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
             if getattr(self, "_sorted", None) is None:
                 self._sorted = self._sort_by_cell()
             Xs, ys, start = self._sorted
-            check(lib.asvgp_phi_accumulate_kron2d_sorted(Xs.data_ptr(), ys.data_ptr(), self.n, start.data_ptr(),
-                                                         b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np, b1.m,
-                                                         b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
-                                                         self._stats.data_ptr(), stream_ptr()), "phi_accumulate_kron2d_sorted")
+            entry = lib.asvgp_phi_accumulate_kron2d_sorted_f32 if Xs.dtype == torch.float32 else lib.asvgp_phi_accumulate_kron2d_sorted
+            check(entry(Xs.data_ptr(), ys.data_ptr(), self.n, start.data_ptr(),
+                        b1.mesh.data_ptr(), b1.mesh.shape[0], b1.delta_np, b1.m,
+                        b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, b2.m, self.order,
+                        self._stats.data_ptr(), stream_ptr()), "phi_accumulate_kron2d_sorted")
         else:
             check(lib.asvgp_phi_accumulate_kron2d(self.X.data_ptr(), self.y.data_ptr(), self.n, b1.mesh.data_ptr(),
                                                   b1.mesh.shape[0], b1.delta_np, b1.m, b2.mesh.data_ptr(),

@@ -1308,6 +1308,36 @@ def test_kron_selected_inverse_and_analytic_gradient(A, order, m1, m2, N):
     np.testing.assert_allclose(g, og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
 
 
+def test_kron_fp32_storage_gives_the_statistics_of_the_upcast_data(A):
+    """BASELINE configs[3] names fp32 data: a GPR_kron built from float32 (X, y) streams a float32 cell-sorted copy through the Phi pass
+    (asvgp_phi_accumulate_kron2d_sorted_f32, 12 B per point) - widened exactly in registers, fp64 arithmetic: the statistics are bit
+    for bit those of the model built from the upcast float64 data (bound and gradient: the same to rounding), and the oracle's bound
+    within the suite's gate."""
+    rng = np.random.default_rng(77)
+    for order, m1, m2, N in ((3, 20, 17, 30_000), (4, 14, 15, 9_001), (1, 9, 8, 700)):
+        X32 = np.stack([rng.uniform(0.001, 0.999, N), rng.uniform(-0.999, 1.999, N)], axis=1).astype(np.float32)
+        y32 = (np.sin(6 * X32[:, :1]) * np.cos(2 * X32[:, 1:]) + 0.1 * rng.normal(size=(N, 1))).astype(np.float32)
+        B = getattr(A, "B%dSpline" % order)
+        Kern, kind = (A.Matern12, 0) if order == 1 else (A.Matern32, 1)
+        mk = lambda: [Kern(variance=1.1, lengthscales=0.3), Kern(variance=0.7, lengthscales=0.6)]
+        m32 = A.GPR_kron((torch.from_numpy(X32), torch.from_numpy(y32)), mk(), [B(0, 1, m1), B(-1, 2, m2)])
+        m64 = A.GPR_kron((torch.from_numpy(X32.astype(np.float64)), torch.from_numpy(y32.astype(np.float64))), mk(), [B(0, 1, m1), B(-1, 2, m2)])
+        assert m32._fp32_storage and not m64._fp32_storage
+        assert m32._sorted[0].dtype == torch.float32 and m64._sorted[0].dtype == torch.float64
+        assert torch.equal(m32._stats, m64._stats)
+        for m in (m32, m64):
+            m.likelihood.variance.assign(0.05)
+        # (the evaluation itself sums its trace / log-det terms with atomics: the same statistics give the bound to rounding, not to the bit)
+        assert abs(m32.elbo().item() - m64.elbo().item()) <= 1e-12 * abs(m64.elbo().item())
+        e32, g32 = m32.elbo_and_grad()
+        e64, g64 = m64.elbo_and_grad()
+        assert abs(e32 - e64) <= 1e-12 * abs(e64)
+        np.testing.assert_allclose(g32, g64, rtol=1e-10, atol=1e-10 * np.max(np.abs(g64)))
+        Xh, yh = X32.astype(np.float64), y32.astype(np.float64)
+        oe, _ = O.elbo_kron([O.Basis(order, 0, 1, m1), O.Basis(order, -1, 2, m2)], [kind, kind], [(1.1, 0.3), (0.7, 0.6)], 0.05, Xh, yh)
+        assert abs(e32 - oe) <= elbo_tol(oe, N, 1.1 * 0.7, 0.05, float(np.sum(yh * yh)), bcr=True)
+
+
 @pytest.mark.parametrize("order,m1,m2,N", [(2, 40, 12, 6000), (3, 30, 9, 5000), (4, 26, 14, 7000), (1, 50, 31, 8000)])
 def test_kron_two_sided_factorisation_equals_the_one_sided_and_the_dense_oracle(A, order, m1, m2, N):
     """The two-sided ("twisted") band Cholesky of P - top system and reversed bottom system factored concurrently, joined by the
