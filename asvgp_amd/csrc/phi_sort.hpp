@@ -864,7 +864,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
             q_planes(SA, n0A, hs, d0, d1);
           }
         }
-        __syncthreads();
+        ps_lds_barrier();                                       // (LDS only: the image is complete)
         if (j < M && j >= col_lo && j <= col_hi) {
           int pid = 0;
 #pragma unroll
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
             pid += K + 1 - d;
           }
         }
-        __syncthreads();
+        ps_lds_barrier();                                       // (LDS only: __syncthreads would also wait for the round's partial stores to be acknowledged before the next round computes)
       }
     }
     // rhs: both halves in one round (2 (K+1) planes)
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(PS_THREADS) void phi_sort_kernel(PsArgs a) {
       for (int i = 0; i <= K; ++i) img[i * IW + hs] = 0.0;
       r_planes(TA, hs, K + 1);
     }
-    __syncthreads();
+    ps_lds_barrier();
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int j = half * PS_THREADS + tid;
