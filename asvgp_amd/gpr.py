@@ -598,7 +598,7 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
                                         b2.mesh.data_ptr(), b2.mesh.shape[0], b2.delta_np, cell.data_ptr(), stream_ptr()),
               "kron_cell_index")
         ncell = (b1.mesh.shape[0] - 1) * (b2.mesh.shape[0] - 1)
-        order = torch.argsort(cell)
+        order = torch.argsort(cell, stable=True)                 # (stable: the same data always stream in the same order - reproducible sums)
         counts = torch.bincount(cell, minlength=ncell)
         start = torch.zeros(ncell + 1, dtype=torch.int64, device=dev)
         start[1:] = torch.cumsum(counts, 0)

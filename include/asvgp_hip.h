@@ -373,7 +373,8 @@ int asvgp_phi_accumulate_kron2d_sorted(const double* Xs, const double* ys, int64
                                        double* stats, asvgp_stream_t stream);
 /* The same pass over points STORED in fp32 (BASELINE.json configs[3] names fp32 data): Xs (N, 2) and ys (N) are float arrays in cell
  * order, 12 bytes per point streamed; every value is widened exactly in registers and all arithmetic is the fp64 arithmetic of the entry
- * above - the statistics are bit for bit those of the upcast data (the reference itself casts to fp64, basis.py:54). */
+ * above - block band and rhs are bit for bit those of the upcast data streamed in the same order (the reference itself casts to fp64,
+ * basis.py:54). */
 int asvgp_phi_accumulate_kron2d_sorted_f32(const float* Xs, const float* ys, int64_t N, const int64_t* cell_start,
                                            const double* mesh1, int64_t n_mesh1, double delta1, int64_t m1,
                                            const double* mesh2, int64_t n_mesh2, double delta2, int64_t m2, int order,
