@@ -652,14 +652,21 @@ __global__ __launch_bounds__(1024) void predict_poly_kernel(const double* __rest
     const pp_d2* x2 = reinterpret_cast<const pp_d2*>(xnew);
     pp_d2* mean2 = reinterpret_cast<pp_d2*>(mean);
     pp_d2* var2 = reinterpret_cast<pp_d2*>(var);
+    // Two pairs in flight behind the one being worked on, loaded UNCONDITIONALLY at clamped indices: behind a branch the loaded value is
+    // a phi node that hipcc materialises right behind the load (s_waitcnt vmcnt(0) in the same iteration - the "prefetch" of the first
+    // version overlapped nothing, 16 KB of reads in flight per CU).
+    const long qlast = nq > 0 ? nq - 1 : 0;
+    pp_d2 xb = __builtin_nontemporal_load(x2 + (qi + stride < nq ? qi + stride : qlast));
     for (; qi < nq; qi += stride) {
+      const long q2 = qi + 2 * stride;
+      const pp_d2 xc = __builtin_nontemporal_load(x2 + (q2 < nq ? q2 : qlast));
       const double xs0 = xa.x, xs1 = xa.y;
-      if (qi + stride < nq) xa = __builtin_nontemporal_load(x2 + qi + stride);
       double m0v, v0v, m1v, v1v;
       point(xs0, m0v, v0v);
       point(xs1, m1v, v1v);
       __builtin_nontemporal_store(pp_d2{v0v, v1v}, var2 + qi);
       __builtin_nontemporal_store(pp_d2{m0v, m1v}, mean2 + qi);
+      xa = xb; xb = xc;
     }
     const long pl = 2 * nq + (long)blockIdx.x * blockDim.x + tid;                    // the odd last point
     if (pl < n) { double mo, vo; point(xnew[pl], mo, vo); var[pl] = vo; mean[pl] = mo; }

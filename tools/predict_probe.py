@@ -11,8 +11,13 @@ for ns in (100_000, 10_000_000, 50_000_000):
     xs = torch.rand(ns, dtype=torch.float64, device="cuda") * 0.998 + 0.001
     for srt in (False, True):
         xq = torch.sort(xs)[0] if srt else xs
-        model.predict_f_device(xq.reshape(-1, 1)); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5): m, v = model.predict_f_device(xq.reshape(-1, 1))
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        for _ in range(3):                                    # (allocator warm-up: the outputs of the first calls at a new size are cudaMalloc'ed)
+            m, v = model.predict_f_device(xq.reshape(-1, 1))
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):                                    # median of three groups of five back-to-back calls
+            t0 = time.perf_counter()
+            for _ in range(5): m, v = model.predict_f_device(xq.reshape(-1, 1))
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 5)
+        dt = sorted(ts)[1]
         print("n* %9d %s: %8.1f us  %7.1f Gpoints/s  %6.2f TB/s (24 B/point)" % (ns, "sorted  " if srt else "unsorted", dt * 1e6, ns / dt / 1e9, 24 * ns / dt / 1e12), flush=True)
