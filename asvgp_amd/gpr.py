@@ -675,17 +675,9 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
 
     def _twist_layout(self):
         """Separator and padding of the two-sided factorisation (asvgp_kron_assemble_twisted), or None for the one-sided band Cholesky."""
-        m2, k, M = self.bases[1].m, self.order, self.Mtot
-        bw = k * m2 + k
-        Bb = ((max(bw, 1) + 31) // 32) * 32
-        nb = -(-(M + Bb) // (2 * Bb))
-        if self.twisted is False or nb < 3 or (self.twisted is None and -(-M // Bb) < 6):
-            return None
-        padt = (2 * nb * Bb - Bb - M) // 2
-        top_end = nb * Bb - padt
-        h = top_end - Bb
-        padb = nb * Bb - (M - h)
-        return dict(Bb=Bb, nb=nb, top_end=top_end, h=h, padt=padt, padb=padb, bw=bw)
+        from .kronecker import twisted_layout
+        m2, k = self.bases[1].m, self.order
+        return twisted_layout(self.Mtot, k * m2 + k, self.twisted)
 
     def _factor(self, want_alpha):
         """Kuu factors per dimension, trace term, wide-band Cholesky of P with the rhs riding along."""

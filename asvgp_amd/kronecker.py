@@ -70,3 +70,21 @@ def make_kvs_two_sparse(A, B):
     M1 = _coo(sparse_repeats(A, B.shape[0]))
     M2 = _coo(sparse_tile(B, A.shape[0]))
     return _coo(M1 * M2).to_sparse_csr()                       # (sparse .multiply, as the reference: nothing is densified)
+
+
+def twisted_layout(M, bw, force=None):
+    """Separator and padding of the two-sided factorisation of a band matrix with M columns and bandwidth bw
+    (include/asvgp_hip.h, asvgp_kron_assemble_twisted), or None when the one-sided band Cholesky is used.
+    Super-block size Bb = bw rounded up to a multiple of 32; both systems have nb super-blocks, the separator [h, h + Bb) being the
+    last one of each: top system = padt identity columns + original columns [0, top_end), bottom system (reversed) = padb identity
+    columns + original columns [h, M).  force: None = by size (at least 6 super-blocks), True = wherever nb >= 3, False = never."""
+    Bb = ((max(bw, 1) + 31) // 32) * 32
+    nb = -(-(M + Bb) // (2 * Bb))
+    if force is False or nb < 3 or (force is None and -(-M // Bb) < 6):
+        return None
+    padt = (2 * nb * Bb - Bb - M) // 2
+    top_end = nb * Bb - padt
+    h = top_end - Bb
+    padb = nb * Bb - (M - h)
+    return dict(Bb=Bb, nb=nb, top_end=top_end, h=h, padt=padt, padb=padb, bw=bw)
+

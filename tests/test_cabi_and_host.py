@@ -382,3 +382,35 @@ def test_prior_plan_device_image_is_consistent_with_the_host_plan(lib, order, M,
                 for t in range(1, nt):
                     acc = acc + c[t] * ent[r, cc, t]
                 assert codes[r, cc] == 0 and acc == K[r - cc, cc], (r, cc)
+
+
+def test_two_sided_factorisation_layout_invariants():
+    """asvgp_amd.kronecker.twisted_layout (host logic of GPR_kron's two-sided band Cholesky): for every size both systems have nb super-blocks,
+    the separator is their last block, paddings are non-negative, the interiors do not overlap and together with the separator cover
+    [0, M); small matrices keep the one-sided factorisation unless forced."""
+    from asvgp_amd.kronecker import twisted_layout
+    seen = 0
+    for M in list(range(40, 3000, 37)) + [16384, 10000, 128 * 128, 100 * 100]:
+        for bw in (3, 10, 26, 36, 60, 147, 387, 404):
+            for force in (None, True, False):
+                lay = twisted_layout(M, bw, force)
+                Bb = ((max(bw, 1) + 31) // 32) * 32
+                if force is False:
+                    assert lay is None
+                    continue
+                if lay is None:
+                    nb = -(-(M + Bb) // (2 * Bb))
+                    assert nb < 3 or (force is None and -(-M // Bb) < 6)
+                    continue
+                seen += 1
+                nb, top_end, h, padt, padb = lay["nb"], lay["top_end"], lay["h"], lay["padt"], lay["padb"]
+                assert lay["Bb"] == Bb and Bb >= bw and Bb % 32 == 0 and nb >= 3
+                assert padt >= 0 and padb >= 0 and h == top_end - Bb and 0 <= h and top_end <= M
+                assert padt + top_end == nb * Bb                      # top system: padding + columns [0, top_end)
+                assert padb + (M - h) == nb * Bb                      # bottom system: padding + columns [h, M)
+                assert abs(padt - padb) <= 1                          # balanced chains
+                assert (nb - 1) * Bb >= padt + h and (nb - 1) * Bb >= padb + (M - top_end)   # interiors fit in front of the separator block
+    assert seen > 100
+    lay = twisted_layout(128 * 128, 3 * 128 + 3)
+    assert lay == dict(Bb=416, nb=21, top_end=8400, h=7984, padt=336, padb=336, bw=387)
+
