@@ -600,6 +600,36 @@ def main():
             torch.cuda.synchronize()
         except Exception:
             pass
+        # The Phi kernel on the OTHER input order SURVEY 8d names (a time series: the same points sorted by x; or, with --sorted, the
+        # unsorted points): HIP events around the kernel alone, same handle mechanism as `roofline` - the driver line then carries both.
+        if world == 1:
+            try:
+                if args.sorted:
+                    perm = torch.randperm(n_local, device="cuda")
+                else:
+                    perm = torch.argsort(xd.reshape(-1))
+                xo, yo = xd.reshape(-1)[perm].contiguous().reshape(-1, 1), yd.reshape(-1)[perm].contiguous().reshape(-1, 1)
+                om = A.GPR_1d((xo, yo), Kern(variance=theta0[0], lengthscales=theta0[1]), basis)
+                for _ in range(3):
+                    om.phi_pass(allreduce=False)
+                torch.cuda.synchronize()
+                lib.asvgp_profile_enable(om._h.ptr, 1)
+                for _ in range(20):
+                    om.phi_pass(allreduce=False)
+                torch.cuda.synchronize()
+                ms_sum, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+                lib.asvgp_profile_read(om._h.ptr, ctypes.byref(ms_sum), ctypes.byref(launches))
+                lib.asvgp_profile_enable(om._h.ptr, 0)
+                kus = ms_sum.value / max(launches.value, 1) * 1e3
+                order_ran = om._h.phi_last_input_order() if hasattr(om._h, "phi_last_input_order") else 0
+                ach = BYTES_PER_POINT * n_local / (kus * 1e-6) / 1e9 if kus > 0 else 0.0
+                extras["phi_kernel_other_input_order"] = {"input": "unsorted (random permutation)" if args.sorted else "time series (the same points sorted by x)",
+                                                          "kernel": PHI_KERNEL_NAMES.get(62 if order_ran == 2 else 6, "tile sort"), "kernel_us": kus, "launches": int(launches.value),
+                                                          "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                                          "what": "HIP events around the Phi kernel alone (the handle's profile ring), 20 passes; the statistics are the same for any order (tests)"}
+                om.close(); del om, xo, yo, perm
+            except Exception as exc:
+                extras["phi_kernel_other_input_order_error"] = repr(exc)[:300]
         # Two more rows of SURVEY section 8 measured in the same process (rank 0, world size 1 only): the streaming posterior over 10M test
         # points with this model's theta, and BASELINE configs[3]'s shape (2-D Kronecker, N = 1M, 128 x 128, B3) - Phi pass, bound, bound +
         # gradient.  Not `value`; they put the kernels' figures into the driver's own record.
@@ -763,7 +793,8 @@ def main():
                         "step (sorted input, small shards); on the unsorted headline the N side bounds and the extra host calls cost more than they save"}
         if "dependent_steps_launch_ahead_error" in extras:
             line["dependent_steps_launch_ahead_error"] = extras["dependent_steps_launch_ahead_error"]
-        for key in ("posterior_10m_points", "posterior_10m_points_error", "kronecker_config4_shape", "kronecker_config4_shape_error"):
+        for key in ("phi_kernel_other_input_order", "phi_kernel_other_input_order_error", "posterior_10m_points", "posterior_10m_points_error",
+                    "kronecker_config4_shape", "kronecker_config4_shape_error"):
             if key in extras:
                 line[key] = extras[key]
         if "emulated_shard" in extras:
