@@ -361,7 +361,7 @@ int asvgp_predict_kron2d(const double* Xnew, int64_t n, const double* mesh1, int
  * c = i1 * (n_mesh2 - 1) + i2 (asvgp_kron_cell_index; basis.py:58-59 per dimension) is non-decreasing, cell_start[c] (int64,
  * n_cells + 1 entries) the first row of cell c.  A cell's statistics are a small Gram matrix: one wavefront per cell forms it on
  * the fp64 matrix core (v_mfma_f64_16x16x4 over the (k+1)^2 basis functions, four points per step), the per-cell results go
- * entry-major into a stream-ordered staging buffer ((k+1)^2 ((k+1)^2 + 3) / 2-ish doubles per cell, hipMallocAsync on `stream`)
+ * entry-major into a stream-ordered staging buffer (152 doubles per cell at k = 3, 350 at k = 4; hipMallocAsync on `stream`)
  * and a gather kernel forms every output from the <= (k+1)^2 cells that touch it: no statistic atomics, deterministic sums.
  * (ASVGP_KRON_PHI_ATOMICS=1 in the environment, or no room for the staging buffer: the per-cell kernel with one global atomic per
  * block-band entry and cell.) */
