@@ -544,7 +544,163 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
             raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite at column %d" % (int(info.item()) - 1))
         return dict(s=s, Ks=Ks, dKs=dKs, Kuu=Kuu, LK=LK, LP=LP)
 
+    nd_banded = None          # d != 2: None = band route for P when its band fits (bandwidth <= 432, band storage <= 1 GiB); False: dense always
+
+    def _nd_band_layout(self):
+        """d != 2: P = kron(K_i) + Kuf Kuf^T / s is a band matrix of bandwidth bw = k (m_2 ... m_d + ... + m_d + 1) (dim-0 major index).
+        Cached index arrays of its band slots (column c, offset e -> row r = c + e): the dense index r M + c, the per-dimension band
+        lookups of the 1-D factors, the pattern mask (all |i_t(r) - i_t(c)| <= k) and the diagonal / off-diagonal weight."""
+        lay = getattr(self, "_nd_lay", None)
+        if lay is not None:
+            return lay if lay else None
+        self._nd_lay = {}
+        k, d, M = self.order, self.d, self.Mtot
+        ms = [bs.m for bs in self.bases]
+        strides = [1] * d
+        for t in range(d - 2, -1, -1):
+            strides[t] = strides[t + 1] * ms[t + 1]
+        bw = k * sum(strides)
+        if self.nd_banded is False or d < 2 or bw > 432 or bw >= M or M * (bw + 1) * 8 * (d + 4) > (1 << 30):
+            return None
+        dev = self._dev
+        c = torch.arange(M, device=dev).view(-1, 1)
+        e = torch.arange(bw + 1, device=dev).view(1, -1)
+        r = c + e
+        inb = r < M
+        rr = torch.where(inb, r, torch.zeros_like(r))
+        pat = inb.clone()
+        kidx = []
+        for t in range(d):
+            it_r = (rr // strides[t]) % ms[t]
+            it_c = ((c // strides[t]) % ms[t]).expand_as(rr)
+            dt = it_r - it_c
+            pat &= dt.abs() <= k
+            dd = dt.abs().clamp(max=k)
+            kidx.append(dd * ms[t] + torch.minimum(it_r, it_c))     # lower band (k+1, m_t): entry (|d|, min(i, j))
+        Bb = ((max(bw, 1) + 31) // 32) * 32
+        nblk = (M + Bb - 1) // Bb
+        bi, bj = rr // Bb, (c // Bb).expand_as(rr)
+        per = Bb * Bb
+        sidx = torch.where(bi == bj, bi * per + (rr % Bb) * Bb + (c % Bb), nblk * per + bj * per + (rr % Bb) * Bb + (c % Bb))
+        self._nd_lay = dict(bw=bw, Bb=Bb, nblk=nblk, pat=pat, didx=(rr * M + c), kidx=kidx, sidx=torch.where(inb, sidx, torch.zeros_like(sidx)),
+                            w=torch.where(e == 0, 1.0, 2.0).to(torch.float64).expand(M, bw + 1), rows=rr, ms=ms)
+        return self._nd_lay
+
+    def _nd_band_factor(self, lay):
+        """Band Cholesky of P (asvgp_blockband_cholesky, the rhs riding along) instead of the dense O(M_tot^3) factorisations; log|Kuu| and
+        tr(Kuu^-1 A) factor-wise from the 1-D chains (band(K_t^-1) is all the trace needs: A has the pattern of the band)."""
+        lib = get_lib()
+        s = float(self.likelihood.variance)
+        M, bw, pat = self.Mtot, lay["bw"], lay["pat"]
+        Ks, dKs, Ss, dSs, lds = [], [], [], [], []
+        for i, (feat, kern) in enumerate(zip(self.inducing_features, self.kernels)):
+            K, dK, S, dS, ld2, info = feat.inverse_band(kern)
+            col = int(feat._info[0].item())
+            if col:
+                raise NotPositiveDefiniteError("Kuu band of dimension %d not positive definite at column %d" % (i, col - 1))
+            Ks.append(K.reshape(-1)); dKs.append(dK.reshape(-1)); Ss.append(S.reshape(-1)); dSs.append(dS.reshape(-1)); lds.append(ld2)
+        zero = torch.zeros((), dtype=torch.float64, device=self._dev)
+        gk = [K[ix] for K, ix in zip(Ks, lay["kidx"])]
+        gs = [S[ix] for S, ix in zip(Ss, lay["kidx"])]
+        kuu = gk[0]
+        sk = gs[0]
+        for a, b in zip(gk[1:], gs[1:]):
+            kuu = kuu * a
+            sk = sk * b
+        kuu, sk = torch.where(pat, kuu, zero), torch.where(pat, sk, zero)   # (outside the pattern the clamped lookups mean nothing)
+        Ab = torch.where(pat, self.KufKfu.reshape(-1)[lay["didx"]], zero)
+        Pb = (kuu + Ab / s).contiguous()
+        c = self.Kuf_y.reshape(-1).clone()
+        logdet_P = torch.zeros(1, dtype=torch.float64, device=self._dev)
+        check(lib.asvgp_blockband_cholesky(Pb.data_ptr(), M, bw, c.data_ptr(), logdet_P.data_ptr(), self._info.data_ptr(), stream_ptr()),
+              "blockband_cholesky")
+        col = int(self._info.item())
+        if col < 0:
+            raise AsvgpError("blockband_cholesky gave up waiting for a block column (its workgroup never became resident): results discarded")
+        if col:
+            raise NotPositiveDefiniteError("P = Kuu + KufKfu/sigma2 not positive definite at column %d" % (col - 1))
+        logdet_K = sum((M // m) * ld[0] for m, ld in zip(lay["ms"], lds))
+        trace = (lay["w"] * sk * Ab).sum()
+        return dict(s=s, Ks=Ks, dKs=dKs, Ss=Ss, dSs=dSs, gk=gk, gs=gs, kuu=kuu, sk=sk, Ab=Ab, Lb=Pb.reshape(-1), bw=bw, c=c / s, cc=((c / s) ** 2).sum(),
+                    logdet_P=logdet_P[0], logdet_K=logdet_K, trace=trace, alpha=None)
+
+    def _nd_band_sigma(self, lay, f):
+        """band(P^-1) in the slot layout (and alpha) from the super-block selected inverse of the band factor"""
+        SigD, SigS, Bb = self._selinv(f)
+        flat = torch.cat((SigD.reshape(-1), SigS.reshape(-1)))
+        return torch.where(lay["pat"], flat[lay["sidx"]], torch.zeros((), dtype=torch.float64, device=self._dev))
+
+    def _nd_band_elbo_and_grad(self, lay, want_grad=True):
+        f = self._nd_band_factor(lay)
+        s, N, M = f["s"], float(self.num_data), self.Mtot
+        vs = [float(k.variance) for k in self.kernels]
+        vprod = float(np.prod(vs))
+        yy = self.tr_yTy
+        elbo = (-0.5 * N * math.log(2 * math.pi * s) - 0.5 * f["logdet_P"] + 0.5 * f["logdet_K"] - 0.5 * yy / s
+                + 0.5 * f["cc"] - 0.5 * N * vprod / s + 0.5 * f["trace"] / s)
+        if not want_grad:
+            return elbo, None
+        from . import banded
+        sig = self._nd_band_sigma(lay, f)                           # (also fills f["alpha"])
+        w, Ab, alpha = lay["w"], f["Ab"], f["alpha"]
+        aa = w * alpha.view(-1, 1) * alpha[lay["rows"]]
+        ws = w * sig
+        tPA, aAa = (ws * Ab).sum(), (aa * Ab).sum()
+        tPK, aKa = (ws * f["kuu"]).sum(), (aa * f["kuu"]).sum()
+        tSA = f["trace"]
+        cc = f["cc"]
+        g = []
+        for t in range(self.d):
+            xt = f["dKs"][t][lay["kidx"][t]]
+            zt = -f["dSs"][t][lay["kidx"][t]]                        # band(K^-1 dK K^-1) = -d band(K^-1)/dl
+            for u in range(self.d):
+                if u != t:
+                    xt = xt * f["gk"][u]
+                    zt = zt * f["gs"][u]
+            xt = torch.where(lay["pat"], xt, torch.zeros((), dtype=torch.float64, device=self._dev))
+            tPX, aXa, tZA = (ws * xt).sum(), (aa * xt).sum(), (w * Ab * zt).sum()
+            mt = lay["ms"][t]
+            trK = banded.band_trace_sym(f["Ss"][t].view(self.order + 1, mt), f["dKs"][t].view(self.order + 1, mt))
+            g.append((0.5 * tPK - 0.5 * M + 0.5 * aKa + 0.5 * tSA / s) / vs[t] - 0.5 * N * vprod / (vs[t] * s))          # d / d v_t
+            g.append(-0.5 * tPX + 0.5 * (M // mt) * trK - 0.5 * aXa - 0.5 * tZA / s)                                       # d / d l_t
+        s2 = s * s
+        g.append(-0.5 * N / s + 0.5 * tPA / s2 - cc / s + 0.5 * aAa / s2 + 0.5 * yy / s2 + 0.5 * N * vprod / s2 - 0.5 * tSA / s2)
+        return elbo, torch.stack([torch.as_tensor(x, dtype=torch.float64, device=self._dev).reshape(()) for x in g])
+
+    def _nd_band_predict(self, lay, Xnew, chunk=8192):
+        key = self.theta()
+        if self._post is None or self._post[0] != key:
+            f = self._nd_band_factor(lay)
+            sig = self._nd_band_sigma(lay, f)
+            M, pat = self.Mtot, lay["pat"]
+            rows, cols = lay["rows"][pat], torch.arange(M, device=self._dev).view(-1, 1).expand_as(pat)[pat]
+            vals = sig[pat]
+            off = rows != cols
+            Sp = torch.sparse_coo_tensor(torch.stack((torch.cat((rows, cols[off])), torch.cat((cols, rows[off])))), torch.cat((vals, vals[off])),
+                                         (M, M)).coalesce()
+            Sd = [utils.band_to_dense_sym(S.view(self.order + 1, m)) for S, m in zip(f["Ss"], lay["ms"])]
+            self._post = (key, f["alpha"], Sp, Sd)
+        _, alpha, Sp, Sd = self._post
+        X = _to_device(Xnew, self._dev)
+        vprod = float(np.prod([float(k.variance) for k in self.kernels]))
+        means, vars_ = [], []
+        for lo in range(0, X.shape[0], chunk):
+            Xc = X[lo:lo + chunk]
+            Phi = self._dense_rows(Xc)
+            means.append(Phi.t() @ alpha.view(-1, 1))
+            qp = (Phi * torch.sparse.mm(Sp, Phi)).sum(0)            # phi*^T band(P^-1) phi*: phi* touches band entries only
+            qk = None
+            for i, bs in enumerate(self.bases):
+                Pt = bs.evaluate_basis(Xc[:, i:i + 1].contiguous(), sparse=False)
+                q = (Pt * (Sd[i] @ Pt)).sum(0)
+                qk = q if qk is None else qk * q
+            vars_.append((vprod + qp - qk).reshape(-1, 1))
+        return torch.cat(means), torch.cat(vars_)
+
     def _dense_elbo_and_grad(self, want_grad=True):
+        lay = self._nd_band_layout()
+        if lay is not None:
+            return self._nd_band_elbo_and_grad(lay, want_grad)
         f = self._dense_factor()
         s, N, A, bvec = f["s"], float(self.num_data), self.KufKfu, self.Kuf_y
         vs = [float(k.variance) for k in self.kernels]
@@ -574,6 +730,9 @@ class GPR_kron(_GPModelSurface, _ShardedStats):
         return elbo, torch.stack([x.reshape(()) for x in g])
 
     def _dense_predict(self, Xnew, chunk=8192):
+        lay = self._nd_band_layout()
+        if lay is not None:
+            return self._nd_band_predict(lay, Xnew, chunk)
         f = self._dense_factor()
         s = f["s"]
         alpha = torch.cholesky_solve(self.Kuf_y, f["LP"]) / s

@@ -12,10 +12,13 @@ min_m = {1: 4, 2: 7, 3: 9, 4: 12}
 fails = 0
 for case in range(n_cases):
     kron = rng.random() < 0.6
-    d = 2 if kron else int(rng.integers(1, 5))
+    d = (2 if rng.random() < 0.75 else 3) if kron else int(rng.integers(1, 5))     # (d = 3: the band route for P, round 4)
     kds = [int(rng.integers(0, 3)) for _ in range(d)]
     order = int(rng.choice(sorted(set.intersection(*[set(orders_for[k]) for k in kds]))))
-    ms = [int(rng.integers(min_m[order], 26)) for _ in range(d)]
+    if kron and d == 3 and order > 2:                             # (the dense long-double oracle of a d = 3 case: M_tot <= 1000)
+        kds = [0, 0, int(rng.integers(0, 2))] if order > 2 else kds
+        order = int(rng.choice(sorted(set.intersection(*[set(orders_for[k]) for k in kds]) & {1, 2})))
+    ms = [int(rng.integers(min_m[order], 26 if not (kron and d == 3) else min_m[order] + 3)) for _ in range(d)]
     N = int(rng.integers(200, 20000))
     X = rng.uniform(0.001, 0.999, (N, d))
     if rng.random() < 0.3: X[:, 0] = np.sort(X[:, 0])
@@ -31,12 +34,14 @@ for case in range(n_cases):
         if kron:
             model = A.GPR_kron((X, y), kerns, bases); model.likelihood.variance.assign(s)
             model.twisted = [None, True, False][int(rng.integers(0, 3))]      # two-sided factorisation: by size / wherever it fits / never
+            if d == 3 and rng.random() < 0.3:
+                model.nd_banded = False                                       # (the dense route of d != 2)
             oe, parts = O.elbo_kron(obases, kds, th, s, X, y)
             e, g = model.elbo_and_grad()
             om, ov = O.predict_f_kron(obases, kds, th, s, X, y, Xs)
             fd = O.elbo_grad_kron(obases, kds, th, s, X, y)[1]      # the dense analytic gradient (differences of the bound lose ~1e-4 here)
             eg = np.max(np.abs(g - fd) / (np.abs(fd) + np.max(np.abs(fd))))
-            vs = th[0][0] * th[1][0]
+            vs = float(np.prod([v for v, _ in th]))
             xe = O.elbo_kron_extended(obases, kds, th, s, X, y)       # the dense bound in long double: how far is the fp64 oracle itself?
             kron_slack = 5 * abs(oe - xe)
             e_ref = xe

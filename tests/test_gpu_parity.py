@@ -972,6 +972,54 @@ def test_kron_three_dimensions_dense_route_vs_oracle(A):
     np.testing.assert_allclose(var[:, :1], ov[:, :1] if ov.ndim == 2 else ov.reshape(-1, 1), rtol=0, atol=1e-8)
     res = model.fit(maxiter=2)
     assert np.isfinite(res.fun)
+    # round 4: P is factored as a BAND matrix (bandwidth k (m2 m3 + m3 + 1)) by the band Cholesky kernel, the gradient and the posterior come
+    # from the band-restricted inverse; the dense factorisations remain for bands that do not fit - both routes, same numbers
+    model = A.GPR_kron((X, y), [_kernel(A, kd, v, l) for kd, (v, l) in zip(kinds, th)], bases)
+    model.likelihood.variance.assign(s)
+    lay = model._nd_band_layout()
+    assert lay is not None and lay["bw"] == 2 * (8 * 9 + 9 + 1)
+    dense = A.GPR_kron((X, y), [_kernel(A, kd, v, l) for kd, (v, l) in zip(kinds, th)], bases)
+    dense.likelihood.variance.assign(s)
+    dense.nd_banded = False
+    assert dense._nd_band_layout() is None
+    eb, gb = model.elbo_and_grad()
+    ed, gd = dense.elbo_and_grad()
+    assert abs(eb - ed) <= 1e-10 * abs(ed)
+    np.testing.assert_allclose(gb, gd, rtol=1e-7, atol=1e-7 * np.max(np.abs(gd)))
+    mb, vb = model.predict_f(Xs)
+    md, vd = dense.predict_f(Xs)
+    np.testing.assert_allclose(mb, md, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vb, vd, rtol=0, atol=1e-9)
+
+
+def test_kron_four_dimensions_band_route_vs_dense_route(A):
+    """d = 4 (kronecker.py:32-33 folds over any d): the band route (bandwidth k (m2 m3 m4 + m3 m4 + m4 + 1)) against the dense route and the oracle."""
+    rng = np.random.default_rng(34)
+    N = 3000
+    X = rng.uniform(0.001, 0.999, (N, 4))
+    y = (np.sin(4 * X[:, :1]) + X[:, 1:2] * X[:, 2:3] - np.cos(3 * X[:, 3:]) + 0.1 * rng.standard_normal((N, 1)))
+    ms, kinds, th, s = [5, 6, 4, 5], [0, 0, 0, 0], [(1.0, 0.5), (0.8, 0.6), (1.2, 0.4), (0.9, 0.7)], 0.08
+    bases = [_mk_basis(A, 1, 0, 1, m) for m in ms]
+    mk = lambda: [_kernel(A, kd, v, l) for kd, (v, l) in zip(kinds, th)]
+    model = A.GPR_kron((X, y), mk(), bases)
+    model.likelihood.variance.assign(s)
+    lay = model._nd_band_layout()
+    assert lay is not None and lay["bw"] == 1 * (6 * 4 * 5 + 4 * 5 + 5 + 1)
+    dense = A.GPR_kron((X, y), mk(), bases)
+    dense.likelihood.variance.assign(s)
+    dense.nd_banded = False
+    eb, gb = model.elbo_and_grad()
+    ed, gd = dense.elbo_and_grad()
+    assert abs(eb - ed) <= 1e-10 * abs(ed)
+    np.testing.assert_allclose(gb, gd, rtol=1e-7, atol=1e-7 * np.max(np.abs(gd)))
+    oe, og = O.elbo_grad_kron([O.Basis(1, 0, 1, m) for m in ms], kinds, th, s, X, y)
+    assert abs(eb - oe) <= 1e-9 * abs(oe) + 1e-8 * (0.5 * N / s)
+    np.testing.assert_allclose(gb, og, rtol=1e-6, atol=1e-6 * np.max(np.abs(og)))
+    Xs = rng.uniform(0.01, 0.99, (150, 4))
+    mb, vb = model.predict_f(Xs)
+    md, vd = dense.predict_f(Xs)
+    np.testing.assert_allclose(mb, md, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vb, vd, rtol=0, atol=1e-9)
 
 
 # ------------------------------------------------------------------------------------------------ additive model
