@@ -3,6 +3,9 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "band_sweeps.hpp"
 
 namespace asvgp {
@@ -28,6 +31,131 @@ template <int K>
 __global__ __launch_bounds__(64) void cholesky_band_kernel(const double* A, double* L, int M, int* info) {
   cholesky_sweep<double, K, false>(BandPtr<double>{A, nullptr}, BandOut<double>{L, nullptr}, M, nullptr, nullptr, info);
 }
+// ---------------------------------------------------------------------------------------------------------
+// The two operator recurrences with the WHOLE band in the LDS (round 4; M (k+1) doubles <= 156 KB: M <= 4000 at k = 4).
+// The register-window sweeps above keep row i on lane i mod (k+1) and pay ~500 instructions per column for v_readlane traffic with
+// run-time lane indices and lane-select chains (1.06 / 0.60 ms at M = 2048).  Here the band is staged into the LDS by the whole
+// workgroup (coalesced), ONE wave then runs the recurrence with every lane holding the same (k+1) x (k+1) register window - all
+// operands are broadcast LDS reads, no cross-lane instruction on the chain, reciprocal square roots by Newton steps on v_rsq_f64 -,
+// the result goes back to the LDS and the workgroup stores it coalesced.  What is left per column is the dependent chain itself
+// (rsqrt -> scale -> the next pivot's update): ~35 instructions.
+// ---------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __restrict__ A, double* __restrict__ L, int M, int* __restrict__ info) {
+  extern __shared__ double bs_lds[];                  // [K+1][M]: the band, overwritten by the factor column by column
+  const int tid = threadIdx.x;
+  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) bs_lds[e] = A[e];
+  __syncthreads();
+  if (tid < 64) {
+    double w[K + 1][K + 1];                           // w[c][d]: entry (j + c + d, j + c) of the matrix as updated so far (window of k+1 columns)
+#pragma unroll
+    for (int c = 0; c <= K; ++c)
+#pragma unroll
+      for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? bs_lds[(long)d * M + c] : 0.0;
+    int bad = 0;
+    // one column; CHECK = false: every row j + d and the column j + k + 1 exist (no bounds tests, no branches in the block of k+1 columns)
+    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+      constexpr int jm = decltype(jm_c)::value;
+      constexpr bool CHECK = decltype(check_c)::value;
+      const double piv = w[jm][0];
+      bad = (!(piv > 0.0) && !bad) ? j + 1 : bad;
+      double y = __builtin_amdgcn_rsq(piv);           // 1 / sqrt(piv): two Newton steps (<= 2e-16 relative)
+      const double hh = 0.5 * piv;
+      y = fma(y, fma(-hh * y, y, 0.5), y);
+      y = fma(y, fma(-hh * y, y, 0.5), y);
+      double l[K + 1];
+      {
+        const double g = piv * y;                     // sqrt(piv), one correction
+        l[0] = fma(fma(-g, g, piv), 0.5 * y, g);
+      }
+#pragma unroll
+      for (int d = 1; d <= K; ++d) l[d] = (!CHECK || j + d < M) ? w[jm][d] * y : 0.0;
+#pragma unroll
+      for (int c = 1; c <= K; ++c)                    // the k columns behind it
+#pragma unroll
+        for (int d = 0; d + c <= K; ++d) w[(jm + c) % (K + 1)][d] = fma(-l[c + d], l[c], w[(jm + c) % (K + 1)][d]);
+#pragma unroll
+      for (int d = 0; d <= K; ++d) bs_lds[(long)d * M + j] = l[d];      // (every lane: the same value to the same address)
+      const int jn = j + K + 1;                       // the window slot takes column j + k + 1 (untouched so far, never the address just written)
+#pragma unroll
+      for (int d = 0; d <= K; ++d) w[jm][d] = (!CHECK || jn < M) ? bs_lds[(long)d * M + jn] : 0.0;
+    };
+    int jb = 0;
+    for (; jb + 2 * K + 1 < M; jb += K + 1) {         // full blocks: unrolled k+1 times, every window index a compile-time constant
+      [&]<int... JM>(std::integer_sequence<int, JM...>) { (column(jb + JM, std::integral_constant<int, JM>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K + 1>{});
+    }
+    for (; jb < M; jb += K + 1) {
+      [&]<int... JM>(std::integer_sequence<int, JM...>) { ((jb + JM < M ? column(jb + JM, std::integral_constant<int, JM>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K + 1>{});
+    }
+    if (info && tid == 0) *info = bad;
+  }
+  __syncthreads();
+  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) L[e] = bs_lds[e];
+}
+
+// S = band((L L^T)^-1) backwards, the factor in the LDS and overwritten column by column:
+//   S(i, j) = ([i = j] / L_jj - sum_{p = j+1 .. j+k} L(p, j) S(max(p, i), min(p, i))) / L_jj,   i = j+k .. j.
+// Every lane holds the symmetric k x k window S(j+1 .. j+k, j+1 .. j+k) in registers (column c in slot c mod k: the new column j takes
+// the slot of column j + k, which is read for the last time while column j is formed); the loop is unrolled k times.
+template <int K>
+__global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __restrict__ L, double* __restrict__ S, int M) {
+  extern __shared__ double bs_lds[];                  // [K+1][M]
+  const int tid = threadIdx.x;
+  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) bs_lds[e] = L[e];
+  __syncthreads();
+  if (tid < 64) {
+    double sw[K][K];                                  // sw[a][b] = S(row in slot a, column in slot b), both orders kept
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+      for (int b = 0; b < K; ++b) sw[a][b] = 0.0;
+    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+      constexpr int jm = decltype(jm_c)::value;       // j mod K
+      constexpr bool CHECK = decltype(check_c)::value;
+      double l[K + 1];
+#pragma unroll
+      for (int d = 0; d <= K; ++d) l[d] = bs_lds[(long)d * M + j];
+      if (CHECK) {
+#pragma unroll
+        for (int d = 1; d <= K; ++d) l[d] = (j + d < M) ? l[d] : 0.0;
+      }
+      double inv = __builtin_amdgcn_rcp(l[0]);        // 1 / L_jj: two Newton steps
+      inv = fma(inv, fma(-l[0], inv, 1.0), inv);
+      inv = fma(inv, fma(-l[0], inv, 1.0), inv);
+      double sn[K + 1];                               // the new column: sn[d] = S(j + d, j)
+#pragma unroll
+      for (int d = K; d >= 1; --d) {                  // i = j + d: sum over p = j+1 .. j+k of L(p, j) S(p, i), all from the window
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 1; c <= K; ++c) acc = fma(-l[c], sw[(jm + c) % K][(jm + d) % K], acc);
+        sn[d] = acc * inv;
+      }
+      {
+        double acc = inv;                             // i = j: [i = j] / L_jj - sum_p L(p, j) S(p, j), with the entries just formed
+#pragma unroll
+        for (int c = 1; c <= K; ++c) acc = fma(-l[c], sn[c], acc);
+        sn[0] = acc * inv;
+      }
+#pragma unroll
+      for (int d = 0; d <= K; ++d) bs_lds[(long)d * M + j] = (!CHECK || j + d < M) ? sn[d] : 0.0;
+      // column j into the window: slot jm = j mod K (it held column j + K: (jm + K) % K), rows j .. j + K - 1
+      sw[jm][jm] = sn[0];
+#pragma unroll
+      for (int d = 1; d < K; ++d) { sw[(jm + d) % K][jm] = sn[d]; sw[jm][(jm + d) % K] = sn[d]; }
+    };
+    const int top = ((M + K - 1) / K) * K;
+    int jb = top - K;
+    for (; jb >= 0 && jb + 2 * K > M; jb -= K) {      // the last blocks: rows beyond the matrix
+      [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - 1 - JR) < M ? column(jb + (K - 1 - JR), std::integral_constant<int, K - 1 - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K>{});
+    }
+    for (; jb >= 0; jb -= K) {
+      [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + (K - 1 - JR), std::integral_constant<int, K - 1 - JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K>{});
+    }
+  }
+  __syncthreads();
+  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) S[e] = bs_lds[e];
+}
+
 template <int K>
 __global__ __launch_bounds__(64) void takahashi_kernel(const double* L, double* S, int M) {
   takahashi_sweep<double, K, false>(BandPtr<double>{L, nullptr}, BandOut<double>{S, nullptr}, M, nullptr, nullptr);
@@ -148,12 +276,30 @@ static int dispatch_k(int k, Args... args) {
 }
 template <int K> struct CholLauncher {
   static int run(const double* A, double* L, int M, int* info, hipStream_t st) {
+    const size_t lds_bytes = sizeof(double) * (size_t)(K + 1) * (size_t)M;
+    static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;      // (0: the register-window sweep always)
+    if (!lds_off && lds_bytes <= 156 * 1024 && M > K + 1) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_band_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess) {
+        hipLaunchKernelGGL(cholesky_band_lds_kernel<K>, dim3(1), dim3(256), lds_bytes, st, A, L, M, info);
+        return check_launch("cholesky_band (band in the LDS)");
+      }
+      (void)hipGetLastError();
+    }
     hipLaunchKernelGGL(cholesky_band_kernel<K>, dim3(1), dim3(64), 0, st, A, L, M, info);
     return check_launch("cholesky_band");
   }
 };
 template <int K> struct TakaLauncher {
   static int run(const double* L, double* S, int M, hipStream_t st) {
+    const size_t lds_bytes = sizeof(double) * (size_t)(K + 1) * (size_t)M;
+    static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
+    if (!lds_off && lds_bytes <= 156 * 1024 && M > 2 * K + 1) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(takahashi_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess) {
+        hipLaunchKernelGGL(takahashi_lds_kernel<K>, dim3(1), dim3(256), lds_bytes, st, L, S, M);
+        return check_launch("inverse_from_cholesky_band (band in the LDS)");
+      }
+      (void)hipGetLastError();
+    }
     hipLaunchKernelGGL(takahashi_kernel<K>, dim3(1), dim3(64), 0, st, L, S, M);
     return check_launch("inverse_from_cholesky_band");
   }
