@@ -620,6 +620,98 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_wave_kernel(const doub
     }
   }
 }
+// Adjoint of the band Cholesky in the lane-uniform register-window form of cholesky_band_lds_kernel (round 4): L and the incoming
+// adjoint in the LDS (2 (k+1) M doubles), ONE wave, every lane the same window - the k+1 columns j-k .. j of L and of the running
+// adjoint, slot = column mod (k+1).  A column's adjoint entries are final when the column is reached, so the running adjoint lives in
+// registers only: it is read from the LDS once, when the column enters the window, and never written back.
+//   for j = M-1 .. 0:  i = j+k .. j:   sb = Lb(i,j) / L_jj  (i = j: Lb(j,j) / (2 L_jj), after Lb(j,j) -= sum_i Lb(i,j) L(i,j) / L_jj)
+//                      Kb(i,j) = sb;   for p = i-k .. j-1:  Lb(i,p) -= sb L(j,p),  Lb(j,p) -= sb L(i,p)
+template <int K>
+__global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ Lbar, double* __restrict__ Kbar, int M) {
+  extern __shared__ double sh[];
+  const long E = (long)(K + 1) * M;
+  double* Ls = sh;                                    // L
+  double* Bs = sh + E;                                // incoming adjoint, overwritten by the result column by column
+  const int tid = threadIdx.x;
+  for (long e = tid; e < E; e += blockDim.x) { Ls[e] = L[e]; Bs[e] = Lbar[e]; }
+  __syncthreads();
+  if (tid < 64) {
+    double wl[K + 1][K + 1], wb[K + 1][K + 1];        // slot s = column mod (k+1): wl[s][d] = L(p + d, p), wb[s][d] = running adjoint of it
+    const int jtop = M - 1;
+#pragma unroll
+    for (int c = 0; c <= K; ++c) {                    // columns jtop - c
+      const int p = jtop - c;
+#pragma unroll
+      for (int sl = 0; sl <= K; ++sl)
+        if (((p % (K + 1)) + (K + 1)) % (K + 1) == sl) {
+#pragma unroll
+          for (int d = 0; d <= K; ++d) { wl[sl][d] = (p >= 0) ? Ls[(long)d * M + p] : 0.0; wb[sl][d] = (p >= 0) ? Bs[(long)d * M + p] : 0.0; }
+        }
+    }
+    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+      constexpr int jm = decltype(jm_c)::value;       // j mod (K+1)
+      constexpr bool CHECK = decltype(check_c)::value;
+      double inv = __builtin_amdgcn_rcp(wl[jm][0]);
+      inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
+      inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
+      double kb[K + 1];
+#pragma unroll
+      for (int d = K; d >= 0; --d) {                  // i = j + d, descending
+        const bool rowok = !CHECK || j + d < M;
+        double sb;
+        if (d == 0) sb = 0.5 * wb[jm][0] * inv;
+        else {
+          const double lb = rowok ? wb[jm][d] : 0.0;
+          sb = lb * inv;
+          wb[jm][0] = fma(-sb, wl[jm][d], wb[jm][0]);
+        }
+        kb[d] = rowok ? sb : 0.0;
+#pragma unroll
+        for (int c = 1; c + d <= K; ++c) {            // p = j - c >= i - k
+          const int sp = ((jm - c) % (K + 1) + (K + 1)) % (K + 1);
+          if (!CHECK || (j - c >= 0 && rowok)) {
+            const double lip = wl[sp][d + c], ljp = wl[sp][c];
+            if (d != 0) {
+              wb[sp][d + c] = fma(-sb, ljp, wb[sp][d + c]);
+              wb[sp][c] = fma(-sb, lip, wb[sp][c]);
+            } else {
+              wb[sp][c] = fma(-2.0 * sb, ljp, wb[sp][c]);      // i = j: the two updates hit the same entry (j, p)
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d <= K; ++d) Bs[(long)d * M + j] = kb[d];
+      const int pn = j - K - 1;                       // the slot takes column j - k - 1 (its incoming adjoint is still untouched in the LDS)
+#pragma unroll
+      for (int d = 0; d <= K; ++d) {
+        wl[jm][d] = (!CHECK || pn >= 0) ? Ls[(long)d * M + (pn >= 0 ? pn : 0)] : 0.0;
+        wb[jm][d] = (!CHECK || pn >= 0) ? Bs[(long)d * M + (pn >= 0 ? pn : 0)] : 0.0;
+      }
+    };
+    // blocks of k+1 columns, descending; the blocks that touch either end of the matrix carry the bounds tests
+    int jb = ((M - 1) / (K + 1)) * (K + 1);
+    for (; jb >= 0; jb -= K + 1) {
+      const bool edge = jb + 2 * K + 1 >= M || jb - K - 1 < 0;
+      if (edge) {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - JR) < M ? column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K + 1>{});
+      } else {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K + 1>{});
+      }
+    }
+  }
+  __syncthreads();
+  for (long e = tid; e < E; e += blockDim.x) Kbar[e] = Bs[e];
+}
+
+template <int K> struct CholVjpLdsLauncher {
+  static int run(const double* L, const double* Lbar, double* Kbar, int M, size_t bytes, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_cholesky_vjp_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+    hipLaunchKernelGGL(band_cholesky_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, Lbar, Kbar, M);
+    return check_launch("cholesky_band_vjp (register window)");
+  }
+};
 template <int K> struct CholVjpWaveLauncher {
   static int run(const double* L, const double* Lbar, double* Kbar, int M, size_t bytes, hipStream_t st) {
     if constexpr ((K + 1) * (K + 1) <= 64) {
@@ -662,6 +754,11 @@ extern "C" int asvgp_cholesky_band_vjp(const double* L, const double* Lbar, doub
   if (!Kbar || !work) { set_error("cholesky_band_vjp: bad argument"); return ASVGP_ERR_BAD_ARG; }
   const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
   const int use_lds = bytes <= 160 * 1024;
+  static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
+  if (use_lds && !lds_off && M > 2 * (k + 1)) {                 // lane-uniform register window (round 4)
+    const int rcl = dispatch_k<CholVjpLdsLauncher>(k, L, Lbar, Kbar, (int)M, bytes, as_stream(stream));
+    if (rcl != 1) return rcl;
+  }
   if (use_lds && (k + 1) * (k + 1) <= 64) {                     // wave-parallel form
     const int rcw = dispatch_k<CholVjpWaveLauncher>(k, L, Lbar, Kbar, (int)M, bytes, as_stream(stream));
     if (rcw != 1) return rcw;
