@@ -416,7 +416,8 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
 // Reverse mode of the four operators the reference's bound differentiates through (gpr.py:56-75; banded_matrices registers these
 // gradients for its TF ops).  The two recurrences are the adjoints of the column loops.  Single-thread sweeps (below) are the general
 // fallback (5.6 / 7.9 ms at M = 2048, k = 4); the wave-parallel forms further down take over whenever (k + 1)^2 <= 64 and the two
-// arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms, on a par with the forward operators (1.05 / 0.59 ms).  The training path
+// arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms; since round 4 the lane-uniform register-window forms at the end of this
+// section run first (0.32 / 0.44 ms; the forward operators: 0.26 / 0.26 ms).  The training path
 // of this library is still the fused asvgp_elbo_grad_1d (one launch, analytic gradient); these make a per-op binding usable.
 // ---------------------------------------------------------------------------------------------------------
 __device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
@@ -704,6 +705,122 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
   for (long e = tid; e < E; e += blockDim.x) Kbar[e] = Bs[e];
 }
 
+// Adjoint of the band-restricted inverse in the same form (round 4).  The recurrence only READS its three inputs, in ascending column
+// order, and its running state - the adjoint of S inside the (k+1) x (k+1) window the column touches - lives in registers, so the LDS
+// is a low-latency staging area: S and the incoming adjoint (2 (k+1) M doubles); L comes from global memory, one block of k+1 columns
+// ahead of its use (vector loads into registers: a block is > 1000 cycles), and the result goes straight to global memory.  ONE wave,
+// every lane the same window: the symmetric entries (r, c), j <= c <= r <= j + k, of S and of its adjoint at [r mod (k+1)][c mod (k+1)];
+// column j consumes column j of the window and the row slot it frees takes row j + k + 1.
+//   for j = 0 .. M-1, i = j .. j+k:  accb = Sb(i,j) / L_jj;  lb_0 -= accb S(i,j)  [- accb / L_jj^2 at i = j]
+//                                     for p = j+1 .. j+k:  lb_{p-j} -= accb S(p,i),  Sb(p,i) -= accb L(p,j)      (symmetric entries)
+template <int K>
+__global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ S, const double* __restrict__ Sbar,
+                                                                     double* __restrict__ Lbar, int M) {
+  extern __shared__ double sh[];
+  constexpr int W = K + 1;
+  const long E = (long)W * M;
+  double* Ss = sh;
+  double* Bs = sh + E;
+  const int tid = threadIdx.x;
+  for (long e = tid; e < E; e += blockDim.x) { Ss[e] = S[e]; Bs[e] = Sbar[e]; }
+  __syncthreads();
+  if (tid >= 64) return;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));                        // (an opaque zero: keeps the loads of L on the vector memory counter, apart from the LDS reads)
+  const double* Lv = L + vz;
+  double* Ov = Lbar + vz;
+  double sw[W][W], bw[W][W];
+#pragma unroll
+  for (int a = 0; a <= K; ++a)
+#pragma unroll
+    for (int b = 0; b <= K; ++b) {
+      const bool in = b <= a && a < M;
+      sw[a][b] = in ? Ss[(long)(a - b) * M + b] : 0.0;
+      bw[a][b] = in ? Bs[(long)(a - b) * M + b] : 0.0;
+    }
+  double lq[W][W];                                    // the NEXT block's columns: lq[c][d] = L(jb + W + c + d, jb + W + c)
+  auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
+    constexpr bool CHECK = decltype(check_c)::value;
+#pragma unroll
+    for (int c = 0; c <= K; ++c)
+#pragma unroll
+      for (int d = 0; d <= K; ++d) {
+        const bool in = !CHECK || j0 + c + d < M;
+        lq[c][d] = Lv[in ? (long)d * M + j0 + c : 0];
+        if (!in) lq[c][d] = 0.0;
+      }
+  };
+  double lc[W][W];
+  auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+    constexpr int jm = decltype(jm_c)::value;         // j mod (K+1)
+    constexpr bool CHECK = decltype(check_c)::value;
+    double sn[W], bn[W];
+    const int rn = j + K + 1;                         // the row that enters after this column: entries (rn, j + 1 + b) = band row k - b
+#pragma unroll
+    for (int b = 0; b <= K; ++b) {
+      const bool in = !CHECK || rn < M;
+      const long o = in ? (long)(K - b) * M + j + 1 + b : 0;
+      sn[b] = Ss[o];
+      bn[b] = Bs[o];
+      if (!in) { sn[b] = 0.0; bn[b] = 0.0; }
+    }
+    const double l0 = lc[jm][0];
+    double inv = __builtin_amdgcn_rcp(l0);
+    inv = fma(inv, fma(-l0, inv, 1.0), inv);
+    inv = fma(inv, fma(-l0, inv, 1.0), inv);
+    double lb[W];
+#pragma unroll
+    for (int d = 0; d <= K; ++d) lb[d] = 0.0;
+#pragma unroll
+    for (int a = 0; a <= K; ++a) {                    // i = j + a
+      const int rs = (jm + a) % W;
+      const double sb = (!CHECK || j + a < M) ? bw[rs][jm] : 0.0;
+      const double accb = sb * inv;
+      lb[0] = fma(-accb, sw[rs][jm], lb[0]);
+      if (a == 0) lb[0] = fma(-accb, inv * inv, lb[0]);
+#pragma unroll
+      for (int c = 1; c <= K; ++c) {                  // p = j + c
+        const int hs = (jm + (c > a ? c : a)) % W, ls = (jm + (c > a ? a : c)) % W;
+        if (!CHECK || j + c < M) {
+          lb[c] = fma(-accb, sw[hs][ls], lb[c]);
+          bw[hs][ls] = fma(-accb, lc[jm][c], bw[hs][ls]);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d <= K; ++d) Ov[(long)d * M + j] = (!CHECK || j + d < M) ? lb[d] : 0.0;   // (every lane: the same value to the same address)
+#pragma unroll
+    for (int b = 0; b <= K; ++b) { sw[jm][(jm + 1 + b) % W] = sn[b]; bw[jm][(jm + 1 + b) % W] = bn[b]; }
+  };
+  fetch(0, std::true_type{});
+  for (int jb = 0; jb < M; jb += W) {                 // blocks of k+1 columns; the blocks near the end of the matrix carry the bounds tests
+#pragma unroll
+    for (int c = 0; c <= K; ++c)
+#pragma unroll
+      for (int d = 0; d <= K; ++d) lc[c][d] = lq[c][d];
+    const bool edge = jb + 3 * K + 2 >= M;            // (rows up to jb + 3k + 2 are touched by the next block's loads)
+    if (edge) {
+      fetch(jb + W, std::true_type{});
+      [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+    } else {
+      fetch(jb + W, std::false_type{});
+      [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+    }
+  }
+}
+
+template <int K> struct TakaVjpLdsLauncher {
+  static int run(const double* L, const double* S, const double* Sbar, double* Lbar, int M, size_t bytes, hipStream_t st) {
+    if constexpr (K <= 6) {                           // (k = 7, 8: the two windows and two blocks of L no longer fit the register file)
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_takahashi_vjp_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+      hipLaunchKernelGGL(band_takahashi_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, S, Sbar, Lbar, M);
+      return check_launch("inverse_from_cholesky_band_vjp (register window)");
+    } else {
+      return 1;
+    }
+  }
+};
 template <int K> struct CholVjpLdsLauncher {
   static int run(const double* L, const double* Lbar, double* Kbar, int M, size_t bytes, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_cholesky_vjp_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -778,6 +895,11 @@ extern "C" int asvgp_inverse_from_cholesky_band_vjp(const double* L, const doubl
   if (!Sbar || !Lbar || !work) { set_error("inverse_from_cholesky_band_vjp: bad argument"); return ASVGP_ERR_BAD_ARG; }
   const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
   const int use_lds = bytes <= 160 * 1024;
+  static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
+  if (use_lds && !lds_off && M > 2 * (k + 1)) {                 // lane-uniform register window (round 4)
+    const int rcl = dispatch_k<TakaVjpLdsLauncher>(k, L, S, Sbar, Lbar, (int)M, bytes, as_stream(stream));
+    if (rcl != 1) return rcl;
+  }
   if (use_lds && (k + 1) * (k + 1) <= 64) {                     // wave-parallel form
     const int rcw = dispatch_k<TakaVjpWaveLauncher>(k, L, S, Sbar, Lbar, work, (int)M, bytes, as_stream(stream));
     if (rcw != 1) return rcw;
