@@ -42,16 +42,18 @@ __global__ __launch_bounds__(64) void cholesky_band_kernel(const double* A, doub
 // ---------------------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __restrict__ A, double* __restrict__ L, int M, int* __restrict__ info) {
-  extern __shared__ double bs_lds[];                  // [K+1][M]: the band, overwritten by the factor column by column
+  extern __shared__ double bs_lds[];                  // [M][K+1], a column's k+1 entries side by side (two-address LDS instructions: 3 per column
+                                                      // instead of 5 - a lone wave pays ~8 cycles per instruction of any kind); overwritten by the factor
   const int tid = threadIdx.x;
-  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) bs_lds[e] = A[e];
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c < M; c += blockDim.x) bs_lds[(long)c * (K + 1) + d] = A[(long)d * M + c];
   __syncthreads();
   if (tid < 64) {
     double w[K + 1][K + 1];                           // w[c][d]: entry (j + c + d, j + c) of the matrix as updated so far (window of k+1 columns)
 #pragma unroll
     for (int c = 0; c <= K; ++c)
 #pragma unroll
-      for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? bs_lds[(long)d * M + c] : 0.0;
+      for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? bs_lds[(long)c * (K + 1) + d] : 0.0;
     int bad = 0;
     // one column; CHECK = false: every row j + d and the column j + k + 1 exist (no bounds tests, no branches in the block of k+1 columns)
     auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
@@ -75,10 +77,10 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
 #pragma unroll
         for (int d = 0; d + c <= K; ++d) w[(jm + c) % (K + 1)][d] = fma(-l[c + d], l[c], w[(jm + c) % (K + 1)][d]);
 #pragma unroll
-      for (int d = 0; d <= K; ++d) bs_lds[(long)d * M + j] = l[d];      // (every lane: the same value to the same address)
+      for (int d = 0; d <= K; ++d) bs_lds[(long)j * (K + 1) + d] = l[d];      // (every lane: the same value to the same address)
       const int jn = j + K + 1;                       // the window slot takes column j + k + 1 (untouched so far, never the address just written)
 #pragma unroll
-      for (int d = 0; d <= K; ++d) w[jm][d] = (!CHECK || jn < M) ? bs_lds[(long)d * M + jn] : 0.0;
+      for (int d = 0; d <= K; ++d) w[jm][d] = (!CHECK || jn < M) ? bs_lds[(long)jn * (K + 1) + d] : 0.0;
     };
     int jb = 0;
     for (; jb + 2 * K + 1 < M; jb += K + 1) {         // full blocks: unrolled k+1 times, every window index a compile-time constant
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
     if (info && tid == 0) *info = bad;
   }
   __syncthreads();
-  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) L[e] = bs_lds[e];
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c < M; c += blockDim.x) L[(long)d * M + c] = bs_lds[(long)c * (K + 1) + d];
 }
 
 // S = band((L L^T)^-1) backwards, the factor in the LDS and overwritten column by column:
@@ -99,9 +102,10 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
 // the slot of column j + k, which is read for the last time while column j is formed); the loop is unrolled k times.
 template <int K>
 __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __restrict__ L, double* __restrict__ S, int M) {
-  extern __shared__ double bs_lds[];                  // [K+1][M]
+  extern __shared__ double bs_lds[];                  // [M][K+1] (as above)
   const int tid = threadIdx.x;
-  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) bs_lds[e] = L[e];
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c < M; c += blockDim.x) bs_lds[(long)c * (K + 1) + d] = L[(long)d * M + c];
   __syncthreads();
   if (tid < 64) {
     double sw[K][K];                                  // sw[a][b] = S(row in slot a, column in slot b), both orders kept
@@ -109,19 +113,30 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
     for (int a = 0; a < K; ++a)
 #pragma unroll
       for (int b = 0; b < K; ++b) sw[a][b] = 0.0;
+    // column j - 1 of L and its reciprocal diagonal are fetched while column j is formed (L is only read: nothing on the dependent
+    // chain, but the LDS read could not move above the stores of the column before it, nor the reciprocal above the read)
+    double ln[K + 1], invn;
+    auto fetch = [&](int jn) __attribute__((always_inline)) {
+      const int jc = jn >= 0 ? jn : 0;
+#pragma unroll
+      for (int d = 0; d <= K; ++d) ln[d] = bs_lds[(long)jc * (K + 1) + d];
+      invn = __builtin_amdgcn_rcp(ln[0]);             // 1 / L_jj: two Newton steps
+      invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+      invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+    };
+    fetch(M - 1);
     auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
       constexpr int jm = decltype(jm_c)::value;       // j mod K
       constexpr bool CHECK = decltype(check_c)::value;
       double l[K + 1];
 #pragma unroll
-      for (int d = 0; d <= K; ++d) l[d] = bs_lds[(long)d * M + j];
+      for (int d = 0; d <= K; ++d) l[d] = ln[d];
       if (CHECK) {
 #pragma unroll
         for (int d = 1; d <= K; ++d) l[d] = (j + d < M) ? l[d] : 0.0;
       }
-      double inv = __builtin_amdgcn_rcp(l[0]);        // 1 / L_jj: two Newton steps
-      inv = fma(inv, fma(-l[0], inv, 1.0), inv);
-      inv = fma(inv, fma(-l[0], inv, 1.0), inv);
+      const double inv = invn;
+      fetch(j - 1);
       double sn[K + 1];                               // the new column: sn[d] = S(j + d, j)
 #pragma unroll
       for (int d = K; d >= 1; --d) {                  // i = j + d: sum over p = j+1 .. j+k of L(p, j) S(p, i), all from the window
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
         sn[0] = acc * inv;
       }
 #pragma unroll
-      for (int d = 0; d <= K; ++d) bs_lds[(long)d * M + j] = (!CHECK || j + d < M) ? sn[d] : 0.0;
+      for (int d = 0; d <= K; ++d) bs_lds[(long)j * (K + 1) + d] = (!CHECK || j + d < M) ? sn[d] : 0.0;
       // column j into the window: slot jm = j mod K (it held column j + K: (jm + K) % K), rows j .. j + K - 1
       sw[jm][jm] = sn[0];
 #pragma unroll
@@ -153,7 +168,8 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
     }
   }
   __syncthreads();
-  for (long e = tid; e < (long)(K + 1) * M; e += blockDim.x) S[e] = bs_lds[e];
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c < M; c += blockDim.x) S[(long)d * M + c] = bs_lds[(long)c * (K + 1) + d];
 }
 
 template <int K>
@@ -417,7 +433,7 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
 // gradients for its TF ops).  The two recurrences are the adjoints of the column loops.  Single-thread sweeps (below) are the general
 // fallback (5.6 / 7.9 ms at M = 2048, k = 4); the wave-parallel forms further down take over whenever (k + 1)^2 <= 64 and the two
 // arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms; since round 4 the lane-uniform register-window forms at the end of this
-// section run first (0.32 / 0.44 ms; the forward operators: 0.26 / 0.26 ms).  The training path
+// section run first (0.31 / 0.39 ms; the forward operators: 0.25 / 0.25 ms).  The training path
 // of this library is still the fused asvgp_elbo_grad_1d (one launch, analytic gradient); these make a per-op binding usable.
 // ---------------------------------------------------------------------------------------------------------
 __device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
@@ -634,7 +650,8 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
   double* Ls = sh;                                    // L
   double* Bs = sh + E;                                // incoming adjoint, overwritten by the result column by column
   const int tid = threadIdx.x;
-  for (long e = tid; e < E; e += blockDim.x) { Ls[e] = L[e]; Bs[e] = Lbar[e]; }
+  for (int d = 0; d <= K; ++d)                        // (both [M][K+1]: a column's entries side by side)
+    for (int c = tid; c < M; c += blockDim.x) { Ls[(long)c * (K + 1) + d] = L[(long)d * M + c]; Bs[(long)c * (K + 1) + d] = Lbar[(long)d * M + c]; }
   __syncthreads();
   if (tid < 64) {
     double wl[K + 1][K + 1], wb[K + 1][K + 1];        // slot s = column mod (k+1): wl[s][d] = L(p + d, p), wb[s][d] = running adjoint of it
@@ -646,7 +663,7 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
       for (int sl = 0; sl <= K; ++sl)
         if (((p % (K + 1)) + (K + 1)) % (K + 1) == sl) {
 #pragma unroll
-          for (int d = 0; d <= K; ++d) { wl[sl][d] = (p >= 0) ? Ls[(long)d * M + p] : 0.0; wb[sl][d] = (p >= 0) ? Bs[(long)d * M + p] : 0.0; }
+          for (int d = 0; d <= K; ++d) { wl[sl][d] = (p >= 0) ? Ls[(long)p * (K + 1) + d] : 0.0; wb[sl][d] = (p >= 0) ? Bs[(long)p * (K + 1) + d] : 0.0; }
         }
     }
     auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
@@ -682,12 +699,12 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
         }
       }
 #pragma unroll
-      for (int d = 0; d <= K; ++d) Bs[(long)d * M + j] = kb[d];
+      for (int d = 0; d <= K; ++d) Bs[(long)j * (K + 1) + d] = kb[d];
       const int pn = j - K - 1;                       // the slot takes column j - k - 1 (its incoming adjoint is still untouched in the LDS)
 #pragma unroll
       for (int d = 0; d <= K; ++d) {
-        wl[jm][d] = (!CHECK || pn >= 0) ? Ls[(long)d * M + (pn >= 0 ? pn : 0)] : 0.0;
-        wb[jm][d] = (!CHECK || pn >= 0) ? Bs[(long)d * M + (pn >= 0 ? pn : 0)] : 0.0;
+        wl[jm][d] = (!CHECK || pn >= 0) ? Ls[(long)(pn >= 0 ? pn : 0) * (K + 1) + d] : 0.0;
+        wb[jm][d] = (!CHECK || pn >= 0) ? Bs[(long)(pn >= 0 ? pn : 0) * (K + 1) + d] : 0.0;
       }
     };
     // blocks of k+1 columns, descending; the blocks that touch either end of the matrix carry the bounds tests
@@ -702,111 +719,187 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
     }
   }
   __syncthreads();
-  for (long e = tid; e < E; e += blockDim.x) Kbar[e] = Bs[e];
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c < M; c += blockDim.x) Kbar[(long)d * M + c] = Bs[(long)c * (K + 1) + d];
 }
 
 // Adjoint of the band-restricted inverse in the same form (round 4).  The recurrence only READS its three inputs, in ascending column
-// order, and its running state - the adjoint of S inside the (k+1) x (k+1) window the column touches - lives in registers, so the LDS
-// is a low-latency staging area: S and the incoming adjoint (2 (k+1) M doubles); L comes from global memory, one block of k+1 columns
-// ahead of its use (vector loads into registers: a block is > 1000 cycles), and the result goes straight to global memory.  ONE wave,
-// every lane the same window: the symmetric entries (r, c), j <= c <= r <= j + k, of S and of its adjoint at [r mod (k+1)][c mod (k+1)];
-// column j consumes column j of the window and the row slot it frees takes row j + k + 1.
+// order; its running state is the adjoint of S inside the symmetric (k+1) x (k+1) window a column touches:
 //   for j = 0 .. M-1, i = j .. j+k:  accb = Sb(i,j) / L_jj;  lb_0 -= accb S(i,j)  [- accb / L_jj^2 at i = j]
 //                                     for p = j+1 .. j+k:  lb_{p-j} -= accb S(p,i),  Sb(p,i) -= accb L(p,j)      (symmetric entries)
+// A lone wave issues one fp64 instruction per ~8 cycles (all four operator kernels measure instructions x 8 cycles), so the column's
+// 56 operations are split over TWO waves on different SIMDs with a one-directional hand-over: wave 0 carries the state (the window
+// of Sb, at [r mod (k+1)][c mod (k+1)]; Sb's incoming rows from the LDS, L from global memory one block of k+1 columns ahead) and
+// leaves the k+1 factors accb of every column in an LDS array; wave 1 follows a block behind, holds the same window of S (from global
+// memory, a block ahead) and forms the results lb from the factors.  Wave 0 never waits for wave 1; wave 1 polls a progress counter
+// once per block (it sits in the one slot of the factor array that belongs to no (row, column): (M - 1 + k, M - 1)).
 template <int K>
 __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ S, const double* __restrict__ Sbar,
                                                                      double* __restrict__ Lbar, int M) {
   extern __shared__ double sh[];
   constexpr int W = K + 1;
   const long E = (long)W * M;
-  double* Ss = sh;
-  double* Bs = sh + E;
+  double* Bs = sh;                                    // incoming adjoint of S by ROWS: (r, r - d) at [r W + d] (a row enters the window at a time)
+  double* Fq = sh + E;                                // accb(j + a, j) at [j W + a]
+  int* prog = reinterpret_cast<int*>(Fq + E - 1);     // columns wave 0 has finished
   const int tid = threadIdx.x;
-  for (long e = tid; e < E; e += blockDim.x) { Ss[e] = S[e]; Bs[e] = Sbar[e]; }
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c + d < M; c += blockDim.x) Bs[(long)(c + d) * W + d] = Sbar[(long)d * M + c];
+  if (tid == 0) *prog = 0;
   __syncthreads();
-  if (tid >= 64) return;
   int vz = 0;
-  asm volatile("" : "+v"(vz));                        // (an opaque zero: keeps the loads of L on the vector memory counter, apart from the LDS reads)
+  asm volatile("" : "+v"(vz));                        // (an opaque zero: keeps the global loads on the vector memory counter, apart from the LDS reads)
   const double* Lv = L + vz;
-  double* Ov = Lbar + vz;
-  double sw[W][W], bw[W][W];
+  const double* Sv = S + vz;
+  if (tid < 64) {
+    // ---------------- wave 0: the window of Sb, the factors
+    double bw[W][W];
 #pragma unroll
-  for (int a = 0; a <= K; ++a)
+    for (int a = 0; a <= K; ++a)
 #pragma unroll
-    for (int b = 0; b <= K; ++b) {
-      const bool in = b <= a && a < M;
-      sw[a][b] = in ? Ss[(long)(a - b) * M + b] : 0.0;
-      bw[a][b] = in ? Bs[(long)(a - b) * M + b] : 0.0;
-    }
-  double lq[W][W];                                    // the NEXT block's columns: lq[c][d] = L(jb + W + c + d, jb + W + c)
-  auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
-    constexpr bool CHECK = decltype(check_c)::value;
+      for (int b = 0; b <= K; ++b) bw[a][b] = (b <= a && a < M) ? Bs[(long)a * W + (a - b)] : 0.0;
+    double lq[W][W], lc[W][W];                        // lq: the NEXT block's columns, lq[c][d] = L(jb + W + c + d, jb + W + c)
+    auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
+      constexpr bool CHECK = decltype(check_c)::value;
 #pragma unroll
-    for (int c = 0; c <= K; ++c)
+      for (int c = 0; c <= K; ++c)
 #pragma unroll
-      for (int d = 0; d <= K; ++d) {
-        const bool in = !CHECK || j0 + c + d < M;
-        lq[c][d] = Lv[in ? (long)d * M + j0 + c : 0];
-        if (!in) lq[c][d] = 0.0;
+        for (int d = 0; d <= K; ++d) {
+          const bool in = !CHECK || j0 + c + d < M;
+          lq[c][d] = Lv[in ? (long)d * M + j0 + c : 0];
+          if (!in) lq[c][d] = 0.0;
+        }
+    };
+    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+      constexpr int jm = decltype(jm_c)::value;       // j mod (K+1)
+      constexpr bool CHECK = decltype(check_c)::value;
+      double bn[W];
+      const int rn = j + K + 1;                       // the row that enters after this column: entries (rn, j + 1 + b) = band row k - b
+#pragma unroll
+      for (int b = 0; b <= K; ++b) {
+        const bool in = !CHECK || rn < M;
+        bn[b] = Bs[in ? (long)rn * W + (K - b) : 0];
+        if (!in) bn[b] = 0.0;
       }
-  };
-  double lc[W][W];
-  auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
-    constexpr int jm = decltype(jm_c)::value;         // j mod (K+1)
-    constexpr bool CHECK = decltype(check_c)::value;
-    double sn[W], bn[W];
-    const int rn = j + K + 1;                         // the row that enters after this column: entries (rn, j + 1 + b) = band row k - b
+      const double l0 = lc[jm][0];
+      double inv = __builtin_amdgcn_rcp(l0);
+      inv = fma(inv, fma(-l0, inv, 1.0), inv);
+      inv = fma(inv, fma(-l0, inv, 1.0), inv);
 #pragma unroll
-    for (int b = 0; b <= K; ++b) {
-      const bool in = !CHECK || rn < M;
-      const long o = in ? (long)(K - b) * M + j + 1 + b : 0;
-      sn[b] = Ss[o];
-      bn[b] = Bs[o];
-      if (!in) { sn[b] = 0.0; bn[b] = 0.0; }
-    }
-    const double l0 = lc[jm][0];
-    double inv = __builtin_amdgcn_rcp(l0);
-    inv = fma(inv, fma(-l0, inv, 1.0), inv);
-    inv = fma(inv, fma(-l0, inv, 1.0), inv);
-    double lb[W];
+      for (int a = 0; a <= K; ++a) {                  // i = j + a
+        const int rs = (jm + a) % W;
+        const bool rowok = !CHECK || j + a < M;
+        const double accb = (rowok ? bw[rs][jm] : 0.0) * inv;
+        if (rowok) Fq[(long)j * W + a] = accb;
 #pragma unroll
-    for (int d = 0; d <= K; ++d) lb[d] = 0.0;
-#pragma unroll
-    for (int a = 0; a <= K; ++a) {                    // i = j + a
-      const int rs = (jm + a) % W;
-      const double sb = (!CHECK || j + a < M) ? bw[rs][jm] : 0.0;
-      const double accb = sb * inv;
-      lb[0] = fma(-accb, sw[rs][jm], lb[0]);
-      if (a == 0) lb[0] = fma(-accb, inv * inv, lb[0]);
-#pragma unroll
-      for (int c = 1; c <= K; ++c) {                  // p = j + c
-        const int hs = (jm + (c > a ? c : a)) % W, ls = (jm + (c > a ? a : c)) % W;
-        if (!CHECK || j + c < M) {
-          lb[c] = fma(-accb, sw[hs][ls], lb[c]);
-          bw[hs][ls] = fma(-accb, lc[jm][c], bw[hs][ls]);
+        for (int c = 1; c <= K; ++c) {                // p = j + c
+          const int hs = (jm + (c > a ? c : a)) % W, ls = (jm + (c > a ? a : c)) % W;
+          if (!CHECK || j + c < M) bw[hs][ls] = fma(-accb, lc[jm][c], bw[hs][ls]);
         }
       }
+#pragma unroll
+      for (int b = 0; b <= K; ++b) bw[jm][(jm + 1 + b) % W] = bn[b];
+    };
+    fetch(0, std::true_type{});
+    for (int jb = 0; jb < M; jb += W) {
+#pragma unroll
+      for (int c = 0; c <= K; ++c)
+#pragma unroll
+        for (int d = 0; d <= K; ++d) lc[c][d] = lq[c][d];
+      const bool edge = jb + 3 * K + 3 >= M;          // (rows up to jb + 3k + 2 are touched by the next block's loads)
+      if (edge) {
+        fetch(jb + W, std::true_type{});
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+      } else {
+        fetch(jb + W, std::false_type{});
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __hip_atomic_store(prog, jb + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+  } else if (tid < 128) {
+    // ---------------- wave 1: the window of S, the results (they take the place of the column's factors in the LDS)
+    double sw[W][W];
 #pragma unroll
-    for (int d = 0; d <= K; ++d) Ov[(long)d * M + j] = (!CHECK || j + d < M) ? lb[d] : 0.0;   // (every lane: the same value to the same address)
+    for (int a = 0; a <= K; ++a)
 #pragma unroll
-    for (int b = 0; b <= K; ++b) { sw[jm][(jm + 1 + b) % W] = sn[b]; bw[jm][(jm + 1 + b) % W] = bn[b]; }
-  };
-  fetch(0, std::true_type{});
-  for (int jb = 0; jb < M; jb += W) {                 // blocks of k+1 columns; the blocks near the end of the matrix carry the bounds tests
+      for (int b = 0; b <= K; ++b) {
+        const bool in = b <= a && a < M;
+        sw[a][b] = Sv[in ? (long)(a - b) * M + b : 0];
+        if (!in) sw[a][b] = 0.0;
+      }
+    double sq[W][W], sc[W][W], dq[W], dc[W];          // the NEXT block: sq[c][b] = S(j + k + 1, j + 1 + b), dq[c] = L(j, j), j = jb + W + c
+    auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
+      constexpr bool CHECK = decltype(check_c)::value;
 #pragma unroll
-    for (int c = 0; c <= K; ++c)
+      for (int c = 0; c <= K; ++c) {
+        const bool inr = !CHECK || j0 + c + K + 1 < M;
 #pragma unroll
-      for (int d = 0; d <= K; ++d) lc[c][d] = lq[c][d];
-    const bool edge = jb + 3 * K + 2 >= M;            // (rows up to jb + 3k + 2 are touched by the next block's loads)
-    if (edge) {
-      fetch(jb + W, std::true_type{});
-      [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
-    } else {
-      fetch(jb + W, std::false_type{});
-      [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+        for (int b = 0; b <= K; ++b) {
+          sq[c][b] = Sv[inr ? (long)(K - b) * M + j0 + c + 1 + b : 0];
+          if (!inr) sq[c][b] = 0.0;
+        }
+        const bool ind = !CHECK || j0 + c < M;
+        dq[c] = Lv[ind ? j0 + c : 0];
+      }
+    };
+    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+      constexpr int jm = decltype(jm_c)::value;
+      constexpr bool CHECK = decltype(check_c)::value;
+      double accb[W];
+#pragma unroll
+      for (int a = 0; a <= K; ++a) {
+        const bool rowok = !CHECK || j + a < M;
+        accb[a] = Fq[rowok ? (long)j * W + a : 0];
+        if (!rowok) accb[a] = 0.0;
+      }
+      const double l0 = dc[jm];
+      double inv = __builtin_amdgcn_rcp(l0);
+      inv = fma(inv, fma(-l0, inv, 1.0), inv);
+      inv = fma(inv, fma(-l0, inv, 1.0), inv);
+      double lb[W];
+#pragma unroll
+      for (int d = 0; d <= K; ++d) lb[d] = 0.0;
+#pragma unroll
+      for (int a = 0; a <= K; ++a) {
+        const int rs = (jm + a) % W;
+        lb[0] = fma(-accb[a], sw[rs][jm], lb[0]);
+        if (a == 0) lb[0] = fma(-accb[a], inv * inv, lb[0]);
+#pragma unroll
+        for (int c = 1; c <= K; ++c) {
+          const int hs = (jm + (c > a ? c : a)) % W, ls = (jm + (c > a ? a : c)) % W;
+          if (!CHECK || j + c < M) lb[c] = fma(-accb[a], sw[hs][ls], lb[c]);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d <= K; ++d)
+        if (!CHECK || j + d < M) Fq[(long)j * W + d] = lb[d];   // (every lane: the same value to the same address)
+#pragma unroll
+      for (int b = 0; b <= K; ++b) sw[jm][(jm + 1 + b) % W] = sc[jm][b];
+    };
+    fetch(0, std::true_type{});
+    for (int jb = 0; jb < M; jb += W) {
+#pragma unroll
+      for (int c = 0; c <= K; ++c) {
+        dc[c] = dq[c];
+#pragma unroll
+        for (int b = 0; b <= K; ++b) sc[c][b] = sq[c][b];
+      }
+      const bool edge = jb + 3 * K + 3 >= M;
+      if (edge) fetch(jb + W, std::true_type{});
+      else fetch(jb + W, std::false_type{});
+      while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + W) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (edge) {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+      } else {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+      }
     }
   }
+  __syncthreads();
+  for (int d = 0; d <= K; ++d)
+    for (int c = tid; c < M; c += blockDim.x) Lbar[(long)d * M + c] = (c + d < M) ? Fq[(long)c * W + d] : 0.0;
 }
 
 template <int K> struct TakaVjpLdsLauncher {
