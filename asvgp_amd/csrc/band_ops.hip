@@ -643,84 +643,101 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_wave_kernel(const doub
 // registers only: it is read from the LDS once, when the column enters the window, and never written back.
 //   for j = M-1 .. 0:  i = j+k .. j:   sb = Lb(i,j) / L_jj  (i = j: Lb(j,j) / (2 L_jj), after Lb(j,j) -= sum_i Lb(i,j) L(i,j) / L_jj)
 //                      Kb(i,j) = sb;   for p = i-k .. j-1:  Lb(i,p) -= sb L(j,p),  Lb(j,p) -= sb L(i,p)
+// Any M: the columns are walked in SEGMENTS of `seg_blocks` blocks of k+1 columns; a segment's columns of L and of the incoming adjoint
+// (+ the k+1 columns below it, which enter the window while it is walked) are staged into the LDS by the whole workgroup, the window
+// registers carry over from segment to segment, the segment's results leave through the LDS.  M (k+1) 16 B <= 160 KB is one segment.
 template <int K>
-__global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ Lbar, double* __restrict__ Kbar, int M) {
+__global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ Lbar, double* __restrict__ Kbar, int M,
+                                                                    int seg_blocks, int cap_cols) {
   extern __shared__ double sh[];
-  const long E = (long)(K + 1) * M;
-  double* Ls = sh;                                    // L
-  double* Bs = sh + E;                                // incoming adjoint, overwritten by the result column by column
+  constexpr int W = K + 1;
+  double* Ls = sh;                                    // L, [column - lbase][K+1]: a column's entries side by side
+  double* Bs = sh + (long)cap_cols * W;               // incoming adjoint, overwritten by the result column by column
   const int tid = threadIdx.x;
-  for (int d = 0; d <= K; ++d)                        // (both [M][K+1]: a column's entries side by side)
-    for (int c = tid; c < M; c += blockDim.x) { Ls[(long)c * (K + 1) + d] = L[(long)d * M + c]; Bs[(long)c * (K + 1) + d] = Lbar[(long)d * M + c]; }
-  __syncthreads();
-  if (tid < 64) {
-    double wl[K + 1][K + 1], wb[K + 1][K + 1];        // slot s = column mod (k+1): wl[s][d] = L(p + d, p), wb[s][d] = running adjoint of it
+  double wl[W][W], wb[W][W];                          // slot s = column mod (k+1): wl[s][d] = L(p + d, p), wb[s][d] = running adjoint of it
+  const int nblk = (M + W - 1) / W;
+  {                                                   // the window of the first column walked: columns M-1 .. M-1-k
     const int jtop = M - 1;
 #pragma unroll
-    for (int c = 0; c <= K; ++c) {                    // columns jtop - c
+    for (int c = 0; c <= K; ++c) {
       const int p = jtop - c;
 #pragma unroll
       for (int sl = 0; sl <= K; ++sl)
-        if (((p % (K + 1)) + (K + 1)) % (K + 1) == sl) {
+        if (((p % W) + W) % W == sl) {
 #pragma unroll
-          for (int d = 0; d <= K; ++d) { wl[sl][d] = (p >= 0) ? Ls[(long)p * (K + 1) + d] : 0.0; wb[sl][d] = (p >= 0) ? Bs[(long)p * (K + 1) + d] : 0.0; }
+          for (int d = 0; d <= K; ++d) {
+            wl[sl][d] = (p >= 0) ? L[(long)d * M + (p >= 0 ? p : 0)] : 0.0;
+            wb[sl][d] = (p >= 0) ? Lbar[(long)d * M + (p >= 0 ? p : 0)] : 0.0;
+          }
         }
     }
-    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
-      constexpr int jm = decltype(jm_c)::value;       // j mod (K+1)
-      constexpr bool CHECK = decltype(check_c)::value;
-      double inv = __builtin_amdgcn_rcp(wl[jm][0]);
-      inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
-      inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
-      double kb[K + 1];
+  }
+  for (int b1 = nblk; b1 > 0; b1 -= seg_blocks) {
+    const int b0 = b1 - seg_blocks > 0 ? b1 - seg_blocks : 0;
+    const int c0 = b0 * W, c1 = b1 * W < M ? b1 * W : M;
+    const int lbase = c0 - W > 0 ? c0 - W : 0;        // first staged column
+    for (int d = 0; d <= K; ++d)
+      for (int c = lbase + tid; c < c1; c += blockDim.x) { Ls[(long)(c - lbase) * W + d] = L[(long)d * M + c]; Bs[(long)(c - lbase) * W + d] = Lbar[(long)d * M + c]; }
+    __syncthreads();
+    if (tid < 64) {
+      auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+        constexpr int jm = decltype(jm_c)::value;     // j mod (K+1)
+        constexpr bool CHECK = decltype(check_c)::value;
+        double inv = __builtin_amdgcn_rcp(wl[jm][0]);
+        inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
+        inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
+        double kb[W];
 #pragma unroll
-      for (int d = K; d >= 0; --d) {                  // i = j + d, descending
-        const bool rowok = !CHECK || j + d < M;
-        double sb;
-        if (d == 0) sb = 0.5 * wb[jm][0] * inv;
-        else {
-          const double lb = rowok ? wb[jm][d] : 0.0;
-          sb = lb * inv;
-          wb[jm][0] = fma(-sb, wl[jm][d], wb[jm][0]);
-        }
-        kb[d] = rowok ? sb : 0.0;
+        for (int d = K; d >= 0; --d) {                // i = j + d, descending
+          const bool rowok = !CHECK || j + d < M;
+          double sb;
+          if (d == 0) sb = 0.5 * wb[jm][0] * inv;
+          else {
+            const double lb = rowok ? wb[jm][d] : 0.0;
+            sb = lb * inv;
+            wb[jm][0] = fma(-sb, wl[jm][d], wb[jm][0]);
+          }
+          kb[d] = rowok ? sb : 0.0;
 #pragma unroll
-        for (int c = 1; c + d <= K; ++c) {            // p = j - c >= i - k
-          const int sp = ((jm - c) % (K + 1) + (K + 1)) % (K + 1);
-          if (!CHECK || (j - c >= 0 && rowok)) {
-            const double lip = wl[sp][d + c], ljp = wl[sp][c];
-            if (d != 0) {
-              wb[sp][d + c] = fma(-sb, ljp, wb[sp][d + c]);
-              wb[sp][c] = fma(-sb, lip, wb[sp][c]);
-            } else {
-              wb[sp][c] = fma(-2.0 * sb, ljp, wb[sp][c]);      // i = j: the two updates hit the same entry (j, p)
+          for (int c = 1; c + d <= K; ++c) {          // p = j - c >= i - k
+            const int sp = ((jm - c) % W + W) % W;
+            if (!CHECK || (j - c >= 0 && rowok)) {
+              const double lip = wl[sp][d + c], ljp = wl[sp][c];
+              if (d != 0) {
+                wb[sp][d + c] = fma(-sb, ljp, wb[sp][d + c]);
+                wb[sp][c] = fma(-sb, lip, wb[sp][c]);
+              } else {
+                wb[sp][c] = fma(-2.0 * sb, ljp, wb[sp][c]);    // i = j: the two updates hit the same entry (j, p)
+              }
             }
           }
         }
-      }
 #pragma unroll
-      for (int d = 0; d <= K; ++d) Bs[(long)j * (K + 1) + d] = kb[d];
-      const int pn = j - K - 1;                       // the slot takes column j - k - 1 (its incoming adjoint is still untouched in the LDS)
+        for (int d = 0; d <= K; ++d) Bs[(long)(j - lbase) * W + d] = kb[d];
+        const int pn = j - K - 1;                     // the slot takes column j - k - 1 (its incoming adjoint is still untouched in the LDS)
 #pragma unroll
-      for (int d = 0; d <= K; ++d) {
-        wl[jm][d] = (!CHECK || pn >= 0) ? Ls[(long)(pn >= 0 ? pn : 0) * (K + 1) + d] : 0.0;
-        wb[jm][d] = (!CHECK || pn >= 0) ? Bs[(long)(pn >= 0 ? pn : 0) * (K + 1) + d] : 0.0;
+        for (int d = 0; d <= K; ++d) {
+          wl[jm][d] = (!CHECK || pn >= 0) ? Ls[(long)(pn >= 0 ? pn - lbase : 0) * W + d] : 0.0;
+          wb[jm][d] = (!CHECK || pn >= 0) ? Bs[(long)(pn >= 0 ? pn - lbase : 0) * W + d] : 0.0;
+        }
+      };
+      // blocks of k+1 columns, descending; the blocks that touch either end of the matrix carry the bounds tests
+      int jb = (b1 - 1) * W;
+      for (; jb >= c0 && jb + 2 * K + 1 >= M; jb -= W) {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - JR) < M ? column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
       }
-    };
-    // blocks of k+1 columns, descending; the blocks that touch either end of the matrix carry the bounds tests
-    int jb = ((M - 1) / (K + 1)) * (K + 1);
-    for (; jb >= 0; jb -= K + 1) {
-      const bool edge = jb + 2 * K + 1 >= M || jb - K - 1 < 0;
-      if (edge) {
-        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - JR) < M ? column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K + 1>{});
-      } else {
-        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K + 1>{});
+      for (; jb >= c0 && jb - K - 1 >= 0; jb -= W) {  // (no bounds tests, no branches)
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+      }
+      for (; jb >= c0; jb -= W) {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - JR) < M ? column(jb + (K - JR), std::integral_constant<int, K - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
       }
     }
+    __syncthreads();
+    for (int d = 0; d <= K; ++d)
+      for (int c = c0 + tid; c < c1; c += blockDim.x) Kbar[(long)d * M + c] = Bs[(long)(c - lbase) * W + d];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c < M; c += blockDim.x) Kbar[(long)d * M + c] = Bs[(long)c * (K + 1) + d];
 }
 
 // Adjoint of the band-restricted inverse in the same form (round 4).  The recurrence only READS its three inputs, in ascending column
@@ -733,20 +750,36 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
 // leaves the k+1 factors accb of every column in an LDS array; wave 1 follows a block behind, holds the same window of S (from global
 // memory, a block ahead) and forms the results lb from the factors.  Wave 0 never waits for wave 1; wave 1 polls a progress counter
 // once per block (it sits in the one slot of the factor array that belongs to no (row, column): (M - 1 + k, M - 1)).
+// Any M: SEGMENTS of `seg_blocks` blocks of k+1 columns, as in the adjoint of the band Cholesky above - the rows of the incoming adjoint
+// that enter the window while the segment is walked and the segment's factor / result columns are what the LDS holds; the register
+// windows, the blocks fetched ahead and the progress counter carry over.  Both waves and the two idle ones pass the same barriers.
 template <int K>
 __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ S, const double* __restrict__ Sbar,
-                                                                     double* __restrict__ Lbar, int M) {
+                                                                     double* __restrict__ Lbar, int M, int seg_blocks, int cap_rows, int cap_fq) {
   extern __shared__ double sh[];
   constexpr int W = K + 1;
-  const long E = (long)W * M;
-  double* Bs = sh;                                    // incoming adjoint of S by ROWS: (r, r - d) at [r W + d] (a row enters the window at a time)
-  double* Fq = sh + E;                                // accb(j + a, j) at [j W + a]
-  int* prog = reinterpret_cast<int*>(Fq + E - 1);     // columns wave 0 has finished
+  double* Bs = sh;                                    // incoming adjoint of S by ROWS: (r, r - d) at [(r - rbase) W + d] (a row enters the window at a time)
+  double* Fq = sh + (long)cap_rows * W;               // accb(j + a, j) at [(j - c0) W + a], then the column's results
+  int* prog = reinterpret_cast<int*>(Fq + cap_fq - 1);   // columns wave 0 has finished (a slot no column uses: see the launcher)
   const int tid = threadIdx.x;
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c + d < M; c += blockDim.x) Bs[(long)(c + d) * W + d] = Sbar[(long)d * M + c];
+  const int nblk = (M + W - 1) / W;
+  int c0 = 0, c1 = 0, rbase = 0;
+  // a segment's rows of the incoming adjoint: those that enter the window while it is walked (the first segment: the first window too)
+  auto stage = [&](int b0) __attribute__((always_inline)) {
+    const int b1 = b0 + seg_blocks < nblk ? b0 + seg_blocks : nblk;
+    c0 = b0 * W;
+    c1 = b1 * W < M ? b1 * W : M;
+    rbase = b0 == 0 ? 0 : c0 + W;
+    const int rend = c1 + W < M ? c1 + W : M;
+    for (int d = 0; d <= K; ++d)
+      for (int r = rbase + tid; r < rend; r += blockDim.x)
+        if (r - d >= 0) Bs[(long)(r - rbase) * W + d] = Sbar[(long)d * M + (r - d)];
+  };
+  auto copy_out = [&]() __attribute__((always_inline)) {
+    for (int d = 0; d <= K; ++d)
+      for (int c = c0 + tid; c < c1; c += blockDim.x) Lbar[(long)d * M + c] = (c + d < M) ? Fq[(long)(c - c0) * W + d] : 0.0;
+  };
   if (tid == 0) *prog = 0;
-  __syncthreads();
   int vz = 0;
   asm volatile("" : "+v"(vz));                        // (an opaque zero: keeps the global loads on the vector memory counter, apart from the LDS reads)
   const double* Lv = L + vz;
@@ -754,10 +787,6 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
   if (tid < 64) {
     // ---------------- wave 0: the window of Sb, the factors
     double bw[W][W];
-#pragma unroll
-    for (int a = 0; a <= K; ++a)
-#pragma unroll
-      for (int b = 0; b <= K; ++b) bw[a][b] = (b <= a && a < M) ? Bs[(long)a * W + (a - b)] : 0.0;
     double lq[W][W], lc[W][W];                        // lq: the NEXT block's columns, lq[c][d] = L(jb + W + c + d, jb + W + c)
     auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
       constexpr bool CHECK = decltype(check_c)::value;
@@ -778,7 +807,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 #pragma unroll
       for (int b = 0; b <= K; ++b) {
         const bool in = !CHECK || rn < M;
-        bn[b] = Bs[in ? (long)rn * W + (K - b) : 0];
+        bn[b] = Bs[in ? (long)(rn - rbase) * W + (K - b) : 0];
         if (!in) bn[b] = 0.0;
       }
       const double l0 = lc[jm][0];
@@ -790,7 +819,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         const int rs = (jm + a) % W;
         const bool rowok = !CHECK || j + a < M;
         const double accb = (rowok ? bw[rs][jm] : 0.0) * inv;
-        if (rowok) Fq[(long)j * W + a] = accb;
+        if (rowok) Fq[(long)(j - c0) * W + a] = accb;
 #pragma unroll
         for (int c = 1; c <= K; ++c) {                // p = j + c
           const int hs = (jm + (c > a ? c : a)) % W, ls = (jm + (c > a ? a : c)) % W;
@@ -801,21 +830,36 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
       for (int b = 0; b <= K; ++b) bw[jm][(jm + 1 + b) % W] = bn[b];
     };
     fetch(0, std::true_type{});
-    for (int jb = 0; jb < M; jb += W) {
+    for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {
+      stage(b0);
+      __syncthreads();
+      if (b0 == 0) {
 #pragma unroll
-      for (int c = 0; c <= K; ++c)
+        for (int a = 0; a <= K; ++a)
 #pragma unroll
-        for (int d = 0; d <= K; ++d) lc[c][d] = lq[c][d];
-      const bool edge = jb + 3 * K + 3 >= M;          // (rows up to jb + 3k + 2 are touched by the next block's loads)
-      if (edge) {
-        fetch(jb + W, std::true_type{});
-        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
-      } else {
-        fetch(jb + W, std::false_type{});
-        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+          for (int b = 0; b <= K; ++b) bw[a][b] = (b <= a && a < M) ? Bs[(long)a * W + (a - b)] : 0.0;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __hip_atomic_store(prog, jb + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      auto block = [&](int jb, auto check_c) __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(check_c)::value;
+#pragma unroll
+        for (int c = 0; c <= K; ++c)
+#pragma unroll
+          for (int d = 0; d <= K; ++d) lc[c][d] = lq[c][d];
+        fetch(jb + W, check_c);
+        if constexpr (CHECK) {
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+        } else {
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(prog, jb + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      int jb = c0;
+      for (; jb < c1 && jb + 3 * K + 3 < M; jb += W) block(jb, std::false_type{});   // (rows up to jb + 3k + 2 are touched by the next block's loads)
+      for (; jb < c1; jb += W) block(jb, std::true_type{});
+      __syncthreads();
+      copy_out();
+      __syncthreads();
     }
   } else if (tid < 128) {
     // ---------------- wave 1: the window of S, the results (they take the place of the column's factors in the LDS)
@@ -850,7 +894,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 #pragma unroll
       for (int a = 0; a <= K; ++a) {
         const bool rowok = !CHECK || j + a < M;
-        accb[a] = Fq[rowok ? (long)j * W + a : 0];
+        accb[a] = Fq[rowok ? (long)(j - c0) * W + a : 0];
         if (!rowok) accb[a] = 0.0;
       }
       const double l0 = dc[jm];
@@ -873,41 +917,71 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
       }
 #pragma unroll
       for (int d = 0; d <= K; ++d)
-        if (!CHECK || j + d < M) Fq[(long)j * W + d] = lb[d];   // (every lane: the same value to the same address)
+        if (!CHECK || j + d < M) Fq[(long)(j - c0) * W + d] = lb[d];   // (every lane: the same value to the same address)
 #pragma unroll
       for (int b = 0; b <= K; ++b) sw[jm][(jm + 1 + b) % W] = sc[jm][b];
     };
     fetch(0, std::true_type{});
-    for (int jb = 0; jb < M; jb += W) {
+    for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {
+      stage(b0);
+      __syncthreads();
+      auto block = [&](int jb, auto check_c) __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(check_c)::value;
 #pragma unroll
-      for (int c = 0; c <= K; ++c) {
-        dc[c] = dq[c];
+        for (int c = 0; c <= K; ++c) {
+          dc[c] = dq[c];
 #pragma unroll
-        for (int b = 0; b <= K; ++b) sc[c][b] = sq[c][b];
-      }
-      const bool edge = jb + 3 * K + 3 >= M;
-      if (edge) fetch(jb + W, std::true_type{});
-      else fetch(jb + W, std::false_type{});
-      while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + W) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (edge) {
-        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
-      } else {
-        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
-      }
+          for (int b = 0; b <= K; ++b) sc[c][b] = sq[c][b];
+        }
+        fetch(jb + W, check_c);
+        while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + W) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (CHECK) {
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+        } else {
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+        }
+      };
+      int jb = c0;
+      for (; jb < c1 && jb + 3 * K + 3 < M; jb += W) block(jb, std::false_type{});
+      for (; jb < c1; jb += W) block(jb, std::true_type{});
+      __syncthreads();
+      copy_out();
+      __syncthreads();
+    }
+  } else {
+    for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {   // the two idle waves stage and store with the others
+      stage(b0);
+      __syncthreads();
+      __syncthreads();
+      copy_out();
+      __syncthreads();
     }
   }
-  __syncthreads();
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c < M; c += blockDim.x) Lbar[(long)d * M + c] = (c + d < M) ? Fq[(long)c * W + d] : 0.0;
 }
 
 template <int K> struct TakaVjpLdsLauncher {
-  static int run(const double* L, const double* S, const double* Sbar, double* Lbar, int M, size_t bytes, hipStream_t st) {
-    if constexpr (K <= 6) {                           // (k = 7, 8: the two windows and two blocks of L no longer fit the register file)
+  static int run(const double* L, const double* S, const double* Sbar, double* Lbar, int M, hipStream_t st) {
+    if constexpr (K <= 6) {                           // (k = 7, 8: the windows and the blocks fetched ahead no longer fit the register file)
+      constexpr int W = K + 1;
+      const int nblk = (M + W - 1) / W;
+      // one segment: rows and factor columns of the whole matrix, the counter in the slot of (row M - 1 + k, column M - 1), which no column
+      // uses; several: seg W + W rows, seg W columns and one more double for the counter
+      int seg, cap_rows, cap_fq;
+      static const int seg_env = getenv("ASVGP_BAND_OPS_SEG_BLOCKS") ? atoi(getenv("ASVGP_BAND_OPS_SEG_BLOCKS")) : 0;   // (tests: short segments)
+      if ((size_t)2 * M * W * sizeof(double) <= 160 * 1024 && !(seg_env >= 2 && seg_env < nblk)) { seg = nblk; cap_rows = M; cap_fq = M * W; }
+      else {
+        const int doubles = 160 * 1024 / (int)sizeof(double);
+        seg = ((doubles - 1) / W - W) / (2 * W);
+        if (seg_env >= 2 && seg_env < seg) seg = seg_env;
+        cap_rows = seg * W + W;
+        cap_fq = seg * W * W + 1;
+      }
+      if (seg < 2) return 1;
+      const size_t bytes = sizeof(double) * ((size_t)cap_rows * W + (size_t)cap_fq);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_takahashi_vjp_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
-      hipLaunchKernelGGL(band_takahashi_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, S, Sbar, Lbar, M);
+      hipLaunchKernelGGL(band_takahashi_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, S, Sbar, Lbar, M, seg, cap_rows, cap_fq);
       return check_launch("inverse_from_cholesky_band_vjp (register window)");
     } else {
       return 1;
@@ -915,10 +989,18 @@ template <int K> struct TakaVjpLdsLauncher {
   }
 };
 template <int K> struct CholVjpLdsLauncher {
-  static int run(const double* L, const double* Lbar, double* Kbar, int M, size_t bytes, hipStream_t st) {
+  static int run(const double* L, const double* Lbar, double* Kbar, int M, hipStream_t st) {
+    constexpr int W = K + 1;
+    int cap = (160 * 1024) / (16 * W);                // columns of both arrays the LDS holds
+    int seg = M <= cap ? (M + W - 1) / W : (cap - W) / W;       // one segment when everything fits, else cap - (k+1) columns per segment
+    static const int seg_env = getenv("ASVGP_BAND_OPS_SEG_BLOCKS") ? atoi(getenv("ASVGP_BAND_OPS_SEG_BLOCKS")) : 0;     // (tests: short segments)
+    if (seg_env >= 2 && seg_env < seg) { seg = seg_env; cap = seg * W + W; }
+    else if (M <= cap) cap = M;
+    if (seg < 2) return 1;
+    const size_t bytes = sizeof(double) * 2 * (size_t)cap * W;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_cholesky_vjp_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
-    hipLaunchKernelGGL(band_cholesky_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, Lbar, Kbar, M);
+    hipLaunchKernelGGL(band_cholesky_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, Lbar, Kbar, M, seg, cap);
     return check_launch("cholesky_band_vjp (register window)");
   }
 };
@@ -965,8 +1047,8 @@ extern "C" int asvgp_cholesky_band_vjp(const double* L, const double* Lbar, doub
   const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
   const int use_lds = bytes <= 160 * 1024;
   static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
-  if (use_lds && !lds_off && M > 2 * (k + 1)) {                 // lane-uniform register window (round 4)
-    const int rcl = dispatch_k<CholVjpLdsLauncher>(k, L, Lbar, Kbar, (int)M, bytes, as_stream(stream));
+  if (!lds_off && M > 2 * (k + 1) && M < (1 << 30)) {           // lane-uniform register window (round 4), any M (segments)
+    const int rcl = dispatch_k<CholVjpLdsLauncher>(k, L, Lbar, Kbar, (int)M, as_stream(stream));
     if (rcl != 1) return rcl;
   }
   if (use_lds && (k + 1) * (k + 1) <= 64) {                     // wave-parallel form
@@ -989,8 +1071,8 @@ extern "C" int asvgp_inverse_from_cholesky_band_vjp(const double* L, const doubl
   const size_t bytes = sizeof(double) * 2 * (size_t)(k + 1) * (size_t)M;
   const int use_lds = bytes <= 160 * 1024;
   static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
-  if (use_lds && !lds_off && M > 2 * (k + 1)) {                 // lane-uniform register window (round 4)
-    const int rcl = dispatch_k<TakaVjpLdsLauncher>(k, L, S, Sbar, Lbar, (int)M, bytes, as_stream(stream));
+  if (!lds_off && M > 2 * (k + 1) && M < (1 << 30)) {           // lane-uniform register windows on two waves (round 4), any M (segments)
+    const int rcl = dispatch_k<TakaVjpLdsLauncher>(k, L, S, Sbar, Lbar, (int)M, as_stream(stream));
     if (rcl != 1) return rcl;
   }
   if (use_lds && (k + 1) * (k + 1) <= 64) {                     // wave-parallel form

@@ -1649,6 +1649,37 @@ def test_config3_n10m_m4096_matern52_single_gpu(A):
     np.testing.assert_allclose(r[1:4], ge, rtol=5e-6)       # (1.6e-6 for every elimination order, the sequential one included: cond 1e9)
 
 
+@pytest.mark.parametrize("M,k", [(5000, 4), (4099, 4), (2100, 6), (6001, 2), (1500, 8)])
+def test_operator_vjps_beyond_the_lds_capacity_walk_the_band_in_segments(A, M, k):
+    """The two adjoint recurrences (gradients banded_matrices registers for cholesky_band / inverse_from_cholesky_band, gpr.py:56-59) keep
+    their state in registers and stage their inputs through the LDS a segment of columns at a time, so M is not limited by the 160 KB
+    (BASELINE config 3: M = 4096): C-ABI VJPs against the oracle's adjoint sweeps for sizes of 2-4 segments and k = 8 (wave-parallel
+    / sequential fallbacks of the inverse's adjoint)."""
+    from asvgp_amd import banded as Bd
+    rng = np.random.default_rng(M + k)
+    lower = np.zeros((k + 1, M))
+    for d in range(k + 1):
+        lower[d, :M - d] = rng.normal(size=M - d) * (0.3 ** d)
+    dom = np.sum(np.abs(lower[1:]), axis=0)
+    for d in range(1, k + 1):
+        dom[d:] += np.abs(lower[d, :M - d])
+    lower[0] = np.abs(lower[0]) + dom + 0.5                  # strictly diagonally dominant: positive definite
+    L = O.cholesky_band(lower)
+    S = O.inverse_from_cholesky_band(L)
+    Lbar, Sbar = np.zeros((k + 1, M)), np.zeros((k + 1, M))
+    for d in range(k + 1):
+        Lbar[d, :M - d] = rng.normal(size=M - d)
+        Sbar[d, :M - d] = rng.normal(size=M - d)
+    Kt = dev(lower).requires_grad_(True)
+    (Bd.cholesky_band(Kt) * dev(Lbar)).sum().backward()
+    ref = O.cholesky_band_vjp(L, Lbar)
+    assert np.max(np.abs(Kt.grad.cpu().numpy() - ref)) <= 1e-11 * np.max(np.abs(ref))
+    Lt = dev(L).requires_grad_(True)
+    (Bd.inverse_from_cholesky_band(Lt) * dev(Sbar)).sum().backward()
+    ref = O.inverse_from_cholesky_band_vjp(L, S, Sbar)
+    assert np.max(np.abs(Lt.grad.cpu().numpy() - ref)) <= 1e-11 * np.max(np.abs(ref))
+
+
 def test_operator_vjps_vs_oracle_and_reference_style_bound_backpropagates(A):
     """banded_matrices registers gradients for cholesky_band, inverse_from_cholesky_band, solve_triang_mat and product_band_band; the
     reference's optimiser differentiates GPR_1d.elbo through them (gpr.py:56-87, example.py:31-32).  (i) each C-ABI VJP against the
