@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void cholesky_band_kernel(const double* A, doub
   cholesky_sweep<double, K, false>(BandPtr<double>{A, nullptr}, BandOut<double>{L, nullptr}, M, nullptr, nullptr, info);
 }
 // ---------------------------------------------------------------------------------------------------------
-// The two operator recurrences with the WHOLE band in the LDS (round 4; M (k+1) doubles <= 156 KB: M <= 4000 at k = 4).
+// The two operator recurrences with the band in the LDS (round 4; M (k+1) doubles <= 156 KB - M <= 4000 at k = 4 - in one piece, in segments beyond).
 // The register-window sweeps above keep row i on lane i mod (k+1) and pay ~500 instructions per column for v_readlane traffic with
 // run-time lane indices and lane-select chains (1.06 / 0.60 ms at M = 2048).  Here the band is staged into the LDS by the whole
 // workgroup (coalesced), ONE wave then runs the recurrence with every lane holding the same (k+1) x (k+1) register window - all
@@ -40,136 +40,164 @@ __global__ __launch_bounds__(64) void cholesky_band_kernel(const double* A, doub
 // the result goes back to the LDS and the workgroup stores it coalesced.  What is left per column is the dependent chain itself
 // (rsqrt -> scale -> the next pivot's update): ~35 instructions.
 // ---------------------------------------------------------------------------------------------------------
+// Any M: the columns are walked in SEGMENTS of `seg_blocks` blocks of k+1 columns; a segment's columns (+ the k+1 behind it, which enter
+// the window while it is walked) are staged into the LDS by the whole workgroup, the window registers carry over from segment to segment,
+// the segment's columns of the factor leave through the LDS.  M (k+1) 8 B <= 160 KB is one segment.
 template <int K>
-__global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __restrict__ A, double* __restrict__ L, int M, int* __restrict__ info) {
-  extern __shared__ double bs_lds[];                  // [M][K+1], a column's k+1 entries side by side (two-address LDS instructions: 3 per column
-                                                      // instead of 5 - a lone wave pays ~8 cycles per instruction of any kind); overwritten by the factor
+__global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __restrict__ A, double* __restrict__ L, int M, int* __restrict__ info,
+                                                                int seg_blocks) {
+  extern __shared__ double bs_lds[];                  // [column - c0][K+1], a column's k+1 entries side by side (two-address LDS instructions: 3 per
+                                                      // column instead of 5); overwritten by the factor column by column
+  constexpr int W = K + 1;
   const int tid = threadIdx.x;
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c < M; c += blockDim.x) bs_lds[(long)c * (K + 1) + d] = A[(long)d * M + c];
-  __syncthreads();
-  if (tid < 64) {
-    double w[K + 1][K + 1];                           // w[c][d]: entry (j + c + d, j + c) of the matrix as updated so far (window of k+1 columns)
+  double w[W][W];                                     // w[c][d]: entry (j + c + d, j + c) of the matrix as updated so far (window of k+1 columns)
 #pragma unroll
-    for (int c = 0; c <= K; ++c)
+  for (int c = 0; c <= K; ++c)
 #pragma unroll
-      for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? bs_lds[(long)c * (K + 1) + d] : 0.0;
-    int bad = 0;
-    // one column; CHECK = false: every row j + d and the column j + k + 1 exist (no bounds tests, no branches in the block of k+1 columns)
-    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
-      constexpr int jm = decltype(jm_c)::value;
-      constexpr bool CHECK = decltype(check_c)::value;
-      const double piv = w[jm][0];
-      bad = (!(piv > 0.0) && !bad) ? j + 1 : bad;
-      double y = __builtin_amdgcn_rsq(piv);           // 1 / sqrt(piv): two Newton steps (<= 2e-16 relative)
-      const double hh = 0.5 * piv;
-      y = fma(y, fma(-hh * y, y, 0.5), y);
-      y = fma(y, fma(-hh * y, y, 0.5), y);
-      double l[K + 1];
-      {
-        const double g = piv * y;                     // sqrt(piv), one correction
-        l[0] = fma(fma(-g, g, piv), 0.5 * y, g);
+    for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? A[(long)d * M + (c < M ? c : 0)] : 0.0;
+  int bad = 0;
+  const int nblk = (M + W - 1) / W;
+  for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {
+    const int b1 = b0 + seg_blocks < nblk ? b0 + seg_blocks : nblk;
+    const int c0 = b0 * W, c1 = b1 * W < M ? b1 * W : M;
+    const int lend = c1 + W < M ? c1 + W : M;         // staged columns [c0, lend)
+    for (int d = 0; d <= K; ++d)
+      for (int c = c0 + tid; c < lend; c += blockDim.x) bs_lds[(long)(c - c0) * W + d] = A[(long)d * M + c];
+    __syncthreads();
+    if (tid < 64) {
+      // one column; CHECK = false: every row j + d and the column j + k + 1 exist (no bounds tests, no branches in the block of k+1 columns)
+      auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+        constexpr int jm = decltype(jm_c)::value;
+        constexpr bool CHECK = decltype(check_c)::value;
+        const double piv = w[jm][0];
+        bad = (!(piv > 0.0) && !bad) ? j + 1 : bad;
+        double y = __builtin_amdgcn_rsq(piv);         // 1 / sqrt(piv): two Newton steps (<= 2e-16 relative)
+        const double hh = 0.5 * piv;
+        y = fma(y, fma(-hh * y, y, 0.5), y);
+        y = fma(y, fma(-hh * y, y, 0.5), y);
+        double l[W];
+        {
+          const double g = piv * y;                   // sqrt(piv), one correction
+          l[0] = fma(fma(-g, g, piv), 0.5 * y, g);
+        }
+#pragma unroll
+        for (int d = 1; d <= K; ++d) l[d] = (!CHECK || j + d < M) ? w[jm][d] * y : 0.0;
+#pragma unroll
+        for (int c = 1; c <= K; ++c)                  // the k columns behind it
+#pragma unroll
+          for (int d = 0; d + c <= K; ++d) w[(jm + c) % W][d] = fma(-l[c + d], l[c], w[(jm + c) % W][d]);
+#pragma unroll
+        for (int d = 0; d <= K; ++d) bs_lds[(long)(j - c0) * W + d] = l[d];     // (every lane: the same value to the same address)
+        const int jn = j + K + 1;                     // the window slot takes column j + k + 1 (untouched so far, never the address just written)
+#pragma unroll
+        for (int d = 0; d <= K; ++d) w[jm][d] = (!CHECK || jn < M) ? bs_lds[(long)((!CHECK || jn < M) ? jn - c0 : 0) * W + d] : 0.0;
+      };
+      int jb = c0;
+      for (; jb < c1 && jb + 2 * K + 1 < M; jb += W) {        // full blocks: unrolled k+1 times, every window index a compile-time constant
+        [&]<int... JM>(std::integer_sequence<int, JM...>) { (column(jb + JM, std::integral_constant<int, JM>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
       }
-#pragma unroll
-      for (int d = 1; d <= K; ++d) l[d] = (!CHECK || j + d < M) ? w[jm][d] * y : 0.0;
-#pragma unroll
-      for (int c = 1; c <= K; ++c)                    // the k columns behind it
-#pragma unroll
-        for (int d = 0; d + c <= K; ++d) w[(jm + c) % (K + 1)][d] = fma(-l[c + d], l[c], w[(jm + c) % (K + 1)][d]);
-#pragma unroll
-      for (int d = 0; d <= K; ++d) bs_lds[(long)j * (K + 1) + d] = l[d];      // (every lane: the same value to the same address)
-      const int jn = j + K + 1;                       // the window slot takes column j + k + 1 (untouched so far, never the address just written)
-#pragma unroll
-      for (int d = 0; d <= K; ++d) w[jm][d] = (!CHECK || jn < M) ? bs_lds[(long)jn * (K + 1) + d] : 0.0;
-    };
-    int jb = 0;
-    for (; jb + 2 * K + 1 < M; jb += K + 1) {         // full blocks: unrolled k+1 times, every window index a compile-time constant
-      [&]<int... JM>(std::integer_sequence<int, JM...>) { (column(jb + JM, std::integral_constant<int, JM>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K + 1>{});
+      for (; jb < c1; jb += W) {
+        [&]<int... JM>(std::integer_sequence<int, JM...>) { ((jb + JM < M ? column(jb + JM, std::integral_constant<int, JM>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+      }
     }
-    for (; jb < M; jb += K + 1) {
-      [&]<int... JM>(std::integer_sequence<int, JM...>) { ((jb + JM < M ? column(jb + JM, std::integral_constant<int, JM>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K + 1>{});
-    }
-    if (info && tid == 0) *info = bad;
+    __syncthreads();
+    for (int d = 0; d <= K; ++d)
+      for (int c = c0 + tid; c < c1; c += blockDim.x) L[(long)d * M + c] = bs_lds[(long)(c - c0) * W + d];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c < M; c += blockDim.x) L[(long)d * M + c] = bs_lds[(long)c * (K + 1) + d];
+  if (info && tid == 0) *info = bad;
 }
 
 // S = band((L L^T)^-1) backwards, the factor in the LDS and overwritten column by column:
 //   S(i, j) = ([i = j] / L_jj - sum_{p = j+1 .. j+k} L(p, j) S(max(p, i), min(p, i))) / L_jj,   i = j+k .. j.
 // Every lane holds the symmetric k x k window S(j+1 .. j+k, j+1 .. j+k) in registers (column c in slot c mod k: the new column j takes
 // the slot of column j + k, which is read for the last time while column j is formed); the loop is unrolled k times.
+// Any M: segments of `seg_blocks` blocks of k columns from the top, a segment's columns of L (+ the one below it, read ahead) in the LDS.
 template <int K>
-__global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __restrict__ L, double* __restrict__ S, int M) {
-  extern __shared__ double bs_lds[];                  // [M][K+1] (as above)
+__global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __restrict__ L, double* __restrict__ S, int M, int seg_blocks) {
+  extern __shared__ double bs_lds[];                  // [column - lbase][K+1] (as above)
+  constexpr int W = K + 1;
   const int tid = threadIdx.x;
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c < M; c += blockDim.x) bs_lds[(long)c * (K + 1) + d] = L[(long)d * M + c];
-  __syncthreads();
-  if (tid < 64) {
-    double sw[K][K];                                  // sw[a][b] = S(row in slot a, column in slot b), both orders kept
+  double sw[K][K];                                    // sw[a][b] = S(row in slot a, column in slot b), both orders kept
 #pragma unroll
-    for (int a = 0; a < K; ++a)
+  for (int a = 0; a < K; ++a)
 #pragma unroll
-      for (int b = 0; b < K; ++b) sw[a][b] = 0.0;
-    // column j - 1 of L and its reciprocal diagonal are fetched while column j is formed (L is only read: nothing on the dependent
-    // chain, but the LDS read could not move above the stores of the column before it, nor the reciprocal above the read)
-    double ln[K + 1], invn;
-    auto fetch = [&](int jn) __attribute__((always_inline)) {
-      const int jc = jn >= 0 ? jn : 0;
+    for (int b = 0; b < K; ++b) sw[a][b] = 0.0;
+  // column j - 1 of L and its reciprocal diagonal are fetched while column j is formed (L is only read: nothing on the dependent chain)
+  double ln[W], invn;
+  int lbase = 0;
+  auto fetch = [&](int jn) __attribute__((always_inline)) {      // (issued at the top of a column - the scheduler otherwise sinks the reads to
+    const int jc = jn >= 0 ? jn - lbase : 0;                     // their first use and the wave waits out the LDS latency every column)
 #pragma unroll
-      for (int d = 0; d <= K; ++d) ln[d] = bs_lds[(long)jc * (K + 1) + d];
-      invn = __builtin_amdgcn_rcp(ln[0]);             // 1 / L_jj: two Newton steps
-      invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
-      invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
-    };
-    fetch(M - 1);
-    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
-      constexpr int jm = decltype(jm_c)::value;       // j mod K
-      constexpr bool CHECK = decltype(check_c)::value;
-      double l[K + 1];
+    for (int d = 0; d <= K; ++d) ln[d] = bs_lds[(long)jc * W + d];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto recip = [&]() __attribute__((always_inline)) {
+    invn = __builtin_amdgcn_rcp(ln[0]);               // 1 / L_jj: two Newton steps
+    invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+    invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+  };
 #pragma unroll
-      for (int d = 0; d <= K; ++d) l[d] = ln[d];
-      if (CHECK) {
+  for (int d = 0; d <= K; ++d) ln[d] = L[(long)d * M + M - 1];  // the first column walked, M - 1
+  invn = __builtin_amdgcn_rcp(ln[0]);
+  invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+  invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+  const int nblk = (M + K - 1) / K;
+  for (int b1 = nblk; b1 > 0; b1 -= seg_blocks) {
+    const int b0 = b1 - seg_blocks > 0 ? b1 - seg_blocks : 0;
+    const int c0 = b0 * K, c1 = b1 * K < M ? b1 * K : M;
+    lbase = c0 - 1 > 0 ? c0 - 1 : 0;
+    for (int d = 0; d <= K; ++d)
+      for (int c = lbase + tid; c < c1; c += blockDim.x) bs_lds[(long)(c - lbase) * W + d] = L[(long)d * M + c];
+    __syncthreads();
+    if (tid < 64) {
+      auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+        constexpr int jm = decltype(jm_c)::value;     // j mod K
+        constexpr bool CHECK = decltype(check_c)::value;
+        double l[W];
 #pragma unroll
-        for (int d = 1; d <= K; ++d) l[d] = (j + d < M) ? l[d] : 0.0;
+        for (int d = 0; d <= K; ++d) l[d] = ln[d];
+        if (CHECK) {
+#pragma unroll
+          for (int d = 1; d <= K; ++d) l[d] = (j + d < M) ? l[d] : 0.0;
+        }
+        const double inv = invn;
+        fetch(j - 1);
+        double sn[W];                                 // the new column: sn[d] = S(j + d, j)
+#pragma unroll
+        for (int d = K; d >= 1; --d) {                // i = j + d: sum over p = j+1 .. j+k of L(p, j) S(p, i), all from the window
+          double acc = 0.0;
+#pragma unroll
+          for (int c = 1; c <= K; ++c) acc = fma(-l[c], sw[(jm + c) % K][(jm + d) % K], acc);
+          sn[d] = acc * inv;
+        }
+        {
+          double acc = inv;                           // i = j: [i = j] / L_jj - sum_p L(p, j) S(p, j), with the entries just formed
+#pragma unroll
+          for (int c = 1; c <= K; ++c) acc = fma(-l[c], sn[c], acc);
+          sn[0] = acc * inv;
+        }
+#pragma unroll
+        for (int d = 0; d <= K; ++d) bs_lds[(long)(j - lbase) * W + d] = (!CHECK || j + d < M) ? sn[d] : 0.0;
+        // column j into the window: slot jm = j mod K (it held column j + K: (jm + K) % K), rows j .. j + K - 1
+        sw[jm][jm] = sn[0];
+#pragma unroll
+        for (int d = 1; d < K; ++d) { sw[(jm + d) % K][jm] = sn[d]; sw[jm][(jm + d) % K] = sn[d]; }
+        recip();
+      };
+      int jb = (b1 - 1) * K;
+      for (; jb >= c0 && jb + 2 * K > M; jb -= K) {   // the last blocks: rows beyond the matrix
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - 1 - JR) < M ? column(jb + (K - 1 - JR), std::integral_constant<int, K - 1 - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K>{});
       }
-      const double inv = invn;
-      fetch(j - 1);
-      double sn[K + 1];                               // the new column: sn[d] = S(j + d, j)
-#pragma unroll
-      for (int d = K; d >= 1; --d) {                  // i = j + d: sum over p = j+1 .. j+k of L(p, j) S(p, i), all from the window
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 1; c <= K; ++c) acc = fma(-l[c], sw[(jm + c) % K][(jm + d) % K], acc);
-        sn[d] = acc * inv;
+      for (; jb >= c0; jb -= K) {
+        [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + (K - 1 - JR), std::integral_constant<int, K - 1 - JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K>{});
       }
-      {
-        double acc = inv;                             // i = j: [i = j] / L_jj - sum_p L(p, j) S(p, j), with the entries just formed
-#pragma unroll
-        for (int c = 1; c <= K; ++c) acc = fma(-l[c], sn[c], acc);
-        sn[0] = acc * inv;
-      }
-#pragma unroll
-      for (int d = 0; d <= K; ++d) bs_lds[(long)j * (K + 1) + d] = (!CHECK || j + d < M) ? sn[d] : 0.0;
-      // column j into the window: slot jm = j mod K (it held column j + K: (jm + K) % K), rows j .. j + K - 1
-      sw[jm][jm] = sn[0];
-#pragma unroll
-      for (int d = 1; d < K; ++d) { sw[(jm + d) % K][jm] = sn[d]; sw[jm][(jm + d) % K] = sn[d]; }
-    };
-    const int top = ((M + K - 1) / K) * K;
-    int jb = top - K;
-    for (; jb >= 0 && jb + 2 * K > M; jb -= K) {      // the last blocks: rows beyond the matrix
-      [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + (K - 1 - JR) < M ? column(jb + (K - 1 - JR), std::integral_constant<int, K - 1 - JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, K>{});
     }
-    for (; jb >= 0; jb -= K) {
-      [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + (K - 1 - JR), std::integral_constant<int, K - 1 - JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, K>{});
-    }
+    __syncthreads();
+    for (int d = 0; d <= K; ++d)
+      for (int c = c0 + tid; c < c1; c += blockDim.x) S[(long)d * M + c] = bs_lds[(long)(c - lbase) * W + d];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int d = 0; d <= K; ++d)
-    for (int c = tid; c < M; c += blockDim.x) S[(long)d * M + c] = bs_lds[(long)c * (K + 1) + d];
 }
 
 template <int K>
@@ -292,11 +320,17 @@ static int dispatch_k(int k, Args... args) {
 }
 template <int K> struct CholLauncher {
   static int run(const double* A, double* L, int M, int* info, hipStream_t st) {
-    const size_t lds_bytes = sizeof(double) * (size_t)(K + 1) * (size_t)M;
+    constexpr int W = K + 1;
     static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;      // (0: the register-window sweep always)
-    if (!lds_off && lds_bytes <= 156 * 1024 && M > K + 1) {
+    static const int seg_env = getenv("ASVGP_BAND_OPS_SEG_BLOCKS") ? atoi(getenv("ASVGP_BAND_OPS_SEG_BLOCKS")) : 0;     // (tests: short segments)
+    if (!lds_off && M > K + 1 && M < (1 << 30)) {
+      int cap = (156 * 1024) / (8 * W);               // columns the LDS holds
+      int seg = M <= cap ? (M + W - 1) / W : (cap - W) / W;     // one segment when the band fits, else cap - (k+1) columns per segment
+      if (seg_env >= 1 && seg_env < seg) { seg = seg_env; cap = seg * W + W; }
+      else if (M <= cap) cap = M;
+      const size_t lds_bytes = sizeof(double) * (size_t)W * (size_t)cap;
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_band_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess) {
-        hipLaunchKernelGGL(cholesky_band_lds_kernel<K>, dim3(1), dim3(256), lds_bytes, st, A, L, M, info);
+        hipLaunchKernelGGL(cholesky_band_lds_kernel<K>, dim3(1), dim3(256), lds_bytes, st, A, L, M, info, seg);
         return check_launch("cholesky_band (band in the LDS)");
       }
       (void)hipGetLastError();
@@ -307,11 +341,17 @@ template <int K> struct CholLauncher {
 };
 template <int K> struct TakaLauncher {
   static int run(const double* L, double* S, int M, hipStream_t st) {
-    const size_t lds_bytes = sizeof(double) * (size_t)(K + 1) * (size_t)M;
+    constexpr int W = K + 1;
     static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
-    if (!lds_off && lds_bytes <= 156 * 1024 && M > 2 * K + 1) {
+    static const int seg_env = getenv("ASVGP_BAND_OPS_SEG_BLOCKS") ? atoi(getenv("ASVGP_BAND_OPS_SEG_BLOCKS")) : 0;     // (tests: short segments)
+    if (!lds_off && M > 2 * K + 1 && M < (1 << 30)) {
+      int cap = (156 * 1024) / (8 * W);               // columns the LDS holds
+      int seg = M <= cap ? (M + K - 1) / K : (cap - 1) / K;     // blocks of k columns: one segment when the band fits, else cap - 1 columns per segment
+      if (seg_env >= 1 && seg_env < seg) { seg = seg_env; cap = seg * K + 1; }
+      else if (M <= cap) cap = M;
+      const size_t lds_bytes = sizeof(double) * (size_t)W * (size_t)cap;
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(takahashi_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess) {
-        hipLaunchKernelGGL(takahashi_lds_kernel<K>, dim3(1), dim3(256), lds_bytes, st, L, S, M);
+        hipLaunchKernelGGL(takahashi_lds_kernel<K>, dim3(1), dim3(256), lds_bytes, st, L, S, M, seg);
         return check_launch("inverse_from_cholesky_band (band in the LDS)");
       }
       (void)hipGetLastError();
@@ -433,7 +473,7 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
 // gradients for its TF ops).  The two recurrences are the adjoints of the column loops.  Single-thread sweeps (below) are the general
 // fallback (5.6 / 7.9 ms at M = 2048, k = 4); the wave-parallel forms further down take over whenever (k + 1)^2 <= 64 and the two
 // arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms; since round 4 the lane-uniform register-window forms at the end of this
-// section run first (0.31 / 0.39 ms; the forward operators: 0.25 / 0.25 ms).  The training path
+// section run first, for any M (0.25 / 0.35 ms; the forward operators: 0.25 / 0.24 ms).  The training path
 // of this library is still the fused asvgp_elbo_grad_1d (one launch, analytic gradient); these make a per-op binding usable.
 // ---------------------------------------------------------------------------------------------------------
 __device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
@@ -714,9 +754,9 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
         }
 #pragma unroll
         for (int d = 0; d <= K; ++d) Bs[(long)(j - lbase) * W + d] = kb[d];
-        const int pn = j - K - 1;                     // the slot takes column j - k - 1 (its incoming adjoint is still untouched in the LDS)
+        const int pn = j - K - 1;                     // the slot takes column j - k - 1 (its incoming adjoint is still untouched in the LDS;
 #pragma unroll
-        for (int d = 0; d <= K; ++d) {
+        for (int d = 0; d <= K; ++d) {                // reading it at the top of the column instead was measured: slower)
           wl[jm][d] = (!CHECK || pn >= 0) ? Ls[(long)(pn >= 0 ? pn - lbase : 0) * W + d] : 0.0;
           wb[jm][d] = (!CHECK || pn >= 0) ? Bs[(long)(pn >= 0 ? pn - lbase : 0) * W + d] : 0.0;
         }
@@ -810,6 +850,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         bn[b] = Bs[in ? (long)(rn - rbase) * W + (K - b) : 0];
         if (!in) bn[b] = 0.0;
       }
+      __builtin_amdgcn_sched_barrier(0);              // (reads issued here, not sunk to the end of the column)
       const double l0 = lc[jm][0];
       double inv = __builtin_amdgcn_rcp(l0);
       inv = fma(inv, fma(-l0, inv, 1.0), inv);
