@@ -31,6 +31,12 @@ template <int K>
 __global__ __launch_bounds__(64) void cholesky_band_kernel(const double* A, double* L, int M, int* info) {
   cholesky_sweep<double, K, false>(BandPtr<double>{A, nullptr}, BandOut<double>{L, nullptr}, M, nullptr, nullptr, info);
 }
+__device__ __forceinline__ double band_rcp(double x) {       // 1 / x: v_rcp_f64 + two Newton steps
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
 // ---------------------------------------------------------------------------------------------------------
 // The two operator recurrences with the band in the LDS (round 4; M (k+1) doubles <= 156 KB - M <= 4000 at k = 4 - in one piece, in segments beyond).
 // The register-window sweeps above keep row i on lane i mod (k+1) and pay ~500 instructions per column for v_readlane traffic with
@@ -55,7 +61,10 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
   for (int c = 0; c <= K; ++c)
 #pragma unroll
     for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? A[(long)d * M + (c < M ? c : 0)] : 0.0;
-  int bad = 0;
+  // A pivot that is not > 0 (or not finite) makes its own diagonal entry NaN and, through the k updates behind it, every later one: the
+  // sweep carries no test; the first column whose diagonal entry is not > 0 is found when the segments are stored (whole workgroup).
+  __shared__ int first_bad;
+  if (tid == 0) first_bad = 0x7fffffff;
   const int nblk = (M + W - 1) / W;
   for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {
     const int b1 = b0 + seg_blocks < nblk ? b0 + seg_blocks : nblk;
@@ -70,7 +79,6 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
         constexpr int jm = decltype(jm_c)::value;
         constexpr bool CHECK = decltype(check_c)::value;
         const double piv = w[jm][0];
-        bad = (!(piv > 0.0) && !bad) ? j + 1 : bad;
         double y = __builtin_amdgcn_rsq(piv);         // 1 / sqrt(piv): two Newton steps (<= 2e-16 relative)
         const double hh = 0.5 * piv;
         y = fma(y, fma(-hh * y, y, 0.5), y);
@@ -102,10 +110,14 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
     }
     __syncthreads();
     for (int d = 0; d <= K; ++d)
-      for (int c = c0 + tid; c < c1; c += blockDim.x) L[(long)d * M + c] = bs_lds[(long)(c - c0) * W + d];
+      for (int c = c0 + tid; c < c1; c += blockDim.x) {
+        const double v = bs_lds[(long)(c - c0) * W + d];
+        L[(long)d * M + c] = v;
+        if (d == 0 && !(v > 0.0)) atomicMin(&first_bad, c + 1);
+      }
     __syncthreads();
   }
-  if (info && tid == 0) *info = bad;
+  if (info && tid == 0) *info = first_bad == 0x7fffffff ? 0 : first_bad;
 }
 
 // S = band((L L^T)^-1) backwards, the factor in the LDS and overwritten column by column:
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
 #pragma unroll
     for (int b = 0; b < K; ++b) sw[a][b] = 0.0;
   // column j - 1 of L and its reciprocal diagonal are fetched while column j is formed (L is only read: nothing on the dependent chain)
-  double ln[W], invn;
+  double ln[W];
   int lbase = 0;
   auto fetch = [&](int jn) __attribute__((always_inline)) {      // (issued at the top of a column - the scheduler otherwise sinks the reads to
     const int jc = jn >= 0 ? jn - lbase : 0;                     // their first use and the wave waits out the LDS latency every column)
@@ -132,23 +144,26 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
     for (int d = 0; d <= K; ++d) ln[d] = bs_lds[(long)jc * W + d];
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto recip = [&]() __attribute__((always_inline)) {
-    invn = __builtin_amdgcn_rcp(ln[0]);               // 1 / L_jj: two Newton steps
-    invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
-    invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
-  };
 #pragma unroll
+  // a column of L enters the recurrence as  m_0 = 1 / L_jj^2,  m_d = -L(j + d, j) / L_jj:  S(j + d, j) = sum_c m_c S(j + c, j + d),
+  // S(j, j) = m_0 + sum_c m_c S(j + c, j) - formed at staging by the whole workgroup (per column 10 instructions off the single wave)
   for (int d = 0; d <= K; ++d) ln[d] = L[(long)d * M + M - 1];  // the first column walked, M - 1
-  invn = __builtin_amdgcn_rcp(ln[0]);
-  invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
-  invn = fma(invn, fma(-ln[0], invn, 1.0), invn);
+  {
+    const double inv = band_rcp(ln[0]);
+    ln[0] = inv * inv;
+#pragma unroll
+    for (int d = 1; d <= K; ++d) ln[d] = -ln[d] * inv;
+  }
   const int nblk = (M + K - 1) / K;
   for (int b1 = nblk; b1 > 0; b1 -= seg_blocks) {
     const int b0 = b1 - seg_blocks > 0 ? b1 - seg_blocks : 0;
     const int c0 = b0 * K, c1 = b1 * K < M ? b1 * K : M;
     lbase = c0 - 1 > 0 ? c0 - 1 : 0;
     for (int d = 0; d <= K; ++d)
-      for (int c = lbase + tid; c < c1; c += blockDim.x) bs_lds[(long)(c - lbase) * W + d] = L[(long)d * M + c];
+      for (int c = lbase + tid; c < c1; c += blockDim.x) {
+        const double inv = band_rcp(L[c]);
+        bs_lds[(long)(c - lbase) * W + d] = d == 0 ? inv * inv : -L[(long)d * M + c] * inv;
+      }
     __syncthreads();
     if (tid < 64) {
       auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
@@ -161,21 +176,20 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
 #pragma unroll
           for (int d = 1; d <= K; ++d) l[d] = (j + d < M) ? l[d] : 0.0;
         }
-        const double inv = invn;
         fetch(j - 1);
         double sn[W];                                 // the new column: sn[d] = S(j + d, j)
 #pragma unroll
-        for (int d = K; d >= 1; --d) {                // i = j + d: sum over p = j+1 .. j+k of L(p, j) S(p, i), all from the window
-          double acc = 0.0;
+        for (int d = K; d >= 1; --d) {                // i = j + d: sum over p = j+1 .. j+k of m_{p-j} S(p, i), all from the window
+          double acc = l[1] * sw[(jm + 1) % K][(jm + d) % K];
 #pragma unroll
-          for (int c = 1; c <= K; ++c) acc = fma(-l[c], sw[(jm + c) % K][(jm + d) % K], acc);
-          sn[d] = acc * inv;
+          for (int c = 2; c <= K; ++c) acc = fma(l[c], sw[(jm + c) % K][(jm + d) % K], acc);
+          sn[d] = acc;
         }
         {
-          double acc = inv;                           // i = j: [i = j] / L_jj - sum_p L(p, j) S(p, j), with the entries just formed
+          double acc = l[0];                          // i = j: 1 / L_jj^2 + sum_p m_{p-j} S(p, j), with the entries just formed
 #pragma unroll
-          for (int c = 1; c <= K; ++c) acc = fma(-l[c], sn[c], acc);
-          sn[0] = acc * inv;
+          for (int c = 1; c <= K; ++c) acc = fma(l[c], sn[c], acc);
+          sn[0] = acc;
         }
 #pragma unroll
         for (int d = 0; d <= K; ++d) bs_lds[(long)(j - lbase) * W + d] = (!CHECK || j + d < M) ? sn[d] : 0.0;
@@ -183,7 +197,6 @@ __global__ __launch_bounds__(256) void takahashi_lds_kernel(const double* __rest
         sw[jm][jm] = sn[0];
 #pragma unroll
         for (int d = 1; d < K; ++d) { sw[(jm + d) % K][jm] = sn[d]; sw[jm][(jm + d) % K] = sn[d]; }
-        recip();
       };
       int jb = (b1 - 1) * K;
       for (; jb >= c0 && jb + 2 * K > M; jb -= K) {   // the last blocks: rows beyond the matrix
@@ -473,7 +486,7 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
 // gradients for its TF ops).  The two recurrences are the adjoints of the column loops.  Single-thread sweeps (below) are the general
 // fallback (5.6 / 7.9 ms at M = 2048, k = 4); the wave-parallel forms further down take over whenever (k + 1)^2 <= 64 and the two
 // arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms; since round 4 the lane-uniform register-window forms at the end of this
-// section run first, for any M (0.25 / 0.35 ms; the forward operators: 0.25 / 0.24 ms).  The training path
+// section run first, for any M (0.22 / 0.32 ms; the forward operators: 0.22 / 0.20 ms).  The training path
 // of this library is still the fused asvgp_elbo_grad_1d (one launch, analytic gradient); these make a per-op binding usable.
 // ---------------------------------------------------------------------------------------------------------
 __device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
@@ -709,6 +722,7 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
             wl[sl][d] = (p >= 0) ? L[(long)d * M + (p >= 0 ? p : 0)] : 0.0;
             wb[sl][d] = (p >= 0) ? Lbar[(long)d * M + (p >= 0 ? p : 0)] : 0.0;
           }
+          wl[sl][0] = (p >= 0) ? band_rcp(wl[sl][0]) : 1.0;       // (entry 0 of a column of L is kept as 1 / L_pp: only ever a divisor)
         }
     }
   }
@@ -717,15 +731,17 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
     const int c0 = b0 * W, c1 = b1 * W < M ? b1 * W : M;
     const int lbase = c0 - W > 0 ? c0 - W : 0;        // first staged column
     for (int d = 0; d <= K; ++d)
-      for (int c = lbase + tid; c < c1; c += blockDim.x) { Ls[(long)(c - lbase) * W + d] = L[(long)d * M + c]; Bs[(long)(c - lbase) * W + d] = Lbar[(long)d * M + c]; }
+      for (int c = lbase + tid; c < c1; c += blockDim.x) {     // (the reciprocal diagonal formed here, by the whole workgroup)
+        const double v = L[(long)d * M + c];
+        Ls[(long)(c - lbase) * W + d] = d == 0 ? band_rcp(v) : v;
+        Bs[(long)(c - lbase) * W + d] = Lbar[(long)d * M + c];
+      }
     __syncthreads();
     if (tid < 64) {
       auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
         constexpr int jm = decltype(jm_c)::value;     // j mod (K+1)
         constexpr bool CHECK = decltype(check_c)::value;
-        double inv = __builtin_amdgcn_rcp(wl[jm][0]);
-        inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
-        inv = fma(inv, fma(-wl[jm][0], inv, 1.0), inv);
+        const double inv = wl[jm][0];
         double kb[W];
 #pragma unroll
         for (int d = K; d >= 0; --d) {                // i = j + d, descending
@@ -795,7 +811,8 @@ __global__ __launch_bounds__(256) void band_cholesky_vjp_lds_kernel(const double
 // windows, the blocks fetched ahead and the progress counter carry over.  Both waves and the two idle ones pass the same barriers.
 template <int K>
 __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const double* __restrict__ L, const double* __restrict__ S, const double* __restrict__ Sbar,
-                                                                     double* __restrict__ Lbar, int M, int seg_blocks, int cap_rows, int cap_fq) {
+                                                                     double* __restrict__ Lbar, double* __restrict__ work, int M, int seg_blocks, int cap_rows,
+                                                                     int cap_fq) {
   extern __shared__ double sh[];
   constexpr int W = K + 1;
   double* Bs = sh;                                    // incoming adjoint of S by ROWS: (r, r - d) at [(r - rbase) W + d] (a row enters the window at a time)
@@ -820,10 +837,14 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
       for (int c = c0 + tid; c < c1; c += blockDim.x) Lbar[(long)d * M + c] = (c + d < M) ? Fq[(long)(c - c0) * W + d] : 0.0;
   };
   if (tid == 0) *prog = 0;
+  // 1 / L_jj (wave 0) and 1 / L_jj^2 (wave 1) by the whole workgroup, into the caller's scratch: 5-6 instructions per column off each wave
+  for (int c = tid; c < M; c += blockDim.x) { const double inv = band_rcp(L[c]); work[c] = inv; work[(long)M + c] = inv * inv; }
+  __syncthreads();
   int vz = 0;
   asm volatile("" : "+v"(vz));                        // (an opaque zero: keeps the global loads on the vector memory counter, apart from the LDS reads)
   const double* Lv = L + vz;
   const double* Sv = S + vz;
+  const double* Wv = work + vz;
   if (tid < 64) {
     // ---------------- wave 0: the window of Sb, the factors
     double bw[W][W];
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 #pragma unroll
         for (int d = 0; d <= K; ++d) {
           const bool in = !CHECK || j0 + c + d < M;
-          lq[c][d] = Lv[in ? (long)d * M + j0 + c : 0];
+          lq[c][d] = d == 0 ? Wv[in ? j0 + c : 0] : Lv[in ? (long)d * M + j0 + c : 0];   // (entry 0: 1 / L_jj)
           if (!in) lq[c][d] = 0.0;
         }
     };
@@ -851,10 +872,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         if (!in) bn[b] = 0.0;
       }
       __builtin_amdgcn_sched_barrier(0);              // (reads issued here, not sunk to the end of the column)
-      const double l0 = lc[jm][0];
-      double inv = __builtin_amdgcn_rcp(l0);
-      inv = fma(inv, fma(-l0, inv, 1.0), inv);
-      inv = fma(inv, fma(-l0, inv, 1.0), inv);
+      const double inv = lc[jm][0];
 #pragma unroll
       for (int a = 0; a <= K; ++a) {                  // i = j + a
         const int rs = (jm + a) % W;
@@ -913,7 +931,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         sw[a][b] = Sv[in ? (long)(a - b) * M + b : 0];
         if (!in) sw[a][b] = 0.0;
       }
-    double sq[W][W], sc[W][W], dq[W], dc[W];          // the NEXT block: sq[c][b] = S(j + k + 1, j + 1 + b), dq[c] = L(j, j), j = jb + W + c
+    double sq[W][W], sc[W][W], dq[W], dc[W];          // the NEXT block: sq[c][b] = S(j + k + 1, j + 1 + b), dq[c] = 1 / L(j, j)^2, j = jb + W + c
     auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
       constexpr bool CHECK = decltype(check_c)::value;
 #pragma unroll
@@ -925,7 +943,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
           if (!inr) sq[c][b] = 0.0;
         }
         const bool ind = !CHECK || j0 + c < M;
-        dq[c] = Lv[ind ? j0 + c : 0];
+        dq[c] = Wv[(long)M + (ind ? j0 + c : 0)];
       }
     };
     auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
@@ -938,10 +956,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         accb[a] = Fq[rowok ? (long)(j - c0) * W + a : 0];
         if (!rowok) accb[a] = 0.0;
       }
-      const double l0 = dc[jm];
-      double inv = __builtin_amdgcn_rcp(l0);
-      inv = fma(inv, fma(-l0, inv, 1.0), inv);
-      inv = fma(inv, fma(-l0, inv, 1.0), inv);
+      const double inv2 = dc[jm];                     // 1 / L_jj^2
       double lb[W];
 #pragma unroll
       for (int d = 0; d <= K; ++d) lb[d] = 0.0;
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
       for (int a = 0; a <= K; ++a) {
         const int rs = (jm + a) % W;
         lb[0] = fma(-accb[a], sw[rs][jm], lb[0]);
-        if (a == 0) lb[0] = fma(-accb[a], inv * inv, lb[0]);
+        if (a == 0) lb[0] = fma(-accb[a], inv2, lb[0]);
 #pragma unroll
         for (int c = 1; c <= K; ++c) {
           const int hs = (jm + (c > a ? c : a)) % W, ls = (jm + (c > a ? a : c)) % W;
@@ -1002,7 +1017,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 }
 
 template <int K> struct TakaVjpLdsLauncher {
-  static int run(const double* L, const double* S, const double* Sbar, double* Lbar, int M, hipStream_t st) {
+  static int run(const double* L, const double* S, const double* Sbar, double* Lbar, double* work, int M, hipStream_t st) {
     if constexpr (K <= 6) {                           // (k = 7, 8: the windows and the blocks fetched ahead no longer fit the register file)
       constexpr int W = K + 1;
       const int nblk = (M + W - 1) / W;
@@ -1022,7 +1037,7 @@ template <int K> struct TakaVjpLdsLauncher {
       const size_t bytes = sizeof(double) * ((size_t)cap_rows * W + (size_t)cap_fq);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_takahashi_vjp_lds_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
-      hipLaunchKernelGGL(band_takahashi_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, S, Sbar, Lbar, M, seg, cap_rows, cap_fq);
+      hipLaunchKernelGGL(band_takahashi_vjp_lds_kernel<K>, dim3(1), dim3(256), bytes, st, L, S, Sbar, Lbar, work, M, seg, cap_rows, cap_fq);
       return check_launch("inverse_from_cholesky_band_vjp (register window)");
     } else {
       return 1;
@@ -1113,7 +1128,7 @@ extern "C" int asvgp_inverse_from_cholesky_band_vjp(const double* L, const doubl
   const int use_lds = bytes <= 160 * 1024;
   static const bool lds_off = getenv("ASVGP_BAND_OPS_LDS") && atoi(getenv("ASVGP_BAND_OPS_LDS")) == 0;
   if (!lds_off && M > 2 * (k + 1) && M < (1 << 30)) {           // lane-uniform register windows on two waves (round 4), any M (segments)
-    const int rcl = dispatch_k<TakaVjpLdsLauncher>(k, L, S, Sbar, Lbar, (int)M, as_stream(stream));
+    const int rcl = dispatch_k<TakaVjpLdsLauncher>(k, L, S, Sbar, Lbar, work, (int)M, as_stream(stream));
     if (rcl != 1) return rcl;
   }
   if (use_lds && (k + 1) * (k + 1) <= 64) {                     // wave-parallel form

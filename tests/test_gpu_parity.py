@@ -285,6 +285,30 @@ def test_cholesky_not_positive_definite_reports_column(A):
         O.cholesky_band(bad)
 
 
+@pytest.mark.parametrize("M,k,col", [(500, 4, 137), (500, 4, 0), (500, 4, 499), (5000, 4, 4321), (3000, 2, 2999), (1300, 8, 650)])
+def test_cholesky_not_positive_definite_column_of_the_streamed_kernel(A, M, k, col):
+    """The lane-uniform kernel carries no pivot test in its sweep: a pivot that is not > 0 turns the rest of the diagonal into NaN and the
+    first such column is found when the segments are stored.  Same report as the reference's op (LinAlgError at the first failing pivot):
+    a negative pivot, a NaN entry, first / interior / last column, one segment and several."""
+    from asvgp_amd import banded
+    rng = np.random.default_rng(M + k + col)
+    lower = np.zeros((k + 1, M))
+    for d in range(k + 1):
+        lower[d, :M - d] = rng.normal(size=M - d) * (0.3 ** d)
+    dom = np.sum(np.abs(lower[1:]), axis=0)
+    for d in range(1, k + 1):
+        dom[d:] += np.abs(lower[d, :M - d])
+    lower[0] = np.abs(lower[0]) + dom + 0.5
+    for poison in (-1.0, float("nan")):
+        bad = lower.copy()
+        bad[0, col] = poison
+        with pytest.raises(banded.NotPositiveDefiniteError) as ei:
+            banded.cholesky_band(dev(bad))
+        assert "column %d" % col in str(ei.value), str(ei.value)
+    L = banded.cholesky_band(dev(lower)).cpu().numpy()           # and the untouched matrix factors
+    assert np.max(np.abs(L - O.cholesky_band(lower))) <= 1e-13 * np.max(np.abs(L))
+
+
 # ------------------------------------------------------------------------------------------------ ELBO / gradient
 @pytest.fixture(scope="module")
 def S(golden_dir):
