@@ -1,5 +1,6 @@
-"""Randomised check of the operator kernels cholesky_band / inverse_from_cholesky_band (LDS-resident forms for M (k+1) doubles <= 156 KB, the
-register-window sweeps beyond) against the oracle's sweeps.  usage: python tests/sweeps/fuzz_band_ops.py [n_cases] [seed]"""
+"""Randomised check of the operator kernels cholesky_band / inverse_from_cholesky_band and of their adjoints (lane-uniform register-window
+kernels, the band streamed through the LDS in segments; ASVGP_BAND_OPS_SEG_BLOCKS=1..3 forces short segments) against the oracle's sweeps.
+usage: python tests/sweeps/fuzz_band_ops.py [n_cases] [seed]"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import asvgp_amd as A
