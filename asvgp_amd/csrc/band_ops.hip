@@ -486,7 +486,7 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
 // gradients for its TF ops).  The two recurrences are the adjoints of the column loops.  Single-thread sweeps (below) are the general
 // fallback (5.6 / 7.9 ms at M = 2048, k = 4); the wave-parallel forms further down take over whenever (k + 1)^2 <= 64 and the two
 // arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms; since round 4 the lane-uniform register-window forms at the end of this
-// section run first, for any M (0.22 / 0.32 ms; the forward operators: 0.22 / 0.20 ms).  The training path
+// section run first, for any M (0.22 / 0.29 ms; the forward operators: 0.22 / 0.20 ms).  The training path
 // of this library is still the fused asvgp_elbo_grad_1d (one launch, analytic gradient); these make a per-op binding usable.
 // ---------------------------------------------------------------------------------------------------------
 __device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
@@ -848,8 +848,10 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
   if (tid < 64) {
     // ---------------- wave 0: the window of Sb, the factors
     double bw[W][W];
-    double lq[W][W], lc[W][W];                        // lq: the NEXT block's columns, lq[c][d] = L(jb + W + c + d, jb + W + c)
-    auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
+    // two buffers of k+1 columns of L (entry [c][d] = L(j + d, j), j = block start + c; [c][0] = 1 / L_jj): one holds the block being walked,
+    // the other receives the next one; the roles alternate block by block (two blocks per loop trip: no register copies)
+    double lA[W][W], lB[W][W];
+    auto fetch = [&](int j0, auto check_c, auto& lq) __attribute__((always_inline)) {
       constexpr bool CHECK = decltype(check_c)::value;
 #pragma unroll
       for (int c = 0; c <= K; ++c)
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
           if (!in) lq[c][d] = 0.0;
         }
     };
-    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+    auto column = [&](int j, auto jm_c, auto check_c, auto& lc) __attribute__((always_inline)) {
       constexpr int jm = decltype(jm_c)::value;       // j mod (K+1)
       constexpr bool CHECK = decltype(check_c)::value;
       double bn[W];
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 #pragma unroll
       for (int b = 0; b <= K; ++b) bw[jm][(jm + 1 + b) % W] = bn[b];
     };
-    fetch(0, std::true_type{});
+    fetch(0, std::true_type{}, lA);
     for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {
       stage(b0);
       __syncthreads();
@@ -898,24 +900,32 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 #pragma unroll
           for (int b = 0; b <= K; ++b) bw[a][b] = (b <= a && a < M) ? Bs[(long)a * W + (a - b)] : 0.0;
       }
-      auto block = [&](int jb, auto check_c) __attribute__((always_inline)) {
+      auto block = [&](int jb, auto check_c, auto& lc, auto& lq) __attribute__((always_inline)) {
         constexpr bool CHECK = decltype(check_c)::value;
-#pragma unroll
-        for (int c = 0; c <= K; ++c)
-#pragma unroll
-          for (int d = 0; d <= K; ++d) lc[c][d] = lq[c][d];
-        fetch(jb + W, check_c);
+        fetch(jb + W, check_c, lq);
         if constexpr (CHECK) {
-          [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}, lc) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
         } else {
-          [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}, lc), ...); }(std::make_integer_sequence<int, W>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(prog, jb + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
+      // lA holds the block about to be walked whenever a loop is entered; an odd block at the end of a loop moves lB back into lA
+      auto walk = [&](int& jb, auto check_c, auto more) __attribute__((always_inline)) {
+        while (more(jb) && more(jb + W)) { block(jb, check_c, lA, lB); block(jb + W, check_c, lB, lA); jb += 2 * W; }
+        if (more(jb)) {
+          block(jb, check_c, lA, lB);
+          jb += W;
+#pragma unroll
+          for (int c = 0; c <= K; ++c)
+#pragma unroll
+            for (int d = 0; d <= K; ++d) lA[c][d] = lB[c][d];
+        }
+      };
       int jb = c0;
-      for (; jb < c1 && jb + 3 * K + 3 < M; jb += W) block(jb, std::false_type{});   // (rows up to jb + 3k + 2 are touched by the next block's loads)
-      for (; jb < c1; jb += W) block(jb, std::true_type{});
+      walk(jb, std::false_type{}, [&](int j) { return j < c1 && j + 3 * K + 3 < M; });   // (rows up to jb + 3k + 2 are touched by the next block's loads)
+      walk(jb, std::true_type{}, [&](int j) { return j < c1; });
       __syncthreads();
       copy_out();
       __syncthreads();
@@ -931,8 +941,10 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         sw[a][b] = Sv[in ? (long)(a - b) * M + b : 0];
         if (!in) sw[a][b] = 0.0;
       }
-    double sq[W][W], sc[W][W], dq[W], dc[W];          // the NEXT block: sq[c][b] = S(j + k + 1, j + 1 + b), dq[c] = 1 / L(j, j)^2, j = jb + W + c
-    auto fetch = [&](int j0, auto check_c) __attribute__((always_inline)) {
+    // two buffers of a block's entering rows and reciprocal diagonals ([c][b] = S(j + k + 1, j + 1 + b), [c] = 1 / L(j, j)^2, j = block start + c),
+    // alternating like wave 0's
+    double sA[W][W], sB[W][W], dA[W], dB[W];
+    auto fetch = [&](int j0, auto check_c, auto& sq, auto& dq) __attribute__((always_inline)) {
       constexpr bool CHECK = decltype(check_c)::value;
 #pragma unroll
       for (int c = 0; c <= K; ++c) {
@@ -946,7 +958,7 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
         dq[c] = Wv[(long)M + (ind ? j0 + c : 0)];
       }
     };
-    auto column = [&](int j, auto jm_c, auto check_c) __attribute__((always_inline)) {
+    auto column = [&](int j, auto jm_c, auto check_c, auto& sc, auto& dc) __attribute__((always_inline)) {
       constexpr int jm = decltype(jm_c)::value;
       constexpr bool CHECK = decltype(check_c)::value;
       double accb[W];
@@ -977,30 +989,37 @@ __global__ __launch_bounds__(256) void band_takahashi_vjp_lds_kernel(const doubl
 #pragma unroll
       for (int b = 0; b <= K; ++b) sw[jm][(jm + 1 + b) % W] = sc[jm][b];
     };
-    fetch(0, std::true_type{});
+    fetch(0, std::true_type{}, sA, dA);
     for (int b0 = 0; b0 < nblk; b0 += seg_blocks) {
       stage(b0);
       __syncthreads();
-      auto block = [&](int jb, auto check_c) __attribute__((always_inline)) {
+      auto block = [&](int jb, auto check_c, auto& sc, auto& dc, auto& sq, auto& dq) __attribute__((always_inline)) {
         constexpr bool CHECK = decltype(check_c)::value;
-#pragma unroll
-        for (int c = 0; c <= K; ++c) {
-          dc[c] = dq[c];
-#pragma unroll
-          for (int b = 0; b <= K; ++b) sc[c][b] = sq[c][b];
-        }
-        fetch(jb + W, check_c);
+        fetch(jb + W, check_c, sq, dq);
         while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + W) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if constexpr (CHECK) {
-          [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { ((jb + JR < M ? column(jb + JR, std::integral_constant<int, JR>{}, std::true_type{}, sc, dc) : (void)0), ...); }(std::make_integer_sequence<int, W>{});
         } else {
-          [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}), ...); }(std::make_integer_sequence<int, W>{});
+          [&]<int... JR>(std::integer_sequence<int, JR...>) { (column(jb + JR, std::integral_constant<int, JR>{}, std::false_type{}, sc, dc), ...); }(std::make_integer_sequence<int, W>{});
+        }
+      };
+      auto walk = [&](int& jb, auto check_c, auto more) __attribute__((always_inline)) {
+        while (more(jb) && more(jb + W)) { block(jb, check_c, sA, dA, sB, dB); block(jb + W, check_c, sB, dB, sA, dA); jb += 2 * W; }
+        if (more(jb)) {
+          block(jb, check_c, sA, dA, sB, dB);
+          jb += W;
+#pragma unroll
+          for (int c = 0; c <= K; ++c) {
+            dA[c] = dB[c];
+#pragma unroll
+            for (int b = 0; b <= K; ++b) sA[c][b] = sB[c][b];
+          }
         }
       };
       int jb = c0;
-      for (; jb < c1 && jb + 3 * K + 3 < M; jb += W) block(jb, std::false_type{});
-      for (; jb < c1; jb += W) block(jb, std::true_type{});
+      walk(jb, std::false_type{}, [&](int j) { return j < c1 && j + 3 * K + 3 < M; });
+      walk(jb, std::true_type{}, [&](int j) { return j < c1; });
       __syncthreads();
       copy_out();
       __syncthreads();

@@ -206,7 +206,7 @@ int asvgp_band_trace_sym(const double* S, const double* A, int64_t M, int k, dou
 /* Reverse mode (vector-Jacobian products) of the operators above - what banded_matrices registers as the gradients of its TF ops, so
  * that a per-op binding (INTEGRATION.md Level 2) can back-propagate through gpr.py:56-75.  Bands are lower bands (k+1, M); `work` is
  * (k+1) * M doubles of scratch (reciprocal diagonals of the inverse's adjoint; the sequential fallbacks' running adjoint).  The two recurrences run with their state in registers and
- * their inputs staged through the LDS a segment of columns at a time (any M; 0.22 / 0.32 ms at M = 2048, k = 4; the inverse's adjoint
+ * their inputs staged through the LDS a segment of columns at a time (any M; 0.22 / 0.29 ms at M = 2048, k = 4; the inverse's adjoint
  * for k <= 6, beyond that a wave-parallel form while 2 (k+1) M doubles fit the LDS, else a sequential sweep).  The training path of this
  * library is the fused asvgp_elbo_grad_1d.
  *   cholesky_band_vjp:              Kbar = d<Lbar, cholesky_band(K)> / dK          (over the stored lower-band entries)
