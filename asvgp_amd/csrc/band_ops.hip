@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
   for (int c = 0; c <= K; ++c)
 #pragma unroll
     for (int d = 0; d <= K; ++d) w[c][d] = (c < M) ? A[(long)d * M + (c < M ? c : 0)] : 0.0;
-  // A pivot that is not > 0 (or not finite) makes its own diagonal entry NaN and, through the k updates behind it, every later one: the
-  // sweep carries no test; the first column whose diagonal entry is not > 0 is found when the segments are stored (whole workgroup).
+  // A pivot that is not > 0 (or not finite) makes every later one NaN through the k updates behind it: the sweep carries no test; the
+  // first column whose pivot is not > 0 is found when the segments are stored (whole workgroup).
   __shared__ int first_bad;
   if (tid == 0) first_bad = 0x7fffffff;
   const int nblk = (M + W - 1) / W;
@@ -84,11 +84,8 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
         y = fma(y, fma(-hh * y, y, 0.5), y);
         y = fma(y, fma(-hh * y, y, 0.5), y);
         double l[W];
-        {
-          const double g = piv * y;                   // sqrt(piv), one correction
-          l[0] = fma(fma(-g, g, piv), 0.5 * y, g);
-        }
-#pragma unroll
+        l[0] = piv;                                   // (the diagonal entry leaves as the PIVOT: its square root is taken when the segment is stored,
+#pragma unroll                                        // by the whole workgroup - the recurrence only needs 1 / sqrt(piv))
         for (int d = 1; d <= K; ++d) l[d] = (!CHECK || j + d < M) ? w[jm][d] * y : 0.0;
 #pragma unroll
         for (int c = 1; c <= K; ++c)                  // the k columns behind it
@@ -111,9 +108,12 @@ __global__ __launch_bounds__(256) void cholesky_band_lds_kernel(const double* __
     __syncthreads();
     for (int d = 0; d <= K; ++d)
       for (int c = c0 + tid; c < c1; c += blockDim.x) {
-        const double v = bs_lds[(long)(c - c0) * W + d];
+        double v = bs_lds[(long)(c - c0) * W + d];
+        if (d == 0) {                                 // the pivot: not > 0 (or NaN) = not positive definite at this column
+          if (!(v > 0.0)) atomicMin(&first_bad, c + 1);
+          v = sqrt(v);
+        }
         L[(long)d * M + c] = v;
-        if (d == 0 && !(v > 0.0)) atomicMin(&first_bad, c + 1);
       }
     __syncthreads();
   }
@@ -486,7 +486,7 @@ extern "C" int asvgp_solve_triang_mat(const double* L, const double* B, double* 
 // gradients for its TF ops).  The two recurrences are the adjoints of the column loops.  Single-thread sweeps (below) are the general
 // fallback (5.6 / 7.9 ms at M = 2048, k = 4); the wave-parallel forms further down take over whenever (k + 1)^2 <= 64 and the two
 // arrays the recurrence walks fit the LDS: 0.85 / 1.09 ms; since round 4 the lane-uniform register-window forms at the end of this
-// section run first, for any M (0.22 / 0.29 ms; the forward operators: 0.22 / 0.20 ms).  The training path
+// section run first, for any M (0.22 / 0.29 ms; the forward operators: 0.21 / 0.20 ms).  The training path
 // of this library is still the fused asvgp_elbo_grad_1d (one launch, analytic gradient); these make a per-op binding usable.
 // ---------------------------------------------------------------------------------------------------------
 __device__ void chol_vjp_sweep(const double* L, double* Lb, double* Kb, int M, int k) {
